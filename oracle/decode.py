@@ -1,0 +1,110 @@
+"""Oracle (test infrastructure): RetinaDecoder / FCOSDecoder postprocess in NumPy.
+
+Restates simpleAICV/detection/decode.py: greedy class-agnostic NMS :45-102
+(python_nms and diou_python_nms), score filter / sort / top-n / pad :121-172,
+RetinaDecoder :201-271 (argmax class, box decode, int32 truncation),
+FCOSDecoder :293-364 (sqrt(cls*ctr) score, exp(ltrb) boxes).  `torch_nms`
+(torchvision) is absent in this image: parity unpinned, not restated.
+"""
+import numpy as np
+
+from . import anchors as _anchors
+
+F32 = np.float32
+
+
+def greedy_nms(boxes, nms_threshold=0.5, diou=False):
+    """Indices kept, boxes [N,4] fp32 already sorted by descending score."""
+    boxes = boxes.astype(F32)
+    wh = boxes[:, 2:4] - boxes[:, 0:2]
+    areas = np.maximum(wh[:, 0] * wh[:, 1], F32(0))
+    alive = np.arange(boxes.shape[0])
+    keep = []
+    while alive.size:
+        k = alive[0]
+        keep.append(k)
+        alive = alive[1:]
+        if alive.size == 0:
+            break
+        o = boxes[alive]
+        tl = np.maximum(boxes[k, 0:2], o[:, 0:2])
+        br = np.minimum(boxes[k, 2:4], o[:, 2:4])
+        s = np.maximum(br - tl, F32(0))
+        inter = s[:, 0] * s[:, 1]
+        union = np.maximum(areas[k] + areas[alive] - inter, F32(1e-4))
+        iou = inter / union
+        if diou:
+            etl = np.minimum(boxes[k, 0:2], o[:, 0:2])
+            ebr = np.maximum(boxes[k, 2:4], o[:, 2:4])
+            es = np.maximum(ebr - etl, F32(0))
+            c2 = np.maximum((es**2).sum(axis=1), F32(1e-4))
+            kc = (boxes[k, 2:4] + boxes[k, 0:2]) / F32(2)
+            oc = (o[:, 2:4] + o[:, 0:2]) / F32(2)
+            p2 = ((kc - oc)**2).sum(axis=1)
+            iou = iou - p2 / c2
+        alive = alive[iou < nms_threshold]
+    return np.asarray(keep, dtype=np.int64)
+
+
+def select_detections(scores, classes, boxes, max_object_num=100, min_score_threshold=0.05,
+                      topn=1000, nms_type='python_nms', nms_threshold=0.5):
+    """decode.py:121-172.  scores [B,N] f32, classes [B,N] int, boxes [B,N,4] int32."""
+    assert nms_type in ('python_nms', 'diou_python_nms')
+    B = scores.shape[0]
+    out_s = np.full((B, max_object_num), -1, dtype=F32)
+    out_c = np.full((B, max_object_num), -1, dtype=F32)
+    out_b = np.zeros((B, max_object_num, 4), dtype=F32)
+    for i in range(B):
+        m = scores[i] > min_score_threshold
+        s = scores[i][m].astype(F32)
+        c = classes[i][m].astype(F32)
+        b = boxes[i][m].astype(F32)
+        if s.shape[0] == 0:
+            continue
+        order = np.argsort(-s)[:topn]
+        s, c, b = s[order], c[order], b[order]
+        keep = greedy_nms(b, nms_threshold, diou=(nms_type == 'diou_python_nms'))
+        keep = keep[:max_object_num]
+        n = keep.shape[0]
+        out_s[i, :n], out_c[i, :n], out_b[i, :n] = s[keep], c[keep], b[keep]
+    return [out_s, out_c, out_b]
+
+
+def _flat(preds):
+    return np.concatenate([np.asarray(p, dtype=F32).reshape(p.shape[0], -1, p.shape[-1])
+                           for p in preds], axis=1)
+
+
+def retina_decode_boxes(reg, anchors):
+    """decode.py:251-271: fp32 decode then truncation toward zero to int32."""
+    awh = anchors[..., 2:4] - anchors[..., 0:2]
+    actr = anchors[..., 0:2] + F32(0.5) * awh
+    wh = np.exp(reg[..., 2:4]) * awh
+    ctr = reg[..., 0:2] * awh + actr
+    boxes = np.concatenate([ctr - F32(0.5) * wh, ctr + F32(0.5) * wh], axis=-1)
+    return boxes.astype(np.int32)
+
+
+def retina_decode(cls_preds, reg_preds, anchor_cfg=None, **kw):
+    """cls_preds: 5 arrays [B,H,W,A,C]; reg_preds: 5 arrays [B,H,W,A,4]."""
+    fs = [[p.shape[2], p.shape[1]] for p in cls_preds]
+    anc = _anchors.retina_anchors(fs, **(anchor_cfg or {}))
+    cls = _flat(cls_preds)
+    reg = _flat(reg_preds)
+    classes = np.argmax(cls, axis=2)
+    scores = np.take_along_axis(cls, classes[..., None], axis=2)[..., 0]
+    boxes = retina_decode_boxes(reg, anc[None])
+    return select_detections(scores, classes, boxes, **kw)
+
+
+def fcos_decode(cls_preds, reg_preds, ctr_preds, strides=_anchors.DEFAULT_STRIDES, **kw):
+    kw.setdefault('nms_threshold', 0.6)
+    fs = [[p.shape[2], p.shape[1]] for p in cls_preds]
+    pos = _anchors.fcos_positions(fs, strides)[None]
+    cls, reg, ctr = _flat(cls_preds), _flat(reg_preds), _flat(ctr_preds)
+    classes = np.argmax(cls, axis=2)
+    scores = np.take_along_axis(cls, classes[..., None], axis=2)[..., 0]
+    scores = np.sqrt(scores * ctr[..., 0])
+    e = np.exp(reg)
+    boxes = np.concatenate([pos - e[..., 0:2], pos + e[..., 2:4]], axis=2).astype(np.int32)
+    return select_detections(scores, classes, boxes, **kw)

@@ -1,0 +1,345 @@
+"""Generate tests/golden/* by running the REFERENCE itself on CPU (build container only).
+
+    python oracle/make_golden.py [section ...]
+
+The reference (/root/reference) is imported through oracle/import_reference.py;
+inputs and weights come from the portable generators in oracle/synth.py and
+oracle/model.py, so tests can regenerate the same inputs on the GPU box and
+compare against the expected outputs stored here.  Only data (inputs' seeds and
+expected outputs) is written -- no reference source travels.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import synth, model as omodel  # noqa: E402
+from oracle.import_reference import load_reference  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+S1 = (800, 1333)
+S2 = (1333, 1333)
+TINY = (96, 128)
+MID = (256, 320)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def digest(t, nsamp=512):
+    """Size-independent summary of a tensor: sum, abs-sum, strided samples."""
+    a = t.detach().cpu().numpy().astype(np.float64).reshape(-1)
+    step = max(1, a.size // nsamp)
+    return dict(sum=float(a.sum()), abssum=float(np.abs(a).sum()), n=int(a.size),
+                step=int(step), samples=a[::step][:nsamp].astype(np.float32))
+
+
+def synth_preds_retina(seed, B, H, W, num_classes=80, A=9):
+    fs = synth.feature_sizes(H, W)
+    cls, reg = [], []
+    for l, (fw, fh) in enumerate(fs):
+        c = synth.uniform(seed + 10 * l + 1, (B, fh, fw, A, num_classes))
+        c = (c**3).astype(np.float32)  # skewed towards 0 like real sigmoid outputs
+        flat = c.reshape(-1)
+        flat[0::9973] = 0.0          # clamp edges (losses.py:196)
+        flat[1::9973] = 1.0
+        flat[2::9973] = 5e-5
+        flat[3::9973] = 1.0 - 5e-5
+        cls.append(c)
+        reg.append(synth.normal(seed + 10 * l + 2, (B, fh, fw, A, 4), std=0.3))
+    return cls, reg
+
+
+def synth_preds_fcos(seed, B, H, W, num_classes=80):
+    fs = synth.feature_sizes(H, W)
+    cls, reg, ctr = [], [], []
+    for l, (fw, fh) in enumerate(fs):
+        c = (synth.uniform(seed + 10 * l + 1, (B, fh, fw, num_classes))**3).astype(np.float32)
+        flat = c.reshape(-1)
+        flat[0::9973] = 0.0
+        flat[1::9973] = 1.0
+        cls.append(c)
+        reg.append(synth.normal(seed + 10 * l + 2, (B, fh, fw, 4), std=0.5) + np.float32(3.0 + 0.7 * l))
+        t = synth.uniform(seed + 10 * l + 3, (B, fh, fw, 1))
+        t.reshape(-1)[0::997] = 0.0
+        t.reshape(-1)[1::997] = 1.0
+        ctr.append(t)
+    return cls, reg, ctr
+
+
+def annots_cases(H, W):
+    """name -> [B,100,5] annotation arrays incl. the edge cases of SURVEY.md 8c."""
+    cases = {}
+    for g in (1, 8, 100):
+        cases[f'g{g}'] = synth.annotations(100 + g, 2, H, W, boxes_per_image=g)
+    mixed = synth.annotations(555, 2, H, W, boxes_per_image=8)
+    mixed[1, :, :] = -1  # image 1 has no GT (losses.py:341-345)
+    cases['one_empty'] = mixed
+    deg = synth.annotations(777, 2, H, W, boxes_per_image=6)
+    deg[0, 0, 2:4] = deg[0, 0, 0:2]            # zero-area box
+    deg[0, 1, 0:4] = [-50., -40., 30., 35.]    # partly outside the image
+    deg[1, 2, 0:4] = [W - 20., H - 20., W + 60., H + 70.]
+    deg[1, 3, 0:4] = deg[1, 4, 0:4]            # duplicated GT -> IoU ties (first index wins)
+    cases['degenerate'] = deg
+    return cases
+
+
+# ----------------------------------------------------------------------------- sections
+def sec_contract(ref):
+    models, losses, decode = ref
+    out = {}
+    for name in ('resnet50_retinanet', 'resnet50_fcos'):
+        net = models.__dict__[name](num_classes=80)
+        sd = net.state_dict()
+        out[name] = dict(
+            keys=[[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in sd.items()],
+            params=[[k, list(v.shape)] for k, v in net.named_parameters()],
+            n_params=int(sum(p.numel() for p in net.parameters())),
+            one_dim_params=[k for k, v in net.named_parameters() if v.ndim == 1],
+        )
+        # the oracle state dict must load strictly into the reference model
+        osd = omodel.init_retinanet_state(0, fcos=name.endswith('fcos'))
+        missing = net.load_state_dict(osd, strict=True)
+        out[name]['oracle_state_loads_strict'] = True
+    json.dump(out, open(os.path.join(GOLD, 'contract.json'), 'w'))
+    print('contract ok')
+
+
+def sec_anchors(ref):
+    models, losses, decode = ref
+    from simpleAICV.detection.models.anchor import RetinaAnchors, FCOSPositions
+    ra, fp = RetinaAnchors(), FCOSPositions()
+    out = {}
+    meta = {}
+    for tag, (H, W) in (('S1', S1), ('S2', S2), ('TINY', TINY), ('MID', MID)):
+        fs = synth.feature_sizes(H, W)
+        lv = ra(fs)
+        flat = np.concatenate([a.reshape(-1, 4) for a in lv], 0)
+        pos = np.concatenate([p.reshape(-1, 2) for p in fp(fs)], 0)
+        meta[tag] = dict(feature_sizes=fs, n_anchors=int(flat.shape[0]), anchors_sha256=sha(flat),
+                         n_points=int(pos.shape[0]), points_sha256=sha(pos))
+        if tag in ('TINY',):
+            out['anchors_' + tag] = flat
+            out['points_' + tag] = pos
+        if tag == 'S1':
+            for l, a in enumerate(lv):
+                f = a.reshape(-1, 4)
+                out[f'S1_l{l}_first64'] = f[:64]
+                out[f'S1_l{l}_last64'] = f[-64:]
+    out['base_anchors'] = np.stack([ra.generate_base_anchors(a, ra.scales, ra.ratios) for a in ra.areas], 0)
+    # the feature sizes really are what the reference model produces (checked on TINY/MID in e2e)
+    np.savez_compressed(os.path.join(GOLD, 'anchors.npz'), **out)
+    json.dump(meta, open(os.path.join(GOLD, 'anchors.json'), 'w'))
+    print('anchors ok', {k: v['n_anchors'] for k, v in meta.items()})
+
+
+def sec_assign(ref):
+    models, losses, decode = ref
+    from simpleAICV.detection.models.anchor import RetinaAnchors, FCOSPositions
+    out, meta = {}, {}
+    for tag, (H, W) in (('TINY', TINY), ('MID', MID), ('S1', S1)):
+        fs = synth.feature_sizes(H, W)
+        anc = torch.tensor(np.concatenate([a.reshape(-1, 4) for a in RetinaAnchors()(fs)], 0))
+        for cname, ann in annots_cases(H, W).items():
+            ann_t = torch.tensor(ann)
+            for blt in ('SmoothL1', 'GIoU'):
+                crit = losses.__dict__['RetinaLoss'](box_loss_type=blt)
+                tg = crit.get_batch_anchors_annotations(anc.unsqueeze(0).repeat(2, 1, 1), ann_t).numpy()
+                key = f'retina_{tag}_{cname}_{blt}'
+                lab = tg[..., 4].astype(np.int8)
+                meta[key] = dict(label_sha256=sha(lab), npos=int((lab > 0).sum()),
+                                 nign=int((lab < 0).sum()), nneg=int((lab == 0).sum()))
+                if tag == 'TINY':
+                    out[key] = tg
+                else:
+                    posm = lab > 0
+                    meta[key]['pos_index_sha256'] = sha(np.nonzero(posm.reshape(-1))[0].astype(np.int64))
+                    out[key + '_postargets'] = tg[posm][:, :4]
+            # FCOS
+            crit = losses.__dict__['FCOSLoss']()
+            B = 2
+            cls = [torch.zeros(B, fh, fw, 80) for fw, fh in fs]
+            reg = [torch.zeros(B, fh, fw, 4) for fw, fh in fs]
+            ctr = [torch.zeros(B, fh, fw, 1) for fw, fh in fs]
+            pos = [torch.tensor(p).unsqueeze(0).repeat(B, 1, 1, 1) for p in FCOSPositions()(fs)]
+            _, _, _, tg = crit.get_batch_position_annotations(cls, reg, ctr, pos, ann_t)
+            tg = tg.numpy()
+            key = f'fcos_{tag}_{cname}'
+            lab = tg[..., 4].astype(np.int8)
+            meta[key] = dict(label_sha256=sha(lab), npos=int((lab > 0).sum()))
+            if tag == 'TINY':
+                out[key] = tg
+            else:
+                posm = lab > 0
+                out[key + '_postargets'] = tg[posm]
+    np.savez_compressed(os.path.join(GOLD, 'assign.npz'), **out)
+    json.dump(meta, open(os.path.join(GOLD, 'assign.json'), 'w'))
+    print('assign ok', len(out), 'arrays')
+
+
+def _loss_and_grads(crit, preds_np, ann):
+    preds = [[torch.tensor(p, requires_grad=True) for p in lv] for lv in preds_np]
+    ld = crit(preds, torch.tensor(ann))
+    rec = {k: float(v) for k, v in ld.items()}
+    total = sum(ld.values())
+    grads = None
+    if total.requires_grad:
+        total.backward()
+        grads = [[p.grad if p.grad is not None else torch.zeros_like(p) for p in lv] for lv in preds]
+    return rec, grads
+
+
+def sec_losses(ref):
+    models, losses, decode = ref
+    out, meta = {}, {}
+    for tag, (H, W) in (('TINY', TINY), ('MID', MID), ('S1', S1)):
+        cases = annots_cases(H, W)
+        cases['none'] = synth.annotations(1, 2, H, W, boxes_per_image=0)  # zero-positive branch
+        for cname, ann in cases.items():
+            if tag == 'S1' and cname not in ('g8', 'one_empty'):
+                continue
+            for blt in ('SmoothL1', 'GIoU', 'IoU', 'DIoU', 'CIoU', 'EIoU'):
+                if blt not in ('SmoothL1', 'GIoU') and (tag != 'TINY' or cname != 'g8'):
+                    continue
+                crit = losses.__dict__['RetinaLoss'](box_loss_type=blt)
+                cls, reg = synth_preds_retina(11, 2, H, W)
+                rec, grads = _loss_and_grads(crit, [cls, reg], ann)
+                key = f'retina_{tag}_{cname}_{blt}'
+                meta[key] = rec
+                meta[key]['has_grad'] = grads is not None
+                if grads is not None:
+                    for nm, gl in zip(('dcls', 'dreg'), grads):
+                        d = digest(torch.cat([g.reshape(-1) for g in gl]))
+                        out[f'{key}_{nm}_samples'] = d.pop('samples')
+                        meta[key][nm] = d
+            crit = losses.__dict__['FCOSLoss']()
+            cls, reg, ctr = synth_preds_fcos(13, 2, H, W)
+            rec, grads = _loss_and_grads(crit, [cls, reg, ctr], ann)
+            key = f'fcos_{tag}_{cname}'
+            meta[key] = rec
+            meta[key]['has_grad'] = grads is not None
+            if grads is not None:
+                for nm, gl in zip(('dcls', 'dreg', 'dctr'), grads):
+                    d = digest(torch.cat([g.reshape(-1) for g in gl]))
+                    out[f'{key}_{nm}_samples'] = d.pop('samples')
+                    meta[key][nm] = d
+    np.savez_compressed(os.path.join(GOLD, 'losses.npz'), **out)
+    json.dump(meta, open(os.path.join(GOLD, 'losses.json'), 'w'), indent=0)
+    print('losses ok', len(meta), 'cases')
+
+
+def synth_preds_decode(seed, B, H, W, fcos=False):
+    """Predictions with DISTINCT scores above threshold (argsort tie order is unpinned)."""
+    if fcos:
+        cls, reg, ctr = synth_preds_fcos(seed, B, H, W)
+        cls = [np.clip(c * 0.9 + 0.01, 0, 1).astype(np.float32) for c in cls]
+        return cls, reg, ctr
+    cls, reg = synth_preds_retina(seed, B, H, W)
+    # sparsify: most anchors below the 0.05 threshold, like a trained net
+    cls = [np.where(synth.uniform(seed + 99 + l, c.shape[:-1] + (1,)) < 0.03, c, c * 0.04).astype(np.float32)
+           for l, c in enumerate(cls)]
+    return cls, reg
+
+
+def sec_decode(ref):
+    models, losses, decode = ref
+    out, meta = {}, {}
+    for tag, (H, W) in (('TINY', TINY), ('MID', MID), ('S1', S1)):
+        for nms_type in ('python_nms', 'diou_python_nms'):
+            if tag == 'S1' and nms_type != 'python_nms':
+                continue
+            dec = decode.__dict__['RetinaDecoder'](nms_type=nms_type, nms_threshold=0.5)
+            cls, reg = synth_preds_decode(21, 2, H, W)
+            s, c, b = dec([[torch.tensor(x) for x in cls], [torch.tensor(x) for x in reg]])
+            key = f'retina_{tag}_{nms_type}'
+            out[key + '_scores'], out[key + '_classes'], out[key + '_boxes'] = s, c, b
+            meta[key] = dict(ndet=[int((s[i] >= 0).sum()) for i in range(s.shape[0])])
+            dec = decode.__dict__['FCOSDecoder'](nms_type=nms_type, nms_threshold=0.6)
+            cls, reg, ctr = synth_preds_decode(23, 2, H, W, fcos=True)
+            s, c, b = dec([[torch.tensor(x) for x in cls], [torch.tensor(x) for x in reg],
+                           [torch.tensor(x) for x in ctr]])
+            key = f'fcos_{tag}_{nms_type}'
+            out[key + '_scores'], out[key + '_classes'], out[key + '_boxes'] = s, c, b
+            meta[key] = dict(ndet=[int((s[i] >= 0).sum()) for i in range(s.shape[0])])
+    np.savez_compressed(os.path.join(GOLD, 'decode.npz'), **out)
+    json.dump(meta, open(os.path.join(GOLD, 'decode.json'), 'w'))
+    print('decode ok', meta)
+
+
+def _e2e(ref, name, H, W, fcos, box_loss_type='SmoothL1', ann_seed=3):
+    models, losses, decode = ref
+    torch.manual_seed(0)
+    net = models.__dict__['resnet50_fcos' if fcos else 'resnet50_retinanet'](num_classes=80)
+    net.load_state_dict(omodel.init_retinanet_state(0, fcos=fcos), strict=True)
+    net.train()
+    crit = losses.__dict__['FCOSLoss']() if fcos else losses.__dict__['RetinaLoss'](box_loss_type=box_loss_type)
+    x = torch.tensor(synth.images(5, 2, H, W))
+    ann = torch.tensor(synth.annotations(ann_seed, 2, H, W, boxes_per_image=8))
+    outs = net(x)
+    ld = crit(outs, ann)
+    total = sum(ld.values())
+    total.backward()
+    meta = dict(loss={k: float(v) for k, v in ld.items()},
+                feature_sizes=[[o.shape[2], o.shape[1]] for o in outs[0]])
+    arrs = {}
+    for gi, grp in enumerate(outs):
+        for l, o in enumerate(grp):
+            d = digest(o, 256)
+            arrs[f'{name}_out{gi}_l{l}_samples'] = d.pop('samples')
+            meta[f'out{gi}_l{l}'] = d
+    gn = {k: float(p.grad.double().norm()) for k, p in net.named_parameters()}
+    meta['grad_norm'] = gn
+    # a few full small gradients and the BN running stats after one training forward
+    for k in ('backbone.conv1.layer.1.weight', 'backbone.layer1.0.conv1.layer.1.bias', 'fpn.P5_1.bias',
+              'backbone.layer4.2.conv3.layer.1.weight'):
+        arrs[f'{name}_grad_{k}'] = dict(net.named_parameters())[k].grad.numpy()
+    sd = net.state_dict()
+    for k in ('backbone.conv1.layer.1.running_mean', 'backbone.conv1.layer.1.running_var',
+              'backbone.layer3.5.conv3.layer.1.running_var'):
+        arrs[f'{name}_buf_{k}'] = sd[k].numpy()
+    return meta, arrs
+
+
+def sec_e2e(ref):
+    out, meta = {}, {}
+    for name, (H, W), fcos, blt in (('retina_TINY', TINY, False, 'SmoothL1'),
+                                    ('retina_MID', MID, False, 'SmoothL1'),
+                                    ('retina_MID_giou', MID, False, 'GIoU'),
+                                    ('fcos_TINY', TINY, True, None), ('fcos_MID', MID, True, None)):
+        m, a = _e2e(ref, name, H, W, fcos, blt)
+        assert m['feature_sizes'] == synth.feature_sizes(H, W), (m['feature_sizes'], synth.feature_sizes(H, W))
+        meta[name] = m
+        out.update(a)
+        print(name, m['loss'])
+    np.savez_compressed(os.path.join(GOLD, 'e2e.npz'), **out)
+    json.dump(meta, open(os.path.join(GOLD, 'e2e.json'), 'w'), indent=0)
+
+
+def sec_e2e_s1(ref):
+    out, meta = {}, {}
+    for name, fcos in (('retina_S1', False), ('fcos_S1', True)):
+        m, a = _e2e(ref, name, S1[0], S1[1], fcos)
+        assert m['feature_sizes'] == synth.feature_sizes(*S1)
+        meta[name] = m
+        out.update(a)
+        print(name, m['loss'])
+    np.savez_compressed(os.path.join(GOLD, 'e2e_s1.npz'), **out)
+    json.dump(meta, open(os.path.join(GOLD, 'e2e_s1.json'), 'w'), indent=0)
+
+
+SECTIONS = dict(contract=sec_contract, anchors=sec_anchors, assign=sec_assign, losses=sec_losses,
+                decode=sec_decode, e2e=sec_e2e, e2e_s1=sec_e2e_s1)
+
+if __name__ == '__main__':
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    ref = load_reference()
+    for s in (sys.argv[1:] or list(SECTIONS)):
+        SECTIONS[s](ref)

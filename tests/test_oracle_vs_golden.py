@@ -1,0 +1,173 @@
+"""Pins the CPU oracle (oracle/) against outputs of the REFERENCE itself.
+
+The fixtures in tests/golden/ were produced by oracle/make_golden.py, which runs
+the reference code from /root/reference on CPU.  These tests run anywhere (no GPU,
+no reference) and establish that the restatement equals the reference: bit-exact
+for anchors / labels / matched indices / detections, <=1e-6 for box targets,
+1e-5 relative for fp32 losses and gradients.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import anchors as oanchors, assign as oassign, decode as odecode, losses as olosses, synth
+from tests import golden_inputs as gi
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope='module')
+def G(golden_dir):
+    class _G:
+        pass
+    g = _G()
+    for name in ('anchors', 'assign', 'losses', 'decode'):
+        setattr(g, name, np.load(os.path.join(golden_dir, name + '.npz')))
+        setattr(g, name + '_meta', json.load(open(os.path.join(golden_dir, name + '.json'))))
+    return g
+
+
+def test_feature_sizes_match_reference_model(golden_dir):
+    e2e = json.load(open(os.path.join(golden_dir, 'e2e.json')))
+    assert e2e['retina_TINY']['feature_sizes'] == synth.feature_sizes(*gi.TINY)
+    assert e2e['retina_MID']['feature_sizes'] == synth.feature_sizes(*gi.MID)
+    assert synth.feature_sizes(*gi.S1) == [[167, 100], [84, 50], [42, 25], [21, 13], [11, 7]]
+
+
+def test_base_anchors_bit_exact(G):
+    ref = G.anchors['base_anchors']
+    for l, area in enumerate(oanchors.DEFAULT_AREAS):
+        got = oanchors.base_anchors(area, oanchors.DEFAULT_SCALES, oanchors.DEFAULT_RATIOS)
+        assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), ref[l].view(np.uint32))
+
+
+@pytest.mark.parametrize('tag', ['S1', 'S2', 'TINY', 'MID'])
+def test_anchors_and_points_sha(G, tag):
+    m = G.anchors_meta[tag]
+    fs = synth.feature_sizes(*gi.SHAPES[tag])
+    assert fs == m['feature_sizes']
+    a = oanchors.retina_anchors(fs)
+    assert a.shape[0] == m['n_anchors'] and sha(a) == m['anchors_sha256']
+    p = oanchors.fcos_positions(fs)
+    assert p.shape[0] == m['n_points'] and sha(p) == m['points_sha256']
+
+
+def test_anchor_samples(G):
+    lv = oanchors.retina_anchors_per_level(synth.feature_sizes(*gi.S1))
+    for l, a in enumerate(lv):
+        f = a.reshape(-1, 4)
+        assert np.array_equal(f[:64], G.anchors[f'S1_l{l}_first64'])
+        assert np.array_equal(f[-64:], G.anchors[f'S1_l{l}_last64'])
+    assert np.array_equal(oanchors.retina_anchors(synth.feature_sizes(*gi.TINY)), G.anchors['anchors_TINY'])
+
+
+@pytest.mark.parametrize('tag', ['TINY', 'MID', 'S1'])
+def test_retina_assign(G, tag):
+    H, W = gi.SHAPES[tag]
+    anc = oanchors.retina_anchors(synth.feature_sizes(H, W))
+    for cname, ann in gi.annots_cases(H, W).items():
+        for blt in ('SmoothL1', 'GIoU'):
+            key = f'retina_{tag}_{cname}_{blt}'
+            tg = oassign.retina_assign(anc, ann, blt)
+            lab = tg[..., 4].astype(np.int8)
+            m = G.assign_meta[key]
+            assert sha(lab) == m['label_sha256'], key
+            assert int((lab > 0).sum()) == m['npos']
+            if tag == 'TINY':
+                ref = G.assign[key]
+                assert np.array_equal(tg[..., 4], ref[..., 4])
+                np.testing.assert_allclose(tg[..., :4], ref[..., :4], rtol=0, atol=1e-6)
+            else:
+                ref = G.assign[key + '_postargets']
+                np.testing.assert_allclose(tg[lab > 0][:, :4], ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('tag', ['TINY', 'MID', 'S1'])
+def test_fcos_assign(G, tag):
+    H, W = gi.SHAPES[tag]
+    fs = synth.feature_sizes(H, W)
+    pos = oanchors.fcos_positions(fs)
+    for cname, ann in gi.annots_cases(H, W).items():
+        key = f'fcos_{tag}_{cname}'
+        tg = oassign.fcos_assign(pos, fs, ann)
+        lab = tg[..., 4].astype(np.int8)
+        assert sha(lab) == G.assign_meta[key]['label_sha256'], key
+        if tag == 'TINY':
+            np.testing.assert_allclose(tg, G.assign[key], rtol=1e-6, atol=1e-6)
+        else:
+            np.testing.assert_allclose(tg[lab > 0], G.assign[key + '_postargets'], rtol=1e-6, atol=1e-6)
+
+
+def _check_digest(got_list, meta, samples, rtol=2e-5):
+    d = gi.digest(np.concatenate([np.asarray(g).reshape(-1) for g in got_list]))
+    assert d['n'] == meta['n']
+    np.testing.assert_allclose(d['sum'], meta['sum'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(d['abssum'], meta['abssum'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(d['samples'], samples, rtol=rtol, atol=1e-9)
+
+
+def _run_oracle_loss(crit, preds_np, ann):
+    preds = [[torch.tensor(p, requires_grad=True) for p in lv] for lv in preds_np]
+    ld = crit(preds, torch.tensor(ann))
+    total = sum(ld.values())
+    grads = None
+    if total.requires_grad:
+        total.backward()
+        grads = [[(p.grad if p.grad is not None else torch.zeros_like(p)).numpy() for p in lv] for lv in preds]
+    return {k: float(v) for k, v in ld.items()}, grads
+
+
+@pytest.mark.parametrize('tag', ['TINY', 'MID', 'S1'])
+def test_losses_and_grads(G, tag):
+    H, W = gi.SHAPES[tag]
+    cases = gi.annots_cases(H, W)
+    cases['none'] = synth.annotations(1, 2, H, W, boxes_per_image=0)
+    todo = [k for k in G.losses_meta if k.split('_')[1] == tag]
+    assert todo
+    for key in todo:
+        parts = key.split('_')
+        kind = parts[0]
+        if kind == 'retina':
+            cname, blt = '_'.join(parts[2:-1]), parts[-1]
+            crit = olosses.RetinaLossOracle(box_loss_type=blt)
+            preds = list(gi.synth_preds_retina(11, 2, H, W))
+            names = ('dcls', 'dreg')
+        else:
+            cname = '_'.join(parts[2:])
+            crit = olosses.FCOSLossOracle()
+            preds = list(gi.synth_preds_fcos(13, 2, H, W))
+            names = ('dcls', 'dreg', 'dctr')
+        rec, grads = _run_oracle_loss(crit, preds, cases[cname])
+        m = G.losses_meta[key]
+        for lk, lv in rec.items():
+            np.testing.assert_allclose(lv, m[lk], rtol=1e-5, atol=1e-7, err_msg=key)
+        assert (grads is not None) == m['has_grad'], key
+        if grads is not None:
+            for nm, gl in zip(names, grads):
+                _check_digest(gl, m[nm], G.losses[f'{key}_{nm}_samples'])
+
+
+@pytest.mark.parametrize('tag', ['TINY', 'MID', 'S1'])
+def test_decoders(G, tag):
+    H, W = gi.SHAPES[tag]
+    for nms_type in ('python_nms', 'diou_python_nms'):
+        key = f'retina_{tag}_{nms_type}'
+        if key + '_scores' not in G.decode:
+            continue
+        cls, reg = gi.synth_preds_decode(21, 2, H, W)
+        s, c, b = odecode.retina_decode(cls, reg, nms_type=nms_type, nms_threshold=0.5)
+        assert np.array_equal(s, G.decode[key + '_scores'])
+        assert np.array_equal(c, G.decode[key + '_classes'])
+        assert np.array_equal(b, G.decode[key + '_boxes'])
+        key = f'fcos_{tag}_{nms_type}'
+        cls, reg, ctr = gi.synth_preds_decode(23, 2, H, W, fcos=True)
+        s, c, b = odecode.fcos_decode(cls, reg, ctr, nms_type=nms_type, nms_threshold=0.6)
+        assert np.array_equal(s, G.decode[key + '_scores'])
+        assert np.array_equal(c, G.decode[key + '_classes'])
+        assert np.array_equal(b, G.decode[key + '_boxes'])

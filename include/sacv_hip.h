@@ -1,0 +1,143 @@
+/* libsacv_hip.so -- C ABI of the MI355X (gfx950) detection training step for SimpleAICV.
+ *
+ * The reference (zgcr/SimpleAICV-pytorch-ImageNet-COCO-training) has no FFI of its own on this
+ * path: its seam is the Python class contract of simpleAICV/detection/{models,losses,decode}.
+ * This ABI sits UNDER that contract.  Each entry point names the reference code it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked "host";
+ *     the caller owns all buffers including workspaces (sizes from the *_workspace_* queries);
+ *   - activations are NHWC fp32 ([N][H][W][C], C contiguous); conv weights are OIHW fp32
+ *     (reference state_dict layout) and are repacked by sacv_pack_weight;
+ *   - `stream` is a hipStream_t (0 = default stream); calls only enqueue work, never synchronise;
+ *   - return 0 on success, negative on error (-1 bad argument, -2 launch failure,
+ *     -3 unsupported); sacv_last_error() returns the message for the calling thread.
+ */
+#ifndef SACV_HIP_H
+#define SACV_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* sacv_last_error(void);
+int sacv_abi_version(void);
+
+/* ---- convolution (nn.Conv2d: classification/backbones/resnet.py:33-39; detection/models/fpn.py:20-58;
+ *      detection/models/head.py:20-33,60-73) -------------------------------------------------------- */
+
+/* epilogue flags */
+#define SACV_CF_BIAS 1     /* + bias[n]                                   */
+#define SACV_CF_RELU 2     /* nn.ReLU fused (head.py:27,67)               */
+#define SACV_CF_SIGMOID 4  /* nn.Sigmoid fused (head.py:50)               */
+#define SACV_CF_ACCUM 8    /* dst += result (gradient fan-in)             */
+#define SACV_CF_MASK 16    /* result *= (mask > 0)  (ReLU backward fused) */
+
+/* Grouped implicit-GEMM convolution on the fp32 matrix cores.  mode 0 = forward
+ * (src = x, w = pack kind 0), mode 1 = data gradient (src = dy, w = pack kind 1).
+ * Up to 8 problems that share the weights (the 5 FPN levels of one head layer) run in one launch.
+ * Problem i: src[i] NHWC [Nb[i]][Hs[i]][Ws[i]][Cs]; dst[i] [Nb[i]*Hd[i]*Wd[i]][N].
+ * remap_s > 0 (single problem): GEMM row (n,h,w) is written to row (n, h*remap_s, w*remap_s) of an
+ * [Nb][Hr][Wr][N] tensor -- the data gradient of a strided 1x1 convolution. */
+int sacv_conv2d_gemm(int nprob, const float* const* src /*host array*/, float* const* dst /*host array*/,
+                     const float* const* mask /*host array or NULL*/, const int* Nb, const int* Hs, const int* Ws,
+                     const int* Hd, const int* Wd /*host arrays*/, const float* w, const float* bias, int Cs, int N,
+                     int KH, int KW, int stride, int pad, int mode, int flags, int remap_s, int Hr, int Wr,
+                     void* stream);
+
+long long sacv_conv2d_wgrad_workspace_bytes(int nseg, const int* Nb, const int* Ho, const int* Wo, int Cin_pad,
+                                            int Cout, int KH, int KW, int chunk);
+
+/* Weight gradient dw[OIHW] (+)= sum over segments of x (*) dy, split over pixels in `chunk`-sized
+ * slabs and reduced in a fixed order (deterministic).  dw_taps > 0: x is the stem im2col matrix
+ * (KH = KW = 1, Cin_pad = padded K) and dw is [Cout][Cin][dw_taps]. */
+int sacv_conv2d_wgrad(int nseg, const float* const* dy, const float* const* x, const int* Nb, const int* Hx,
+                      const int* Wx, const int* Ho, const int* Wo /*host arrays*/, float* dw, float* workspace,
+                      int Cin, int Cin_pad, int Cout, int KH, int KW, int stride, int pad, int chunk, int accumulate,
+                      int dw_taps, void* stream);
+
+/* kind 0: [Cout][KH*KW*Cin] forward panel; 1: [Cin][KH*KW*Cout] data-gradient panel;
+ * 2: stem panel [Cout][Kpad] (k = tap*Cin + ci, zero padded). */
+int sacv_pack_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW, int kind, int Kpad,
+                     void* stream);
+
+/* im2col of the 7x7/s2 stem (backbones/resnet.py:42-49).  x is addressed by element strides, so both
+ * NCHW-contiguous and the collater's channels_last images (detection/common.py:262-268) are accepted. */
+int sacv_im2col_stem(const float* x, float* col, int Nb, int Cin, int H, int W, long long sN, long long sC,
+                     long long sH, long long sW, int Ho, int Wo, int KH, int KW, int stride, int pad, int Kpad,
+                     void* stream);
+
+/* ---- BatchNorm2d (classification/backbones/resnet.py:41; training mode batch statistics) ------------ */
+long long sacv_bn_workspace_floats(int R, int C);
+int sacv_bn_train_stats(const float* y, int R, int C, float eps, float momentum, float* mean, float* invstd,
+                        float* running_mean, float* running_var, long long* num_batches_tracked, float* workspace,
+                        void* stream);
+/* z = act((y-mean)*invstd*gamma + beta [+ residual]); stat_is_var=1: eval mode with running_var. */
+int sacv_bn_apply(const float* y, const float* mean, const float* invstd_or_var, const float* gamma,
+                  const float* beta, const float* residual, float* z, long long numel, int C, int relu,
+                  int stat_is_var, float eps, void* stream);
+/* zmask != NULL fuses the ReLU backward (resnet.py:42, :153); g_out receives the masked upstream
+ * gradient (the residual branch's gradient). */
+int sacv_bn_train_bwd(const float* dz, const float* zmask, const float* y, const float* mean, const float* invstd,
+                      const float* gamma, float* dy, float* g_out, float* dgamma, float* dbeta, int R, int C,
+                      int accumulate, float* workspace, void* stream);
+
+/* ---- pooling / resize / elementwise ------------------------------------------------------------------ */
+/* nn.MaxPool2d(3,2,1) (detection/models/backbones/resnet.py:50); idx = window position of the max */
+int sacv_maxpool_fwd(const float* x, float* y, unsigned char* idx, int Nb, int H, int W, int C, int Ho, int Wo,
+                     int k, int s, int p, void* stream);
+int sacv_maxpool_bwd(const float* dy, const unsigned char* idx, float* dx, int Nb, int H, int W, int C, int Ho,
+                     int Wo, int k, int s, int p, void* stream);
+/* F.interpolate(bilinear, align_corners=True) + lateral (fpn.py:65-73) */
+int sacv_upsample_bilinear_add_fwd(const float* top, const float* lateral, float* out, int Nb, int Hs, int Ws,
+                                   int Hd, int Wd, int C, void* stream);
+int sacv_upsample_bilinear_bwd(const float* dout, float* dtop, int Nb, int Hs, int Ws, int Hd, int Wd, int C,
+                               int accumulate, void* stream);
+/* op 0 relu(a); 1 a*(b>0); 2 a*b*(1-b); 3 a+b; 4 a*scalar; 5 a*scalar*b*(1-b) */
+int sacv_eltwise(const float* a, const float* b, float* out, long long n, int op, float scalar, void* stream);
+long long sacv_colsum_workspace_floats(int R, int C);
+int sacv_colsum(const float* x, float* out, int R, int C, int accumulate, float* workspace, void* stream);
+
+/* ---- targets and losses (detection/models/anchor.py, detection/losses.py) ---------------------------- */
+/* RetinaAnchors.__call__ (anchor.py:18-86): bit-exact vs NumPy fp32; fw/fh/areas/... are host arrays */
+int sacv_retina_anchors(int nlev, const int* fw, const int* fh, const float* areas, const float* ratios,
+                        int nratios, const float* scales, int nscales, const float* strides, float* anchors_out,
+                        void* stream);
+/* FCOSPositions.__call__ (anchor.py:94-130) */
+int sacv_fcos_points(int nlev, const int* fw, const int* fh, const float* strides, float* points_out,
+                     void* stream);
+/* RetinaLoss.get_batch_anchors_annotations (losses.py:322-409): targets [B][A][5], counts int[2] */
+int sacv_retina_assign(const float* anchors, const float* annots, float* targets, int* counts, int B, int A, int G,
+                       int smooth_l1, void* stream);
+long long sacv_loss_workspace_floats(void);
+/* compute_batch_focal_loss (losses.py:220-261 / :513-548) forward + gradient in one pass */
+int sacv_focal_loss_fwd_bwd(int nlev, const float* const* cls_in, float* const* grad, const int* level_off,
+                            const float* targets, int tstride, int B, int A, int C, float alpha, float gamma,
+                            float weight, const int* counts, float* workspace, float* loss_out, int slot,
+                            void* stream);
+/* compute_batch_box_loss (losses.py:263-320): box_type 0 SmoothL1, 1 IoU, 2 GIoU */
+int sacv_retina_box_loss_fwd_bwd(int nlev, const float* const* reg_in, float* const* grad, const int* level_off,
+                                 const float* targets, const float* anchors, int B, int A, int box_type, float beta,
+                                 float weight, const int* counts, float* workspace, float* loss_out, int slot,
+                                 void* stream);
+
+/* ---- postprocess (detection/decode.py) -------------------------------------------------------------- */
+long long sacv_decode_workspace_bytes(int B, int A, int topn);
+/* RetinaDecoder / FCOSDecoder + DecodeMethod + DetNMSMethod (decode.py:26-364).
+ * kind 0 RetinaNet (geom = anchors), 1 FCOS (geom = points); nms_type 0 python_nms, 1 diou_python_nms */
+int sacv_decode_topk_nms(int kind, int nlev, const float* const* cls, const float* const* reg,
+                         const float* const* ctr, const int* level_off, const float* geom, int B, int A, int C,
+                         float min_score, int topn, int nms_type, float nms_thr, int max_obj, void* workspace,
+                         float* out_scores, float* out_classes, float* out_boxes, void* stream);
+
+/* ---- optimizer (tools/utils.py:480-582 build_optimizer -> torch.optim.AdamW) ------------------------- */
+int sacv_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                    long long split, float lr, float beta1, float beta2, float eps, float wd_lo, float wd_hi,
+                    int step, float grad_scale, void* stream);
+int sacv_fill(float* p, long long n, float value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SACV_HIP_H */

@@ -236,16 +236,34 @@ def sec_losses(ref):
 
 
 def synth_preds_decode(seed, B, H, W, fcos=False):
-    """Predictions with DISTINCT scores above threshold (argsort tie order is unpinned)."""
-    if fcos:
-        cls, reg, ctr = synth_preds_fcos(seed, B, H, W)
-        cls = [np.clip(c * 0.9 + 0.01, 0, 1).astype(np.float32) for c in cls]
-        return cls, reg, ctr
-    cls, reg = synth_preds_retina(seed, B, H, W)
-    # sparsify: most anchors below the 0.05 threshold, like a trained net
-    cls = [np.where(synth.uniform(seed + 99 + l, c.shape[:-1] + (1,)) < 0.03, c, c * 0.04).astype(np.float32)
-           for l, c in enumerate(cls)]
-    return cls, reg
+    """Predictions whose above-threshold scores are pairwise DISTINCT by construction (the order of
+    equal scores under the reference's np.argsort(-scores) is unspecified, so ties are unpinned)."""
+    fs = synth.feature_sizes(H, W)
+    A = 1 if fcos else 9
+    n_per_img = sum(fw * fh * A for fw, fh in fs)
+    n_hot = max(1, n_per_img // 29)
+    cls, reg, ctr = [], [], []
+    start = 0
+    for l, (fw, fh) in enumerate(fs):
+        shape = (B, fh, fw, 80) if fcos else (B, fh, fw, A, 80)
+        c = (synth.uniform(seed + 10 * l + 1, shape) * 0.04).astype(np.float32)  # all below 0.05
+        n_l = fw * fh * A
+        flat = c.reshape(B, n_l, 80)
+        for b in range(B):
+            idx = np.arange(start, start + n_l)
+            hot = idx[(idx * 7 + b * 3) % 29 == 0]
+            rank = (hot.astype(np.int64) * 7919 + b * 104729) % 1000003  # distinct for distinct anchors
+            val = (0.06 + 0.93 * rank.astype(np.float64) / 1000003.0).astype(np.float32)
+            klass = (hot * 13 + b * 5) % 80
+            flat[b, hot - start, klass] = val
+        start += n_l
+        cls.append(c)
+        if fcos:
+            reg.append(synth.normal(seed + 10 * l + 2, (B, fh, fw, 4), std=0.5) + np.float32(3.0 + 0.7 * l))
+            ctr.append((0.25 + 0.75 * synth.uniform(seed + 10 * l + 3, (B, fh, fw, 1))).astype(np.float32))
+        else:
+            reg.append(synth.normal(seed + 10 * l + 2, (B, fh, fw, A, 4), std=0.3))
+    return (cls, reg, ctr) if fcos else (cls, reg)
 
 
 def sec_decode(ref):
@@ -259,6 +277,9 @@ def sec_decode(ref):
             cls, reg = synth_preds_decode(21, 2, H, W)
             s, c, b = dec([[torch.tensor(x) for x in cls], [torch.tensor(x) for x in reg]])
             key = f'retina_{tag}_{nms_type}'
+            for i in range(s.shape[0]):
+                v = s[i][s[i] >= 0]
+                assert np.unique(v).size == v.size, 'tied scores in a decode fixture'
             out[key + '_scores'], out[key + '_classes'], out[key + '_boxes'] = s, c, b
             meta[key] = dict(ndet=[int((s[i] >= 0).sum()) for i in range(s.shape[0])])
             dec = decode.__dict__['FCOSDecoder'](nms_type=nms_type, nms_threshold=0.6)
@@ -266,6 +287,9 @@ def sec_decode(ref):
             s, c, b = dec([[torch.tensor(x) for x in cls], [torch.tensor(x) for x in reg],
                            [torch.tensor(x) for x in ctr]])
             key = f'fcos_{tag}_{nms_type}'
+            for i in range(s.shape[0]):
+                v = s[i][s[i] >= 0]
+                assert np.unique(v).size == v.size, 'tied scores in a decode fixture'
             out[key + '_scores'], out[key + '_classes'], out[key + '_boxes'] = s, c, b
             meta[key] = dict(ndet=[int((s[i] >= 0).sum()) for i in range(s.shape[0])])
     np.savez_compressed(os.path.join(GOLD, 'decode.npz'), **out)

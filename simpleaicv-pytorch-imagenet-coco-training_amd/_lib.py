@@ -1,0 +1,83 @@
+"""ctypes binding of libsacv_hip.so (the C ABI declared in include/sacv_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent the import
+fails loudly -- build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C simpleaicv-pytorch-imagenet-coco-training_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libsacv_hip.so')
+
+P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+# name -> (restype, argtypes); mirrors include/sacv_hip.h
+SIGNATURES = {
+    'sacv_last_error': (C.c_char_p, []),
+    'sacv_abi_version': (I, []),
+    'sacv_conv2d_gemm': (I, [I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    'sacv_conv2d_wgrad_workspace_bytes': (LL, [I, P, P, P, I, I, I, I, I]),
+    'sacv_conv2d_wgrad': (I, [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    'sacv_pack_weight': (I, [P, P, I, I, I, I, I, I, P]),
+    'sacv_im2col_stem': (I, [P, P, I, I, I, I, LL, LL, LL, LL, I, I, I, I, I, I, I, P]),
+    'sacv_bn_workspace_floats': (LL, [I, I]),
+    'sacv_bn_train_stats': (I, [P, I, I, F, F, P, P, P, P, P, P, P]),
+    'sacv_bn_apply': (I, [P, P, P, P, P, P, P, LL, I, I, I, F, P]),
+    'sacv_bn_train_bwd': (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
+    'sacv_maxpool_fwd': (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    'sacv_maxpool_bwd': (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    'sacv_upsample_bilinear_add_fwd': (I, [P, P, P, I, I, I, I, I, I, P]),
+    'sacv_upsample_bilinear_bwd': (I, [P, P, I, I, I, I, I, I, I, P]),
+    'sacv_eltwise': (I, [P, P, P, LL, I, F, P]),
+    'sacv_colsum_workspace_floats': (LL, [I, I]),
+    'sacv_colsum': (I, [P, P, I, I, I, P, P]),
+    'sacv_retina_anchors': (I, [I, P, P, P, P, I, P, I, P, P, P]),
+    'sacv_fcos_points': (I, [I, P, P, P, P, P]),
+    'sacv_retina_assign': (I, [P, P, P, P, I, I, I, I, P]),
+    'sacv_loss_workspace_floats': (LL, []),
+    'sacv_focal_loss_fwd_bwd': (I, [I, P, P, P, P, I, I, I, I, F, F, F, P, P, P, I, P]),
+    'sacv_retina_box_loss_fwd_bwd': (I, [I, P, P, P, P, P, I, I, I, F, F, P, P, P, I, P]),
+    'sacv_decode_workspace_bytes': (LL, [I, I, I]),
+    'sacv_decode_topk_nms': (I, [I, I, P, P, P, P, P, I, I, I, F, I, I, F, I, P, P, P, P, P]),
+    'sacv_adamw_step': (I, [P, P, P, P, LL, LL, F, F, F, F, F, F, I, F, P]),
+    'sacv_fill': (I, [P, LL, F, P]),
+}
+
+
+class SacvError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} is missing: the HIP extension has not been built. There is no CPU or '
+            'PyTorch fallback for this package; run __graft_entry__.build() (hipcc --offload-arch=gfx950).')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib.sacv_last_error()
+        raise SacvError(f'{what} failed (code {rc}): {msg.decode() if msg else ""}')
+
+
+def iarr(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def farr(vals):
+    return (C.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def parr(ptrs):
+    return (C.c_void_p * len(ptrs))(*[C.c_void_p(int(p)) if p else None for p in ptrs])

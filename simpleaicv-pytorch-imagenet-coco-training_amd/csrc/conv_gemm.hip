@@ -1,0 +1,704 @@
+// Implicit-GEMM convolution engine for gfx950 (MI355X), fp32 in / fp32 accumulate on the
+// f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fma chain, 155 TF peak).
+//
+// Activations are NHWC ([N][H][W][C], C contiguous) so that the GEMM-K slice of one filter
+// tap is a contiguous, 16-byte-vectorisable run; weights are repacked per step into
+// K-contiguous GEMM panels.  Three kernels cover every convolution on the detection path
+// (reference call sites: simpleAICV/classification/backbones/resnet.py:33-39 nn.Conv2d in
+// ConvBnActBlock, simpleAICV/detection/models/fpn.py:20-58, head.py:20-33,60-73):
+//
+//   conv_nt_kernel  C[m][n] = sum_k A(m,k) * B[n][k]
+//        forward : A = im2col gather of x      (mode 0), B = w   as [Cout][KH*KW*Cin]
+//        dgrad   : A = transposed gather of dy (mode 1), B = w^T as [Cin ][KH*KW*Cout]
+//        up to 8 same-weight problems (FPN levels sharing one head) run in ONE launch so the
+//        small pyramid levels do not serialise as latency-bound launches of a few blocks.
+//   conv_tn_kernel  dW[co][tap,ci] = sum_pix dy[pix][co] * x[pix@tap][ci]   (split over pix)
+//   wgrad_reduce    deterministic sum of the split slabs, written as OIHW (+ optional accumulate)
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile BM x BN x 32, wave tile (BM/2)x(BN/2) as
+// 32x32 MFMA blocks, LDS double-buffered with one barrier per K tile, global->register
+// prefetch of tile k+1 issued before the MFMAs of tile k (T14 split staging).
+// LDS image [row][36] floats: ds_write_b128 per 8-lane row group and ds_read_b128 per lane are
+// both bank-conflict free (row stride 36 dwords = 9 x 16 B, 9 odd).
+#include "sacv_common.h"
+
+#define SACV_MAXP 8
+
+#define CF_BIAS 1
+#define CF_RELU 2
+#define CF_SIGMOID 4
+#define CF_ACCUM 8
+#define CF_MASK 16
+
+struct ConvProb {
+  const float* src;
+  float* dst;
+  const float* mask;
+  int Nb, Hs, Ws;  // source tensor dims
+  int Hd, Wd;      // M-space spatial dims
+  int M;           // Nb*Hd*Wd
+  int tile_begin;  // first M-tile of this problem
+  int remap_s, Hr, Wr;  // dst row remap (strided scatter) when remap_s > 0
+};
+
+struct ConvArgs {
+  ConvProb p[SACV_MAXP];
+  int nprob;
+  int total_mtiles;
+  const float* w;
+  const float* bias;
+  int Cs;  // channels of src
+  int N, K;
+  int KH, KW, stride_log2, pad;
+  int mode;
+  int flags;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
+  constexpr int LS = 36;
+  constexpr int RA = BM / 32, RB = BN / 32;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;
+  float* sB = smem + 2 * BM * LS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int ntn = (a.N + BN - 1) / BN;
+  const int bid = blockIdx.x;
+  const int nt = bid % ntn;
+  const int mt = bid / ntn;
+  int pi = 0;
+  for (int i = 1; i < a.nprob; ++i)
+    if (mt >= a.p[i].tile_begin) pi = i;
+  const ConvProb& P = a.p[pi];
+  const int m0 = (mt - P.tile_begin) * BM;
+  const int n0 = nt * BN;
+  const int Hs = P.Hs, Ws = P.Ws, M = P.M, Cs = a.Cs;
+  const float* __restrict__ src = P.src;
+  const float* __restrict__ wgt = a.w;
+
+  // per-thread gather rows
+  const int kq = tid & 7;
+  const int r0 = tid >> 3;
+  int hb[RA], wb[RA], nb[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    int m = m0 + r0 + 32 * i;
+    if (m < M) {
+      int hw = P.Hd * P.Wd;
+      int n = m / hw;
+      int rem = m - n * hw;
+      int hd = rem / P.Wd;
+      int wd = rem - hd * P.Wd;
+      nb[i] = n * Hs * Ws;
+      if (a.mode == 0) {
+        hb[i] = (hd << a.stride_log2) - a.pad;
+        wb[i] = (wd << a.stride_log2) - a.pad;
+      } else {
+        hb[i] = hd + a.pad;
+        wb[i] = wd + a.pad;
+      }
+    } else {
+      nb[i] = 0;
+      hb[i] = -100000;  // never valid in either mode
+      wb[i] = -100000;
+    }
+  }
+  const int cpt = (Cs + 31) >> 5;  // K tiles per tap (last one zero-padded when Cs % 32 != 0)
+  const int KT = a.KH * a.KW * cpt;
+  const int smask = (1 << a.stride_log2) - 1;
+
+  f32x4 ra[RA], rb[RB];
+  auto load_tile = [&](int kt) {
+    int tap = kt / cpt;
+    int c0 = (kt - tap * cpt) << 5;
+    int kh = tap / a.KW;
+    int kw = tap - kh * a.KW;
+    const bool kok = (c0 + kq * 4) < Cs;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int hs, ws;
+      bool ok;
+      if (a.mode == 0) {
+        hs = hb[i] + kh;
+        ws = wb[i] + kw;
+        ok = ((unsigned)hs < (unsigned)Hs) && ((unsigned)ws < (unsigned)Ws);
+      } else {
+        int th = hb[i] - kh, tw = wb[i] - kw;
+        ok = (th >= 0) && (tw >= 0) && (((th | tw) & smask) == 0);
+        hs = th >> a.stride_log2;
+        ws = tw >> a.stride_log2;
+        ok = ok && (hs < Hs) && (ws < Ws);
+      }
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok && kok) {
+        size_t off = ((size_t)(nb[i] + hs * Ws + ws)) * Cs + c0 + kq * 4;
+        v = *reinterpret_cast<const f32x4*>(src + off);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int n = n0 + r0 + 32 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n < a.N && kok) v = *reinterpret_cast<const f32x4*>(wgt + (size_t)n * a.K + tap * Cs + c0 + kq * 4);
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* dA = sA + buf * BM * LS;
+    float* dB = sB + buf * BN * LS;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(dA + (r0 + 32 * i) * LS + kq * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(dB + (r0 + 32 * i) * LS + kq * 4) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wm0 = (wid >> 1) * WTM;
+  const int wn0 = (wid & 1) * WTN;
+  const int l31 = lane & 31;
+  const int lh = lane >> 5;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + 1 < KT) load_tile(kt + 1);
+    const float* cA = sA + cur * BM * LS + (wm0 + l31) * LS + 4 * lh;
+    const float* cB = sB + cur * BN * LS + (wn0 + l31) * LS + 4 * lh;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * LS + jj * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * LS + jj * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < KT) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue
+  const int flags = a.flags;
+  float* __restrict__ dst = P.dst;
+  const int ldd = a.N;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int n = n0 + wn0 + j * 32 + l31;
+    bool nok = n < a.N;
+    float bv = ((flags & CF_BIAS) && nok) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (nok && m < M) {
+          size_t row = (size_t)m;
+          if (P.remap_s > 0) {
+            int hw = P.Hd * P.Wd;
+            int nn = m / hw;
+            int rem = m - nn * hw;
+            int hd = rem / P.Wd;
+            int wd = rem - hd * P.Wd;
+            row = ((size_t)nn * P.Hr + (size_t)hd * P.remap_s) * P.Wr + (size_t)wd * P.remap_s;
+          }
+          size_t o = row * ldd + n;
+          float v = acc[i][j][r] + bv;
+          if (flags & CF_ACCUM) v += dst[o];
+          if (flags & CF_RELU) v = fmaxf(v, 0.f);
+          if (flags & CF_SIGMOID) v = 1.f / (1.f + __expf(-v));
+          if (flags & CF_MASK) v = (P.mask[o] > 0.f) ? v : 0.f;
+          dst[o] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad: split-K (over pixels) TN GEMM.  part[s][co][n2], n2 = tap*Cin + ci.
+struct WgradSeg {
+  const float* dy;  // [pix][Cout]
+  const float* x;   // [Nb][Hx][Wx][Cin]
+  int Nb, Hx, Wx;   // x dims
+  int Ho, Wo;       // dy dims
+  int npix;         // Nb*Ho*Wo
+  int chunk_begin;  // first split index of this segment
+};
+struct WgradArgs {
+  WgradSeg s[SACV_MAXP];
+  int nseg;
+  int nchunks;  // total splits
+  int chunk;    // pixels per split (multiple of 32)
+  float* part;  // [nchunks][Cout][N2]
+  int Cin, Cout, N2;
+  int KH, KW, stride, pad;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_tn_kernel(const WgradArgs a) {
+  constexpr int RA = BM / 32, RB = BN / 32;  // float4 per thread per tile (32 pix rows x BM/4 col groups / 256)
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                // [2][32][BM]
+  float* sB = smem + 2 * 32 * BM;  // [2][32][BN]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ntm = (a.Cout + BM - 1) / BM;
+  const int ntn = (a.N2 + BN - 1) / BN;
+  int bid = blockIdx.x;
+  const int tm = bid % ntm;
+  bid /= ntm;
+  const int tn = bid % ntn;
+  const int ck = bid / ntn;
+  int si = 0;
+  for (int i = 1; i < a.nseg; ++i)
+    if (ck >= a.s[i].chunk_begin) si = i;
+  const WgradSeg& S = a.s[si];
+  const int pix0 = (ck - S.chunk_begin) * a.chunk;
+  const int pix1 = min(pix0 + a.chunk, S.npix);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const float* __restrict__ dy = S.dy;
+  const float* __restrict__ x = S.x;
+
+  // A' loader: thread -> (col group ca = tid % (BM/4), rows tid / (BM/4) + k*(256/(BM/4)))
+  constexpr int CGA = BM / 4, RSA = 256 / CGA;  // col groups, row step
+  constexpr int CGB = BN / 4, RSB = 256 / CGB;
+  const int ca = tid % CGA, rra = tid / CGA;
+  const int cb = tid % CGB, rrb = tid / CGB;
+  const int co = m0 + ca * 4;
+  const bool co_ok = co < a.Cout;  // Cout % 4 == 0 required
+  const int n2 = n0 + cb * 4;
+  const bool n2_ok = n2 < a.N2;
+  int tap = 0, ci = 0, kh = 0, kw = 0;
+  if (n2_ok) {
+    tap = n2 / a.Cin;
+    ci = n2 - tap * a.Cin;
+    kh = tap / a.KW;
+    kw = tap - kh * a.KW;
+  }
+  const int HoWo = S.Ho * S.Wo;
+
+  f32x4 ra[RA], rb[RB];
+  auto load_tile = [&](int p0) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int pix = p0 + rra + i * RSA;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (co_ok && pix < pix1) v = *reinterpret_cast<const f32x4*>(dy + (size_t)pix * a.Cout + co);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int pix = p0 + rrb + i * RSB;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (n2_ok && pix < pix1) {
+        int n = pix / HoWo;
+        int rem = pix - n * HoWo;
+        int ho = rem / S.Wo;
+        int wo = rem - ho * S.Wo;
+        int hi = ho * a.stride - a.pad + kh;
+        int wi = wo * a.stride - a.pad + kw;
+        if ((unsigned)hi < (unsigned)S.Hx && (unsigned)wi < (unsigned)S.Wx)
+          v = *reinterpret_cast<const f32x4*>(x + ((size_t)(n * S.Hx + hi) * S.Wx + wi) * a.Cin + ci);
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* dA = sA + buf * 32 * BM;
+    float* dB = sB + buf * 32 * BN;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(dA + (rra + i * RSA) * BM + ca * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(dB + (rrb + i * RSB) * BN + cb * 4) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int KT = (pix1 - pix0 + 31) >> 5;
+  if (KT > 0) {
+    load_tile(pix0);
+    store_tile(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + 1 < KT) load_tile(pix0 + ((kt + 1) << 5));
+    const float* cA = sA + cur * 32 * BM + wm0 + l31;
+    const float* cB = sB + cur * 32 * BN + wn0 + l31;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      float fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = cA[(2 * s + lh) * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = cB[(2 * s + lh) * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < KT) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  float* __restrict__ part = a.part + (size_t)ck * a.Cout * a.N2;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int n = n0 + wn0 + j * 32 + l31;
+    if (n >= a.N2) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < a.Cout) part[(size_t)m * a.N2 + n] = acc[i][j][r];
+      }
+  }
+}
+
+// dw_oihw[co][ci][kh][kw] (+)= sum_s part[s][co][(kh*KW+kw)*Cin_pad + ci]   (ci < Cin)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nchunks,
+                                    int Cout, int Cin, int Cin_pad, int T, int accumulate) {
+  const int N2 = T * Cin_pad;
+  size_t total = (size_t)Cout * N2;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    int co = (int)(idx / N2);
+    int n2 = (int)(idx - (size_t)co * N2);
+    int tap = n2 / Cin_pad;
+    int ci = n2 - tap * Cin_pad;
+    if (ci >= Cin) continue;
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += part[(size_t)c * total + idx];
+    size_t o = ((size_t)co * Cin + ci) * T + tap;
+    dw[o] = accumulate ? dw[o] + s : s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight repacks from OIHW [Cout][Cin][KH][KW]
+//   fwd  panel: wf[co][tap*Cin + ci]            (K = T*Cin contiguous)
+//   dgrad panel: wd[ci][tap*Cout + co]           (K = T*Cout contiguous)
+__global__ void pack_w_fwd_kernel(const float* __restrict__ w, float* __restrict__ wf, int Cout, int Cin, int T) {
+  size_t total = (size_t)Cout * Cin * T;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    int ci = (int)(idx % Cin);
+    size_t q = idx / Cin;
+    int tap = (int)(q % T);
+    int co = (int)(q / T);
+    wf[idx] = w[((size_t)co * Cin + ci) * T + tap];
+  }
+}
+__global__ void pack_w_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wd, int Cout, int Cin, int T) {
+  size_t total = (size_t)Cout * Cin * T;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    int co = (int)(idx % Cout);
+    size_t q = idx / Cout;
+    int tap = (int)(q % T);
+    int ci = (int)(q / T);
+    wd[idx] = w[((size_t)co * Cin + ci) * T + tap];
+  }
+}
+// stem panel: wf[co][k], k = (kh*KW+kw)*Cin + ci for k < T*Cin, zero up to Kpad
+__global__ void pack_w_stem_kernel(const float* __restrict__ w, float* __restrict__ wf, int Cout, int Cin, int T,
+                                   int Kpad) {
+  int total = Cout * Kpad;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int k = idx % Kpad, co = idx / Kpad;
+    float v = 0.f;
+    if (k < T * Cin) {
+      int tap = k / Cin, ci = k - tap * Cin;
+      v = w[((size_t)co * Cin + ci) * T + tap];
+    }
+    wf[idx] = v;
+  }
+}
+
+// explicit im2col for the 7x7/s2 stem (Cin = 3 is too narrow for 16-byte gathers):
+// col[m][k], k = (kh*KW+kw)*Cin + ci, zero padded to Kpad.  Input given by element strides so
+// NCHW-contiguous and channels_last images are both accepted (SURVEY.md finding 3).
+__global__ void im2col_stem_kernel(const float* __restrict__ x, float* __restrict__ col, int Nb, int Cin, int H,
+                                   int W, long long sN, long long sC, long long sH, long long sW, int Ho, int Wo,
+                                   int KH, int KW, int stride, int pad, int Kpad) {
+  size_t total = (size_t)Nb * Ho * Wo * Kpad;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    int k = (int)(idx % Kpad);
+    size_t m = idx / Kpad;
+    float v = 0.f;
+    if (k < KH * KW * Cin) {
+      int tap = k / Cin, ci = k - tap * Cin;
+      int kh = tap / KW, kw = tap - kh * KW;
+      int wo = (int)(m % Wo);
+      size_t q = m / Wo;
+      int ho = (int)(q % Ho);
+      int n = (int)(q / Ho);
+      int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
+      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[n * sN + ci * sC + hi * sH + wi * sW];
+    }
+    col[idx] = v;
+  }
+}
+
+// stem: part[s][co][k], k = tap*Cin + ci (k < T*Cin), row length Kpad -> dw[co][ci][tap]
+__global__ void wgrad_reduce_stem_kernel(const float* __restrict__ part, float* __restrict__ dw, int nchunks,
+                                         int Cout, int Cin, int T, int Kpad, int accumulate) {
+  size_t slab = (size_t)Cout * Kpad;
+  int total = Cout * T * Cin;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    int k = idx % (T * Cin);
+    int co = idx / (T * Cin);
+    int tap = k / Cin, ci = k - tap * Cin;
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += part[(size_t)c * slab + (size_t)co * Kpad + k];
+    size_t o = ((size_t)co * Cin + ci) * T + tap;
+    dw[o] = accumulate ? dw[o] + s : s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+static int log2_exact(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return ((1 << l) == v) ? l : -1;
+}
+
+template <int BM, int BN>
+static int launch_nt(const ConvArgs& a, hipStream_t st) {
+  int ntn = (a.N + BN - 1) / BN;
+  size_t lds = (size_t)2 * (BM + BN) * 36 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_nt_kernel<BM, BN>), dim3(a.total_mtiles * ntn), dim3(256), lds, st, a);
+  SACV_CHECK_LAUNCH("conv_nt_kernel");
+  return SACV_OK;
+}
+
+template <int BM, int BN>
+static int launch_tn(const WgradArgs& a, int chunks, hipStream_t st) {
+  int ntm = (a.Cout + BM - 1) / BM, ntn = (a.N2 + BN - 1) / BN;
+  size_t lds = (size_t)2 * 32 * (BM + BN) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tn_kernel<BM, BN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_tn_kernel<BM, BN>), dim3(ntm * ntn * chunks), dim3(256), lds, st, a);
+  SACV_CHECK_LAUNCH("conv_tn_kernel");
+  return SACV_OK;
+}
+
+extern "C" {
+
+// Grouped implicit-GEMM convolution (forward when mode==0, data-gradient when mode==1).
+// Every problem p: src[p] is NHWC [Nb[p]][Hs[p]][Ws[p]][Cs]; dst[p] is [M_p][N] with
+// M_p = Nb*Hd*Wd.  w is the packed panel [N][KH*KW*Cs].
+int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, const float* const* mask,
+                     const int* Nb, const int* Hs, const int* Ws, const int* Hd, const int* Wd, const float* w,
+                     const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode, int flags,
+                     int remap_s, int Hr, int Wr, void* stream) {
+  SACV_CHECK_ARG(nprob >= 1 && nprob <= SACV_MAXP, "conv2d_gemm: nprob %d out of range", nprob);
+  SACV_CHECK_ARG(Cs % 4 == 0 && Cs > 0, "conv2d_gemm: Cs=%d must be a positive multiple of 4", Cs);
+  SACV_CHECK_ARG(N > 0 && KH > 0 && KW > 0, "conv2d_gemm: bad N/KH/KW");
+  int sl = log2_exact(stride);
+  SACV_CHECK_ARG(sl >= 0, "conv2d_gemm: stride %d must be a power of two", stride);
+  SACV_CHECK_ARG(mode == 0 || mode == 1, "conv2d_gemm: mode");
+  SACV_CHECK_ARG(!(flags & CF_BIAS) || bias, "conv2d_gemm: bias flag without bias pointer");
+  SACV_CHECK_ARG(remap_s == 0 || nprob == 1, "conv2d_gemm: remap only for single problems");
+  ConvArgs a;
+  const bool small_n = N <= 64;
+  const int BM = 128;
+  int tiles = 0;
+  for (int i = 0; i < nprob; ++i) {
+    SACV_CHECK_ARG(src[i] && dst[i], "conv2d_gemm: null tensor pointer (problem %d)", i);
+    SACV_CHECK_ARG(Nb[i] > 0 && Hs[i] > 0 && Ws[i] > 0 && Hd[i] > 0 && Wd[i] > 0, "conv2d_gemm: bad dims");
+    SACV_CHECK_ARG(!(flags & CF_MASK) || (mask && mask[i]), "conv2d_gemm: mask flag without mask pointer");
+    long long M = (long long)Nb[i] * Hd[i] * Wd[i];
+    SACV_CHECK_ARG(M * (long long)(N > Cs ? N : Cs) < (1LL << 31) &&
+                       (long long)Nb[i] * Hs[i] * Ws[i] * Cs < (1LL << 31),
+                   "conv2d_gemm: tensor too large for 32-bit pixel indexing");
+    ConvProb& p = a.p[i];
+    p.src = src[i];
+    p.dst = dst[i];
+    p.mask = mask ? mask[i] : nullptr;
+    p.Nb = Nb[i];
+    p.Hs = Hs[i];
+    p.Ws = Ws[i];
+    p.Hd = Hd[i];
+    p.Wd = Wd[i];
+    p.M = (int)M;
+    p.tile_begin = tiles;
+    p.remap_s = remap_s;
+    p.Hr = Hr;
+    p.Wr = Wr;
+    tiles += (p.M + BM - 1) / BM;
+  }
+  a.nprob = nprob;
+  a.total_mtiles = tiles;
+  a.w = w;
+  a.bias = bias;
+  a.Cs = Cs;
+  a.N = N;
+  a.K = KH * KW * Cs;
+  a.KH = KH;
+  a.KW = KW;
+  a.stride_log2 = sl;
+  a.pad = pad;
+  a.mode = mode;
+  a.flags = flags;
+  if (small_n) return launch_nt<128, 64>(a, (hipStream_t)stream);
+  return launch_nt<128, 128>(a, (hipStream_t)stream);
+}
+
+// Workspace (bytes) needed by sacv_conv2d_wgrad for the given problem list.
+long long sacv_conv2d_wgrad_workspace_bytes(int nseg, const int* Nb, const int* Ho, const int* Wo, int Cin_pad,
+                                            int Cout, int KH, int KW, int chunk) {
+  long long chunks = 0;
+  for (int i = 0; i < nseg; ++i) chunks += ((long long)Nb[i] * Ho[i] * Wo[i] + chunk - 1) / chunk;
+  return chunks * Cout * (long long)KH * KW * Cin_pad * (long long)sizeof(float);
+}
+
+// Weight gradient.  dy[s]: [Nb*Ho*Wo][Cout]; x[s]: NHWC [Nb][Hx][Wx][Cin_pad]; dw: OIHW
+// [Cout][Cin][KH][KW] (Cin <= Cin_pad; the stem uses its im2col matrix as a 1x1 problem).
+int sacv_conv2d_wgrad(int nseg, const float* const* dy, const float* const* x, const int* Nb, const int* Hx,
+                      const int* Wx, const int* Ho, const int* Wo, float* dw, float* workspace, int Cin, int Cin_pad,
+                      int Cout, int KH, int KW, int stride, int pad, int chunk, int accumulate, int dw_taps,
+                      void* stream) {
+  SACV_CHECK_ARG(nseg >= 1 && nseg <= SACV_MAXP, "conv2d_wgrad: nseg");
+  SACV_CHECK_ARG(Cin_pad % 4 == 0 && Cout % 4 == 0, "conv2d_wgrad: channels must be multiples of 4");
+  SACV_CHECK_ARG(chunk % 32 == 0 && chunk > 0, "conv2d_wgrad: chunk must be a multiple of 32");
+  SACV_CHECK_ARG(workspace && dw, "conv2d_wgrad: null pointer");
+  WgradArgs a;
+  int chunks = 0;
+  for (int i = 0; i < nseg; ++i) {
+    WgradSeg& s = a.s[i];
+    s.dy = dy[i];
+    s.x = x[i];
+    s.Nb = Nb[i];
+    s.Hx = Hx[i];
+    s.Wx = Wx[i];
+    s.Ho = Ho[i];
+    s.Wo = Wo[i];
+    long long np = (long long)Nb[i] * Ho[i] * Wo[i];
+    SACV_CHECK_ARG(np * (long long)(Cout > Cin_pad ? Cout : Cin_pad) < (1LL << 31) &&
+                       (long long)Nb[i] * Hx[i] * Wx[i] < (1LL << 31),
+                   "conv2d_wgrad: too large");
+    s.npix = (int)np;
+    s.chunk_begin = chunks;
+    chunks += (int)((np + chunk - 1) / chunk);
+  }
+  a.nseg = nseg;
+  a.nchunks = chunks;
+  a.chunk = chunk;
+  a.part = workspace;
+  a.Cin = Cin_pad;
+  a.Cout = Cout;
+  a.N2 = KH * KW * Cin_pad;
+  a.KH = KH;
+  a.KW = KW;
+  a.stride = stride;
+  a.pad = pad;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (Cout <= 64)
+    rc = (a.N2 <= 64) ? launch_tn<64, 64>(a, chunks, st) : launch_tn<64, 128>(a, chunks, st);
+  else
+    rc = (a.N2 <= 64) ? launch_tn<128, 64>(a, chunks, st) : launch_tn<128, 128>(a, chunks, st);
+  if (rc != SACV_OK) return rc;
+  int T = dw_taps > 0 ? dw_taps : KH * KW;
+  // for the stem (dw_taps = 49, KH=KW=1, Cin_pad = Kpad): part is [Cout][Kpad] with k = tap*Cin + ci
+  size_t total = (size_t)Cout * KH * KW * Cin_pad;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (dw_taps > 0) {
+    // reinterpret: N2 = Kpad, real k < dw_taps*Cin laid out tap-major
+    // handled by the generic reduce with T=dw_taps, Cin_pad=Cin when Kpad == padded T*Cin: use stem reducer
+    hipLaunchKernelGGL(wgrad_reduce_stem_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw, chunks, Cout, Cin,
+                       dw_taps, Cin_pad, accumulate);
+  } else {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw, chunks, Cout, Cin, Cin_pad,
+                       T, accumulate);
+  }
+  SACV_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return SACV_OK;
+}
+
+int sacv_pack_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW, int kind, int Kpad,
+                     void* stream) {
+  SACV_CHECK_ARG(w_oihw && out, "pack_weight: null pointer");
+  size_t total = (size_t)Cout * Cin * KH * KW;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  if (kind == 0)
+    hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(blocks), dim3(256), 0, st, w_oihw, out, Cout, Cin, KH * KW);
+  else if (kind == 1)
+    hipLaunchKernelGGL(pack_w_dgrad_kernel, dim3(blocks), dim3(256), 0, st, w_oihw, out, Cout, Cin, KH * KW);
+  else if (kind == 2) {
+    SACV_CHECK_ARG(Kpad >= Cin * KH * KW, "pack_weight: Kpad too small");
+    hipLaunchKernelGGL(pack_w_stem_kernel, dim3(sacv_cdiv((long long)Cout * Kpad, 256)), dim3(256), 0, st, w_oihw,
+                       out, Cout, Cin, KH * KW, Kpad);
+  } else {
+    sacv_set_error("pack_weight: unknown kind %d", kind);
+    return SACV_ERR_ARG;
+  }
+  SACV_CHECK_LAUNCH("pack_weight");
+  return SACV_OK;
+}
+
+int sacv_im2col_stem(const float* x, float* col, int Nb, int Cin, int H, int W, long long sN, long long sC,
+                     long long sH, long long sW, int Ho, int Wo, int KH, int KW, int stride, int pad, int Kpad,
+                     void* stream) {
+  SACV_CHECK_ARG(x && col, "im2col_stem: null pointer");
+  SACV_CHECK_ARG(Kpad % 32 == 0 && Kpad >= Cin * KH * KW, "im2col_stem: Kpad must be a multiple of 32 >= K");
+  size_t total = (size_t)Nb * Ho * Wo * Kpad;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(im2col_stem_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, col, Nb, Cin, H, W, sN,
+                     sC, sH, sW, Ho, Wo, KH, KW, stride, pad, Kpad);
+  SACV_CHECK_LAUNCH("im2col_stem");
+  return SACV_OK;
+}
+
+}  // extern "C"
+

@@ -1,0 +1,379 @@
+// Device-side detection postprocess: per-anchor class argmax + box decode, exact top-n radix
+// select, LDS bitonic sort by score, bit-mask hard NMS with a single-wave greedy scan, pad to
+// max_object_num.  Replaces the host NumPy path of simpleAICV/detection/decode.py:
+//   RetinaDecoder.__call__ :201-249, snap_txtytwth_to_x1y1x2y2 :251-271 (int32 truncation),
+//   FCOSDecoder :293-364, DecodeMethod.__call__ :121-172, DetNMSMethod python_nms /
+//   diou_python_nms :45-102 (class-agnostic, area = max(w*h,0), union clamped at 1e-4).
+// Equal scores: the reference's np.argsort(-scores) order is unspecified; here ties are broken
+// by ascending anchor index (deterministic).
+// Compiled with -ffp-contract=off so IoU arithmetic rounds like the NumPy fp32 ops.
+#include "sacv_common.h"
+#include <math.h>
+
+#define DMAXL 8
+#define TOPN_MAX 1024
+#define SEL_THREADS 1024
+
+struct DecodeArgs {
+  const float* cls[DMAXL];
+  const float* reg[DMAXL];
+  const float* ctr[DMAXL];  // FCOS only
+  int off[DMAXL + 1];
+  int nlev;
+};
+
+// kind 0: RetinaNet (geom = anchors [A][4]); kind 1: FCOS (geom = points [A][2])
+__global__ __launch_bounds__(256) void decode_kernel(const DecodeArgs d, const float* __restrict__ geom, int kind,
+                                                      int B, int A, int C, float* __restrict__ scores,
+                                                      int* __restrict__ classes, int* __restrict__ boxes) {
+  size_t total = (size_t)B * A;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int a = (int)(i % A), b = (int)(i / A);
+    int l = 0;
+    for (int k = 1; k < d.nlev; ++k)
+      if (a >= d.off[k]) l = k;
+    int nl = d.off[l + 1] - d.off[l];
+    size_t row = (size_t)b * nl + (a - d.off[l]);
+    const float* c = d.cls[l] + row * C;
+    float best = c[0];
+    int bi = 0;
+    for (int k = 1; k < C; ++k) {
+      float v = c[k];
+      if (v > best) {  // first maximum, like np.argmax
+        best = v;
+        bi = k;
+      }
+    }
+    f32x4 r = *reinterpret_cast<const f32x4*>(d.reg[l] + row * 4);
+    float x1, y1, x2, y2, sc = best;
+    if (kind == 0) {
+      f32x4 an = *reinterpret_cast<const f32x4*>(geom + (size_t)a * 4);
+      float aw = an[2] - an[0], ah = an[3] - an[1];
+      float acx = an[0] + 0.5f * aw, acy = an[1] + 0.5f * ah;
+      float bw = expf(r[2]) * aw, bh = expf(r[3]) * ah;
+      float cx = r[0] * aw + acx, cy = r[1] * ah + acy;
+      x1 = cx - 0.5f * bw;
+      y1 = cy - 0.5f * bh;
+      x2 = cx + 0.5f * bw;
+      y2 = cy + 0.5f * bh;
+    } else {
+      float px = geom[(size_t)a * 2], py = geom[(size_t)a * 2 + 1];
+      x1 = px - expf(r[0]);
+      y1 = py - expf(r[1]);
+      x2 = px + expf(r[2]);
+      y2 = py + expf(r[3]);
+      sc = sqrtf(best * d.ctr[l][row]);
+    }
+    scores[i] = sc;
+    classes[i] = bi;
+    int4 bx = make_int4((int)x1, (int)y1, (int)x2, (int)y2);  // truncation toward zero (astype(np.int32))
+    *reinterpret_cast<int4*>(boxes + i * 4) = bx;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Exact top-n selection + sort, one block per image.
+__device__ __forceinline__ unsigned score_key(float s, float thr) { return (s > thr) ? __float_as_uint(s) : 0u; }
+
+__global__ __launch_bounds__(SEL_THREADS) void select_sort_kernel(const float* __restrict__ scores,
+                                                                   const int* __restrict__ classes,
+                                                                   const int* __restrict__ boxes, int A, int topn,
+                                                                   float min_score, float* __restrict__ s_scores,
+                                                                   float* __restrict__ s_classes,
+                                                                   float* __restrict__ s_boxes,
+                                                                   int* __restrict__ s_count) {
+  __shared__ int hist[4096];
+  __shared__ unsigned long long item[TOPN_MAX];  // (key << 32) | (~idx) so bigger = better, lower idx first
+  __shared__ int sh_prefix, sh_remaining, sh_total, sh_cnt_gt, sh_cnt_eq;
+  __shared__ int wave_cnt[2][SEL_THREADS / 64];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const float* sc = scores + (size_t)b * A;
+
+  // count valid
+  if (tid == 0) sh_total = 0;
+  __syncthreads();
+  int local = 0;
+  for (int i = tid; i < A; i += SEL_THREADS) local += score_key(sc[i], min_score) != 0u;
+  local = (int)wave_sum((float)local);  // counts < 2^24: exact in fp32
+  if ((tid & 63) == 0 && local) atomicAdd(&sh_total, local);
+  __syncthreads();
+  const int total = sh_total;
+  const int K = min(total, topn);
+  unsigned T = 0u;   // threshold key: take all keys > T and `rem_eq` keys == T
+  int rem_eq = 0;
+  if (total > topn) {
+    // 3-level radix select for the K-th largest key
+    unsigned prefix = 0u;
+    int remaining = K;
+    const int shifts[3] = {20, 8, 0};
+    const int bitsn[3] = {12, 12, 8};
+    for (int lev = 0; lev < 3; ++lev) {
+      const int nb = 1 << bitsn[lev];
+      for (int i = tid; i < nb; i += SEL_THREADS) hist[i] = 0;
+      __syncthreads();
+      const unsigned hi_mask = (lev == 0) ? 0u : (0xFFFFFFFFu << (shifts[lev - 1]));
+      for (int i = tid; i < A; i += SEL_THREADS) {
+        unsigned k = score_key(sc[i], min_score);
+        if (k != 0u && (k & hi_mask) == prefix) atomicAdd(&hist[(k >> shifts[lev]) & (nb - 1)], 1);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int cum = 0, bin = nb - 1;
+        for (; bin >= 0; --bin) {
+          if (cum + hist[bin] >= remaining) break;
+          cum += hist[bin];
+        }
+        if (bin < 0) bin = 0;
+        sh_prefix = bin;
+        sh_remaining = remaining - cum;
+      }
+      __syncthreads();
+      prefix |= ((unsigned)sh_prefix) << shifts[lev];
+      remaining = sh_remaining;
+      __syncthreads();
+    }
+    T = prefix;
+    rem_eq = remaining;
+  } else {
+    T = 0u;  // take everything valid (keys are never 0 for valid scores)
+    rem_eq = 0;
+  }
+  // ordered collection: all keys > T, then the first rem_eq keys == T in index order
+  if (tid == 0) {
+    sh_cnt_gt = 0;
+    sh_cnt_eq = 0;
+  }
+  for (int i = tid; i < TOPN_MAX; i += SEL_THREADS) item[i] = 0ull;
+  __syncthreads();
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int base = 0; base < A; base += SEL_THREADS) {
+    int i = base + tid;
+    unsigned k = (i < A) ? score_key(sc[i], min_score) : 0u;
+    bool gt = k > T && k != 0u;
+    bool eq = (T != 0u) && (k == T);
+    unsigned long long mg = __ballot(gt), me = __ballot(eq);
+    if (lane == 0) {
+      wave_cnt[0][wv] = __popcll(mg);
+      wave_cnt[1][wv] = __popcll(me);
+    }
+    __syncthreads();
+    int off_g = sh_cnt_gt, off_e = sh_cnt_eq;
+    for (int w = 0; w < wv; ++w) {
+      off_g += wave_cnt[0][w];
+      off_e += wave_cnt[1][w];
+    }
+    unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int pg = off_g + __popcll(mg & below);
+    int pe = off_e + __popcll(me & below);
+    unsigned long long v = ((unsigned long long)k << 32) | (unsigned)(~(unsigned)i);
+    // layout: [0, K - rem_eq) greater-than items, [K - rem_eq, K) equal items
+    if (gt && pg < K) item[pg] = v;
+    if (eq && pe < rem_eq) item[(K - rem_eq) + pe] = v;
+    __syncthreads();
+    if (tid == 0) {
+      int sg = 0, se = 0;
+      for (int w = 0; w < SEL_THREADS / 64; ++w) {
+        sg += wave_cnt[0][w];
+        se += wave_cnt[1][w];
+      }
+      sh_cnt_gt += sg;
+      sh_cnt_eq += se;
+    }
+    __syncthreads();
+  }
+  // bitonic sort, descending, TOPN_MAX elements (zeros sink to the end)
+  for (int k2 = 2; k2 <= TOPN_MAX; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < TOPN_MAX; i += SEL_THREADS) {
+        int ixj = i ^ j;
+        if (ixj > i) {
+          unsigned long long x = item[i], y = item[ixj];
+          bool desc = ((i & k2) == 0);
+          if (desc ? (x < y) : (x > y)) {
+            item[i] = y;
+            item[ixj] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) s_count[b] = K;
+  for (int i = tid; i < topn; i += SEL_THREADS) {
+    size_t o = (size_t)b * topn + i;
+    if (i < K) {
+      unsigned idx = ~(unsigned)(item[i] & 0xFFFFFFFFull);
+      size_t g = (size_t)b * A + idx;
+      s_scores[o] = sc[idx];
+      s_classes[o] = (float)classes[g];
+      int4 bx = *reinterpret_cast<const int4*>(boxes + g * 4);
+      f32x4 fb = {(float)bx.x, (float)bx.y, (float)bx.z, (float)bx.w};
+      *reinterpret_cast<f32x4*>(s_boxes + o * 4) = fb;
+    } else {
+      s_scores[o] = -1.f;
+      s_classes[o] = -1.f;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(s_boxes + o * 4) = z;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Hard NMS on <= 1024 score-sorted boxes, one block per image.
+__global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ s_scores,
+                                                    const float* __restrict__ s_classes,
+                                                    const float* __restrict__ s_boxes,
+                                                    const int* __restrict__ s_count, int topn, float thr, int diou,
+                                                    int max_obj, float* __restrict__ out_scores,
+                                                    float* __restrict__ out_classes, float* __restrict__ out_boxes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  f32x4* box = reinterpret_cast<f32x4*>(smem_raw);                                    // [1024]
+  float* area = reinterpret_cast<float*>(smem_raw + 1024 * 16);                        // [1024]
+  int* keep = reinterpret_cast<int*>(smem_raw + 1024 * 20);                             // [1024]
+  int* nkeep_p = reinterpret_cast<int*>(smem_raw + 1024 * 24);                          // [4] (16 B slot)
+  unsigned long long* mask = reinterpret_cast<unsigned long long*>(smem_raw + 1024 * 24 + 16);  // [1024][16]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = s_count[b];
+  if (tid < n) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(s_boxes + ((size_t)b * topn + tid) * 4);
+    box[tid] = v;
+    float w = v[2] - v[0], h = v[3] - v[1];
+    area[tid] = fmaxf(w * h, 0.f);
+  }
+  __syncthreads();
+  const int nwords = (n + 63) >> 6;
+  for (int t = tid; t < n * nwords; t += 1024) {
+    int i = t / nwords, w = t - i * nwords;
+    unsigned long long bits = 0ull;
+    f32x4 bi = box[i];
+    float ai = area[i];
+    int j0 = w << 6;
+    for (int jj = 0; jj < 64; ++jj) {
+      int j = j0 + jj;
+      if (j <= i || j >= n) continue;
+      f32x4 bj = box[j];
+      float tlx = fmaxf(bi[0], bj[0]), tly = fmaxf(bi[1], bj[1]);
+      float brx = fminf(bi[2], bj[2]), bry = fminf(bi[3], bj[3]);
+      float sw = fmaxf(brx - tlx, 0.f), sh = fmaxf(bry - tly, 0.f);
+      float inter = sw * sh;
+      float uni = fmaxf((ai + area[j]) - inter, 1e-4f);
+      float iou = inter / uni;
+      if (diou) {
+        float ex = fmaxf(fmaxf(bi[2], bj[2]) - fminf(bi[0], bj[0]), 0.f);
+        float ey = fmaxf(fmaxf(bi[3], bj[3]) - fminf(bi[1], bj[1]), 0.f);
+        float c2 = fmaxf(ex * ex + ey * ey, 1e-4f);
+        float kx = (bi[2] + bi[0]) / 2.f, ky = (bi[3] + bi[1]) / 2.f;
+        float ox = (bj[2] + bj[0]) / 2.f, oy = (bj[3] + bj[1]) / 2.f;
+        float dx = kx - ox, dy = ky - oy;
+        float p2 = dx * dx + dy * dy;
+        iou = iou - p2 / c2;
+      }
+      if (!(iou < thr)) bits |= (1ull << jj);
+    }
+    mask[(size_t)i * 16 + w] = bits;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    unsigned long long removed = 0ull;  // lane w (< nwords) owns word w of the removed bitmap
+    int nk = 0;
+    for (int i = 0; i < n; ++i) {
+      unsigned long long r = __shfl(removed, i >> 6, 64);
+      if (!((r >> (i & 63)) & 1ull)) {
+        if (tid == 0) keep[nk] = i;
+        ++nk;
+        if (nk >= max_obj) break;
+        if (tid < nwords) removed |= mask[(size_t)i * 16 + tid];
+      }
+    }
+    if (tid == 0) nkeep_p[0] = nk;
+  }
+  __syncthreads();
+  const int nk = nkeep_p[0];
+  for (int i = tid; i < max_obj; i += 1024) {
+    size_t o = (size_t)b * max_obj + i;
+    if (i < nk) {
+      int k = keep[i];
+      size_t s = (size_t)b * topn + k;
+      out_scores[o] = s_scores[s];
+      out_classes[o] = s_classes[s];
+      *reinterpret_cast<f32x4*>(out_boxes + o * 4) = box[k];
+    } else {
+      out_scores[o] = -1.f;
+      out_classes[o] = -1.f;
+      f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(out_boxes + o * 4) = z;
+    }
+  }
+}
+
+extern "C" {
+
+// bytes of workspace for sacv_decode_topk_nms
+long long sacv_decode_workspace_bytes(int B, int A, int topn) {
+  long long dense = (long long)B * A * (4 + 4 + 16);
+  long long sorted = (long long)B * topn * (4 + 4 + 16) + (long long)B * 4;
+  return dense + sorted + 256;
+}
+
+// kind 0: RetinaNet (cls [B][n_l][C] probs, reg [B][n_l][4], geom = anchors [A][4]);
+// kind 1: FCOS (plus ctr [B][n_l][1], geom = points [A][2]).
+// Outputs: out_scores/out_classes [B][max_obj] (-1 padded), out_boxes [B][max_obj][4] (0 padded).
+int sacv_decode_topk_nms(int kind, int nlev, const float* const* cls, const float* const* reg,
+                         const float* const* ctr, const int* level_off, const float* geom, int B, int A, int C,
+                         float min_score, int topn, int nms_type, float nms_thr, int max_obj, void* workspace,
+                         float* out_scores, float* out_classes, float* out_boxes, void* stream) {
+  SACV_CHECK_ARG(kind == 0 || kind == 1, "decode: kind");
+  SACV_CHECK_ARG(nlev >= 1 && nlev <= DMAXL, "decode: nlev");
+  SACV_CHECK_ARG(topn >= 1 && topn <= TOPN_MAX, "decode: topn must be in [1, %d]", TOPN_MAX);
+  SACV_CHECK_ARG(max_obj >= 1 && max_obj <= 1024, "decode: max_object_num must be in [1, 1024]");
+  SACV_CHECK_ARG(nms_type == 0 || nms_type == 1, "decode: nms_type must be 0 (python_nms) or 1 (diou_python_nms)");
+  SACV_CHECK_ARG(level_off[nlev] == A, "decode: level offsets do not sum to A");
+  SACV_CHECK_ARG(geom && workspace && out_scores && out_classes && out_boxes, "decode: null pointer");
+  SACV_CHECK_ARG(min_score >= 0.f, "decode: min_score_threshold must be >= 0");
+  DecodeArgs d;
+  d.nlev = nlev;
+  for (int l = 0; l < nlev; ++l) {
+    SACV_CHECK_ARG(cls[l] && reg[l] && (kind == 0 || (ctr && ctr[l])), "decode: null level pointer");
+    d.cls[l] = cls[l];
+    d.reg[l] = reg[l];
+    d.ctr[l] = kind == 1 ? ctr[l] : nullptr;
+    d.off[l] = level_off[l];
+  }
+  d.off[nlev] = level_off[nlev];
+  unsigned char* ws = (unsigned char*)workspace;
+  float* scores = (float*)ws;
+  ws += (size_t)B * A * 4;
+  int* classes = (int*)ws;
+  ws += (size_t)B * A * 4;
+  int* boxes = (int*)ws;
+  ws += (size_t)B * A * 16;
+  float* s_boxes = (float*)ws;
+  ws += (size_t)B * topn * 16;
+  float* s_scores = (float*)ws;
+  ws += (size_t)B * topn * 4;
+  float* s_classes = (float*)ws;
+  ws += (size_t)B * topn * 4;
+  int* s_count = (int*)ws;
+  hipStream_t st = (hipStream_t)stream;
+  size_t total = (size_t)B * A;
+  int blocks = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(decode_kernel, dim3(blocks), dim3(256), 0, st, d, geom, kind, B, A, C, scores, classes, boxes);
+  SACV_CHECK_LAUNCH("decode_kernel");
+  hipLaunchKernelGGL(select_sort_kernel, dim3(B), dim3(SEL_THREADS), 0, st, scores, classes, boxes, A, topn,
+                     min_score, s_scores, s_classes, s_boxes, s_count);
+  SACV_CHECK_LAUNCH("select_sort_kernel");
+  size_t lds = 1024 * 24 + 16 + (size_t)1024 * 16 * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), lds, st, s_scores, s_classes, s_boxes, s_count, topn, nms_thr,
+                     nms_type, max_obj, out_scores, out_classes, out_boxes);
+  SACV_CHECK_LAUNCH("nms_kernel");
+  return SACV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// Fused AdamW over the flat fp32 parameter arena (one launch for all 195 tensors).
+// Semantics of torch.optim.AdamW as built by the reference (tools/utils.py:480-582, AdamW
+// lr 1e-4, betas (0.9, 0.999), eps 1e-8, weight decay 1e-3 on ndim>1 tensors and 0 on 1-D
+// tensors): decoupled decay p *= 1 - lr*wd, then p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).
+// The arena is laid out [1-D tensors | >=2-D tensors]; `split` is the element index of the
+// boundary so the two parameter groups are one kernel.  HBM-bound: 16 B read + 12 B written
+// per element, float4 streams.
+#include "sacv_common.h"
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                     float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                     size_t split, float lr, float beta1, float beta2, float eps,
+                                                     float wd_lo, float wd_hi, float bc1, float bc2_sqrt,
+                                                     float grad_scale) {
+  size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 pp = *reinterpret_cast<f32x4*>(p + i * 4);
+    f32x4 gg = *reinterpret_cast<const f32x4*>(g + i * 4);
+    f32x4 mm = *reinterpret_cast<f32x4*>(m + i * 4);
+    f32x4 vv = *reinterpret_cast<f32x4*>(v + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float wd = (i * 4 + e) < split ? wd_lo : wd_hi;
+      float gr = gg[e] * grad_scale;
+      float x = pp[e] * (1.f - lr * wd);
+      float m1 = beta1 * mm[e] + (1.f - beta1) * gr;
+      float v1 = beta2 * vv[e] + (1.f - beta2) * gr * gr;
+      float denom = sqrtf(v1) / bc2_sqrt + eps;
+      x = x - (lr / bc1) * (m1 / denom);
+      pp[e] = x;
+      mm[e] = m1;
+      vv[e] = v1;
+    }
+    *reinterpret_cast<f32x4*>(p + i * 4) = pp;
+    *reinterpret_cast<f32x4*>(m + i * 4) = mm;
+    *reinterpret_cast<f32x4*>(v + i * 4) = vv;
+  }
+}
+
+__global__ void fill_kernel(float* __restrict__ p, size_t n, float value) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = value;
+}
+
+extern "C" {
+
+// n must be a multiple of 4 (the arena pads every tensor to 4 floats); split likewise.
+int sacv_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                    long long split, float lr, float beta1, float beta2, float eps, float wd_lo, float wd_hi,
+                    int step, float grad_scale, void* stream) {
+  SACV_CHECK_ARG(params && grads && exp_avg && exp_avg_sq, "adamw_step: null pointer");
+  SACV_CHECK_ARG(n > 0 && n % 4 == 0 && split % 4 == 0 && split >= 0 && split <= n, "adamw_step: bad sizes");
+  SACV_CHECK_ARG(step >= 1, "adamw_step: step counts from 1");
+  double bc1 = 1.0 - pow((double)beta1, (double)step);
+  double bc2 = 1.0 - pow((double)beta2, (double)step);
+  size_t n4 = (size_t)n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                     exp_avg_sq, (size_t)n, (size_t)split, lr, beta1, beta2, eps, wd_lo, wd_hi, (float)bc1,
+                     (float)sqrt(bc2), grad_scale);
+  SACV_CHECK_LAUNCH("adamw_step");
+  return SACV_OK;
+}
+
+int sacv_fill(float* p, long long n, float value, void* stream) {
+  SACV_CHECK_ARG(p && n >= 0, "fill: bad args");
+  if (n == 0) return SACV_OK;
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, (size_t)n, value);
+  SACV_CHECK_LAUNCH("fill");
+  return SACV_OK;
+}
+
+}  // extern "C"

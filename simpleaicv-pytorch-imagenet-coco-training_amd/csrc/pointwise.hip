@@ -1,0 +1,322 @@
+// HBM-bound NHWC helpers of the detection step: 3x3/s2 max-pool, bilinear(align_corners)
+// upsample + lateral add of the FPN top-down path, activation backward passes and the bias
+// gradient column sum.  All stream float4 along the channel axis; reductions are two-stage and
+// deterministic.  References: nn.MaxPool2d(3,2,1) simpleAICV/detection/models/backbones/
+// resnet.py:50; F.interpolate(mode='bilinear', align_corners=True)+add fpn.py:65-73;
+// nn.ReLU head.py:27,67 / fpn.py:56; nn.Sigmoid head.py:50.
+#include "sacv_common.h"
+
+// ---------------------------------------------------------------- max pool
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           unsigned char* __restrict__ idx, int Nb, int H, int W,
+                                                           int C, int Ho, int Wo, int k, int s, int p) {
+  const int cg = C >> 2;
+  size_t total = (size_t)Nb * Ho * Wo * cg;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c4 = (int)(i % cg);
+    size_t q = i / cg;
+    int wo = (int)(q % Wo);
+    q /= Wo;
+    int ho = (int)(q % Ho);
+    int n = (int)(q / Ho);
+    f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bi[4] = {0, 0, 0, 0};
+    bool first[4] = {true, true, true, true};
+    for (int kh = 0; kh < k; ++kh) {
+      int hi = ho * s - p + kh;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int kw = 0; kw < k; ++kw) {
+        int wi = wo * s - p + kw;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)(n * H + hi) * W + wi) * C + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // first maximum in window scan order wins (torch CPU max_pool2d); NaN propagates
+          if (first[e] || v[e] > best[e] || v[e] != v[e]) {
+            best[e] = v[e];
+            bi[e] = kh * k + kw;
+            first[e] = false;
+          }
+        }
+      }
+    }
+    size_t o = ((size_t)(n * Ho + ho) * Wo + wo) * C + c4 * 4;
+    *reinterpret_cast<f32x4*>(y + o) = best;
+    if (idx) {
+      uchar4 b = make_uchar4((unsigned char)bi[0], (unsigned char)bi[1], (unsigned char)bi[2], (unsigned char)bi[3]);
+      *reinterpret_cast<uchar4*>(idx + o) = b;
+    }
+  }
+}
+
+// gather form of the backward: each input pixel sums the windows that selected it
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy,
+                                                           const unsigned char* __restrict__ idx,
+                                                           float* __restrict__ dx, int Nb, int H, int W, int C,
+                                                           int Ho, int Wo, int k, int s, int p) {
+  const int cg = C >> 2;
+  size_t total = (size_t)Nb * H * W * cg;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c4 = (int)(i % cg);
+    size_t q = i / cg;
+    int wi = (int)(q % W);
+    q /= W;
+    int hi = (int)(q % H);
+    int n = (int)(q / H);
+    f32x4 acc = {0, 0, 0, 0};
+    // windows ho with ho*s - p <= hi <= ho*s - p + k - 1
+    int ho_lo = (hi + p - (k - 1) + s - 1) / s;
+    if (hi + p - (k - 1) < 0) ho_lo = 0;
+    int ho_hi = min(Ho - 1, (hi + p) / s);
+    int wo_lo = (wi + p - (k - 1) + s - 1) / s;
+    if (wi + p - (k - 1) < 0) wo_lo = 0;
+    int wo_hi = min(Wo - 1, (wi + p) / s);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      int kh = hi - (ho * s - p);
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        int kw = wi - (wo * s - p);
+        int code = kh * k + kw;
+        size_t o = ((size_t)(n * Ho + ho) * Wo + wo) * C + c4 * 4;
+        uchar4 b = *reinterpret_cast<const uchar4*>(idx + o);
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + o);
+        if (b.x == code) acc[0] += g[0];
+        if (b.y == code) acc[1] += g[1];
+        if (b.z == code) acc[2] += g[2];
+        if (b.w == code) acc[3] += g[3];
+      }
+    }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
+  }
+}
+
+// ---------------------------------------------------------------- bilinear upsample (align_corners) + add
+__device__ __forceinline__ void src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+  float src = scale * (float)dst;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+// out[n,h,w,c] = lateral[n,h,w,c] + bilinear(top)[n,h,w,c]
+__global__ __launch_bounds__(256) void upsample_add_fwd_kernel(const float* __restrict__ top,
+                                                                const float* __restrict__ lateral,
+                                                                float* __restrict__ out, int Nb, int Hs, int Ws,
+                                                                int Hd, int Wd, int C, float sh, float sw) {
+  const int cg = C >> 2;
+  size_t total = (size_t)Nb * Hd * Wd * cg;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c4 = (int)(i % cg);
+    size_t q = i / cg;
+    int w = (int)(q % Wd);
+    q /= Wd;
+    int h = (int)(q % Hd);
+    int n = (int)(q / Hd);
+    int h0, h1, w0, w1;
+    float lh, lw;
+    src_index(h, sh, Hs, h0, h1, lh);
+    src_index(w, sw, Ws, w0, w1, lw);
+    float hh = 1.f - lh, hw = 1.f - lw;
+    const float* b = top + (size_t)n * Hs * Ws * C + c4 * 4;
+    f32x4 v00 = *reinterpret_cast<const f32x4*>(b + ((size_t)h0 * Ws + w0) * C);
+    f32x4 v01 = *reinterpret_cast<const f32x4*>(b + ((size_t)h0 * Ws + w1) * C);
+    f32x4 v10 = *reinterpret_cast<const f32x4*>(b + ((size_t)h1 * Ws + w0) * C);
+    f32x4 v11 = *reinterpret_cast<const f32x4*>(b + ((size_t)h1 * Ws + w1) * C);
+    f32x4 up = hh * (hw * v00 + lw * v01) + lh * (hw * v10 + lw * v11);
+    f32x4 lat = *reinterpret_cast<const f32x4*>(lateral + i * 4);
+    *reinterpret_cast<f32x4*>(out + i * 4) = up + lat;
+  }
+}
+
+// dtop[n,hs,ws,c] (+)= sum over destination pixels that sampled (hs,ws) of weight * dout
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dtop,
+                                                            int Nb, int Hs, int Ws, int Hd, int Wd, int C, float sh,
+                                                            float sw, int accumulate) {
+  const int cg = C >> 2;
+  size_t total = (size_t)Nb * Hs * Ws * cg;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int c4 = (int)(i % cg);
+    size_t q = i / cg;
+    int ws = (int)(q % Ws);
+    q /= Ws;
+    int hs = (int)(q % Hs);
+    int n = (int)(q / Hs);
+    // candidate destination range (generous; exact membership is re-tested with the forward formula)
+    int h_lo = (sh > 0.f) ? max(0, (int)floorf((float)(hs - 1) / sh) - 1) : 0;
+    int h_hi = (sh > 0.f) ? min(Hd - 1, (int)ceilf((float)(hs + 1) / sh) + 1) : Hd - 1;
+    int w_lo = (sw > 0.f) ? max(0, (int)floorf((float)(ws - 1) / sw) - 1) : 0;
+    int w_hi = (sw > 0.f) ? min(Wd - 1, (int)ceilf((float)(ws + 1) / sw) + 1) : Wd - 1;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int h = h_lo; h <= h_hi; ++h) {
+      int h0, h1;
+      float lh;
+      src_index(h, sh, Hs, h0, h1, lh);
+      float wy = 0.f;
+      if (h0 == hs) wy += 1.f - lh;
+      if (h1 == hs) wy += lh;
+      if (h0 != hs && h1 != hs) continue;
+      for (int w = w_lo; w <= w_hi; ++w) {
+        int w0, w1;
+        float lw;
+        src_index(w, sw, Ws, w0, w1, lw);
+        if (w0 != ws && w1 != ws) continue;
+        float wx = 0.f;
+        if (w0 == ws) wx += 1.f - lw;
+        if (w1 == ws) wx += lw;
+        f32x4 g = *reinterpret_cast<const f32x4*>(dout + ((size_t)(n * Hd + h) * Wd + w) * C + c4 * 4);
+        acc += (wy * wx) * g;
+      }
+    }
+    if (accumulate) acc += *reinterpret_cast<const f32x4*>(dtop + i * 4);
+    *reinterpret_cast<f32x4*>(dtop + i * 4) = acc;
+  }
+}
+
+// ---------------------------------------------------------------- elementwise
+// op 0: out = relu(a); 1: out = a * (b > 0); 2: out = a * b * (1 - b)  (sigmoid backward, b = prob);
+// 3: out = a + b; 4: out = a * scalar; 5: out = a * scalar * b * (1 - b)
+__global__ __launch_bounds__(256) void eltwise_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       float* __restrict__ out, size_t n, int op, float scalar) {
+  size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 x = *reinterpret_cast<const f32x4*>(a + i * 4);
+    f32x4 y = {0, 0, 0, 0};
+    if (b) y = *reinterpret_cast<const f32x4*>(b + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v;
+      switch (op) {
+        case 0: v = fmaxf(x[e], 0.f); break;
+        case 1: v = y[e] > 0.f ? x[e] : 0.f; break;
+        case 2: v = x[e] * y[e] * (1.f - y[e]); break;
+        case 3: v = x[e] + y[e]; break;
+        case 4: v = x[e] * scalar; break;
+        default: v = x[e] * scalar * y[e] * (1.f - y[e]); break;
+      }
+      o[e] = v;
+    }
+    *reinterpret_cast<f32x4*>(out + i * 4) = o;
+  }
+  // tail
+  size_t t = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) {
+    float x = a[t], y = b ? b[t] : 0.f, v;
+    switch (op) {
+      case 0: v = fmaxf(x, 0.f); break;
+      case 1: v = y > 0.f ? x : 0.f; break;
+      case 2: v = x * y * (1.f - y); break;
+      case 3: v = x + y; break;
+      case 4: v = x * scalar; break;
+      default: v = x * scalar * y * (1.f - y); break;
+    }
+    out[t] = v;
+  }
+}
+
+// ---------------------------------------------------------------- column sum  out[c] (+)= sum_r x[r][c]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
+                                                              int R, int C, int rows_per_block) {
+  const int r_begin = blockIdx.x * rows_per_block;
+  const int r_end = min(R, r_begin + rows_per_block);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int r = r_begin; r < r_end; ++r) s += x[(size_t)r * C + c];
+    partial[(size_t)blockIdx.x * C + c] = s;
+  }
+}
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ out,
+                                       int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * C + c];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+static int grid_for(size_t work, int cap = 8192) {
+  size_t b = (work + 255) / 256;
+  if (b < 1) b = 1;
+  return (int)(b > (size_t)cap ? cap : b);
+}
+
+extern "C" {
+
+int sacv_maxpool_fwd(const float* x, float* y, unsigned char* idx, int Nb, int H, int W, int C, int Ho, int Wo,
+                     int k, int s, int p, void* stream) {
+  SACV_CHECK_ARG(x && y, "maxpool_fwd: null pointer");
+  SACV_CHECK_ARG(C % 4 == 0 && k * k <= 255, "maxpool_fwd: bad C/k");
+  SACV_CHECK_ARG(Ho == (H + 2 * p - k) / s + 1 && Wo == (W + 2 * p - k) / s + 1, "maxpool_fwd: output dims mismatch");
+  size_t total = (size_t)Nb * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, idx, Nb, H,
+                     W, C, Ho, Wo, k, s, p);
+  SACV_CHECK_LAUNCH("maxpool_fwd");
+  return SACV_OK;
+}
+
+int sacv_maxpool_bwd(const float* dy, const unsigned char* idx, float* dx, int Nb, int H, int W, int C, int Ho,
+                     int Wo, int k, int s, int p, void* stream) {
+  SACV_CHECK_ARG(dy && idx && dx, "maxpool_bwd: null pointer");
+  SACV_CHECK_ARG(C % 4 == 0, "maxpool_bwd: C %% 4");
+  size_t total = (size_t)Nb * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, Nb, H,
+                     W, C, Ho, Wo, k, s, p);
+  SACV_CHECK_LAUNCH("maxpool_bwd");
+  return SACV_OK;
+}
+
+static float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+int sacv_upsample_bilinear_add_fwd(const float* top, const float* lateral, float* out, int Nb, int Hs, int Ws,
+                                   int Hd, int Wd, int C, void* stream) {
+  SACV_CHECK_ARG(top && lateral && out, "upsample_add_fwd: null pointer");
+  SACV_CHECK_ARG(C % 4 == 0, "upsample_add_fwd: C %% 4");
+  size_t total = (size_t)Nb * Hd * Wd * (C / 4);
+  hipLaunchKernelGGL(upsample_add_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, top, lateral,
+                     out, Nb, Hs, Ws, Hd, Wd, C, ac_scale(Hs, Hd), ac_scale(Ws, Wd));
+  SACV_CHECK_LAUNCH("upsample_add_fwd");
+  return SACV_OK;
+}
+
+int sacv_upsample_bilinear_bwd(const float* dout, float* dtop, int Nb, int Hs, int Ws, int Hd, int Wd, int C,
+                               int accumulate, void* stream) {
+  SACV_CHECK_ARG(dout && dtop, "upsample_bwd: null pointer");
+  SACV_CHECK_ARG(C % 4 == 0, "upsample_bwd: C %% 4");
+  size_t total = (size_t)Nb * Hs * Ws * (C / 4);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dout, dtop, Nb, Hs,
+                     Ws, Hd, Wd, C, ac_scale(Hs, Hd), ac_scale(Ws, Wd), accumulate);
+  SACV_CHECK_LAUNCH("upsample_bwd");
+  return SACV_OK;
+}
+
+int sacv_eltwise(const float* a, const float* b, float* out, long long n, int op, float scalar, void* stream) {
+  SACV_CHECK_ARG(a && out && n >= 0, "eltwise: null pointer");
+  SACV_CHECK_ARG(op >= 0 && op <= 5, "eltwise: unknown op %d", op);
+  SACV_CHECK_ARG(b || op == 0 || op == 4, "eltwise: op %d needs a second operand", op);
+  if (n == 0) return SACV_OK;
+  hipLaunchKernelGGL(eltwise_kernel, dim3(grid_for((size_t)n / 4 + 4)), dim3(256), 0, (hipStream_t)stream, a, b, out,
+                     (size_t)n, op, scalar);
+  SACV_CHECK_LAUNCH("eltwise");
+  return SACV_OK;
+}
+
+long long sacv_colsum_workspace_floats(int R, int C) {
+  int nb = R < 256 ? 1 : (R < 65536 ? 64 : 512);
+  return (long long)nb * C;
+}
+
+int sacv_colsum(const float* x, float* out, int R, int C, int accumulate, float* workspace, void* stream) {
+  SACV_CHECK_ARG(x && out && workspace && R > 0 && C > 0, "colsum: bad args");
+  int nb = R < 256 ? 1 : (R < 65536 ? 64 : 512);
+  int rpb = (R + nb - 1) / nb;
+  nb = (R + rpb - 1) / rpb;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, x, workspace, R, C, rpb);
+  SACV_CHECK_LAUNCH("colsum_partial");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, workspace, nb, C, out,
+                     accumulate);
+  SACV_CHECK_LAUNCH("colsum_finalize");
+  return SACV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+"""RetinaDecoder with the reference's constructor / call contract (simpleAICV/detection/
+decode.py:175-271 + DecodeMethod :107-172 + DetNMSMethod :26-104), run on the device:
+argmax/score, box decode with int32 truncation, score > threshold, exact top-n, hard
+class-agnostic NMS (python_nms or diou_python_nms), pad to max_object_num.  Only the three
+small result arrays ([B,100], [B,100], [B,100,4]) cross PCIe; they are returned as host
+NumPy float32 arrays because the caller edits them in place (tools/scripts.py:742-758).
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from .losses import AnchorCache
+
+__all__ = ['RetinaDecoder']
+
+_NMS = {'python_nms': 0, 'diou_python_nms': 1}
+
+
+class RetinaDecoder:
+
+    def __init__(self, areas=[[32, 32], [64, 64], [128, 128], [256, 256], [512, 512]], ratios=[0.5, 1, 2],
+                 scales=[2**0, 2**(1.0 / 3.0), 2**(2.0 / 3.0)], strides=[8, 16, 32, 64, 128], max_object_num=100,
+                 min_score_threshold=0.05, topn=1000, nms_type='python_nms', nms_threshold=0.5):
+        assert nms_type in ['torch_nms', 'python_nms', 'diou_python_nms'], 'wrong nms type!'
+        if nms_type not in _NMS:
+            raise NotImplementedError('nms_type=torch_nms needs torchvision (absent); use python_nms / '
+                                      'diou_python_nms, which run as HIP kernels')
+        self.anchors = AnchorCache(areas, ratios, scales, strides)
+        self.max_object_num, self.min_score_threshold, self.topn = max_object_num, min_score_threshold, topn
+        self.nms_type, self.nms_threshold = nms_type, nms_threshold
+
+    def device_call(self, preds):
+        """-> (scores [B,M], classes [B,M], boxes [B,M,4]) fp32 tensors on the device."""
+        cls_preds, reg_preds = preds
+        device = cls_preds[0].device
+        if device.type != 'cuda':
+            raise RuntimeError('sacv_amd RetinaDecoder runs on MI355X only (no CPU fallback)')
+        feature_sizes = [[p.shape[2], p.shape[1]] for p in cls_preds]
+        anchors = self.anchors.get(feature_sizes, device)
+        cls_c = [p.detach().float().contiguous() for p in cls_preds]
+        reg_c = [p.detach().float().contiguous() for p in reg_preds]
+        return ops.decode_topk_nms(0, cls_c, reg_c, None, anchors, float(np.float32(self.min_score_threshold)),
+                                   self.topn, _NMS[self.nms_type], float(np.float32(self.nms_threshold)),
+                                   self.max_object_num)
+
+    def __call__(self, preds):
+        s, c, b = self.device_call(preds)
+        return [s.cpu().numpy(), c.cpu().numpy(), b.cpu().numpy()]

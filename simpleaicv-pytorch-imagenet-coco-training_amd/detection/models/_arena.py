@@ -1,0 +1,62 @@
+"""Flat fp32 parameter / gradient arenas.
+
+All trainable tensors of a detector live in ONE contiguous buffer (and their gradients in a
+second one of the same layout), ordered [1-D tensors | >=2-D tensors], every tensor padded
+to a multiple of 4 floats.  This is what makes the optimizer a single fused AdamW launch
+(two weight-decay groups = one split index, tools/utils.py:484-509) and a gradient bucket a
+zero-copy slice for the RCCL all-reduce.  nn.Parameter objects keep their reference names
+and shapes: their .data are views into the arena, so state_dict()/load_state_dict() work.
+"""
+import torch
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class ParamArena:
+
+    def __init__(self, module):
+        named = [(n, p) for n, p in module.named_parameters()]
+        if not named:
+            raise ValueError('module has no parameters')
+        dev = named[0][1].device
+        one_d = [(n, p) for n, p in named if p.ndim == 1]
+        multi = [(n, p) for n, p in named if p.ndim != 1]
+        self.order = one_d + multi
+        self.offsets = {}
+        off = 0
+        for n, p in one_d:
+            self.offsets[n] = off
+            off += _pad4(p.numel())
+        self.split = off
+        for n, p in multi:
+            self.offsets[n] = off
+            off += _pad4(p.numel())
+        self.numel = off
+        self.device = dev
+        self.params = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grads = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad_views = {}
+        self._ptrs = {}
+        with torch.no_grad():
+            for n, p in self.order:
+                o = self.offsets[n]
+                view = self.params[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                self.grad_views[n] = self.grads[o:o + p.numel()].view(p.shape)
+                self._ptrs[n] = view.data_ptr()
+        self.module_params = dict(self.order)
+
+    def is_current(self):
+        """False when something (.to(), .cuda(), load via assignment) re-allocated a parameter."""
+        for n, p in self.order:
+            if p.data_ptr() != self._ptrs[n]:
+                return False
+        return True
+
+    def attach_grads(self):
+        """Expose the gradient arena as p.grad (no copies)."""
+        for n, p in self.order:
+            p.grad = self.grad_views[n]

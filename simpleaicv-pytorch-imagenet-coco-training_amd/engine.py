@@ -1,0 +1,317 @@
+"""Forward/backward executor of the RetinaNet-/FCOS-ResNet50 detector on the HIP kernels.
+
+The network is a fixed graph, so instead of a per-op autograd tape the executor runs a
+hand-ordered forward that keeps exactly the activations the backward needs and a
+hand-ordered backward that writes parameter gradients straight into the flat gradient
+arena (see detection/models/_arena.py).  Everything that executes on the GPU is a kernel
+from libsacv_hip.so; tensors are NHWC.
+
+Reference graph: ResNetBackbone.forward (simpleAICV/detection/models/backbones/resnet.py:
+96-113), Bottleneck.forward (simpleAICV/classification/backbones/resnet.py:141-155),
+RetinaFPN.forward (simpleAICV/detection/models/fpn.py:60-87), RetinaClsHead/RetinaRegHead
+(head.py:46-52, 81-85), RetinaNet.forward (retinanet.py:61-94).
+"""
+import torch
+
+from . import ops
+from .ops import CF_RELU, CF_SIGMOID, CF_ACCUM, CF_MASK, PACK_FWD, PACK_DGRAD, PACK_STEM
+
+RESNET50_LAYERS = (3, 4, 6, 3)
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _out_hw(h, w, k, s, p):
+    return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+
+
+class _CBA:
+    """Saved state of one conv + BatchNorm (+ residual) (+ ReLU) layer."""
+    __slots__ = ('prefix', 'x', 'y', 'mean', 'invstd', 'z', 'k', 'stride', 'pad', 'relu', 'residual')
+
+
+class DetectorEngine:
+    """Executes one detector (RetinaNet when fcos=False).
+
+    p: dict name -> parameter/buffer tensor (reference state_dict key names)
+    g: dict name -> gradient tensor of the same shape (views into the flat gradient arena)
+    """
+
+    def __init__(self, p, g, num_classes=80, num_anchors=9, planes=256, fcos=False):
+        self.p, self.g = p, g
+        self.num_classes, self.num_anchors, self.planes, self.fcos = num_classes, num_anchors, planes, fcos
+        if fcos:
+            raise NotImplementedError('FCOS execution is not built yet (next SURVEY.md 8 row)')
+        self.ctx = None
+
+    # ------------------------------------------------------------------ building blocks
+    def _cba_fwd(self, x, prefix, k, stride, pad, relu, training, residual=None, keep=True):
+        p = self.p
+        w = p[prefix + '.layer.0.weight']
+        cout = w.shape[0]
+        wp = ops.pack_weight(w, PACK_FWD)
+        hw = _out_hw(x.shape[1], x.shape[2], k, stride, pad)
+        y = ops.conv_gemm([x], wp, cout, k, k, stride, pad, 0, [hw])[0]
+        return self._bn_fwd(x, y, prefix, k, stride, pad, relu, training, residual, keep)
+
+    def _bn_fwd(self, x, y, prefix, k, stride, pad, relu, training, residual, keep):
+        p = self.p
+        bn = prefix + '.layer.1.'
+        if training:
+            mean, invstd = ops.bn_train_stats(y, BN_EPS, BN_MOMENTUM, p[bn + 'running_mean'], p[bn + 'running_var'],
+                                              p[bn + 'num_batches_tracked'])
+            z = ops.bn_apply(y, mean, invstd, p[bn + 'weight'], p[bn + 'bias'], residual, relu)
+        else:
+            mean = invstd = None
+            z = ops.bn_apply(y, p[bn + 'running_mean'], p[bn + 'running_var'], p[bn + 'weight'], p[bn + 'bias'],
+                             residual, relu, stat_is_var=True, eps=BN_EPS)
+        if not keep:
+            return z, None
+        c = _CBA()
+        c.prefix, c.x, c.y, c.mean, c.invstd, c.z = prefix, x, y, mean, invstd, z
+        c.k, c.stride, c.pad, c.relu, c.residual = k, stride, pad, relu, residual is not None
+        return z, c
+
+    def _cba_bwd(self, c, dz, need_dx=True, want_g=False, dx_out=None, dx_accum=False):
+        """Backward of one layer.  Returns (dx, g) where g is the ReLU-masked upstream gradient."""
+        p, g = self.p, self.g
+        bn = c.prefix + '.layer.1.'
+        wname = c.prefix + '.layer.0.weight'
+        dy, gm = ops.bn_train_bwd(dz, c.z if c.relu else None, c.y, c.mean, c.invstd, p[bn + 'weight'],
+                                  g[bn + 'weight'], g[bn + 'bias'], want_g=want_g)
+        w = p[wname]
+        cin = w.shape[1]
+        ops.conv_wgrad([dy], [c.x], g[wname], cin, c.k, c.k, c.stride, c.pad)
+        dx = None
+        if need_dx:
+            dx = self._dgrad(dy, w, c.x.shape, c.k, c.stride, c.pad, out=dx_out, accumulate=dx_accum)
+        return dx, gm
+
+    def _dgrad(self, dy, w, x_shape, k, stride, pad, out=None, accumulate=False, mask=None):
+        cin = w.shape[1]
+        wd = ops.pack_weight(w, PACK_DGRAD)
+        n, h, wdt, _ = x_shape
+        flags = (CF_ACCUM if accumulate else 0) | (CF_MASK if mask is not None else 0)
+        if k == 1 and stride > 1:
+            # 1x1 strided conv: only every stride-th input pixel receives gradient -> GEMM over the
+            # dy pixels scattered (accumulated) into dx
+            if out is None:
+                out = torch.zeros(x_shape, device=dy.device, dtype=torch.float32)
+                flags |= CF_ACCUM
+            elif not accumulate:
+                raise ValueError('strided 1x1 dgrad writes a sparse pattern: out must be accumulated into')
+            ops.conv_gemm([dy], wd, cin, 1, 1, 1, 0, 0, [(dy.shape[1], dy.shape[2])], flags=flags,
+                          outs=[out], remap=(stride, h, wdt))
+            return out
+        outs = [out] if out is not None else None
+        return ops.conv_gemm([dy], wd, cin, k, k, stride, pad, 1, [(h, wdt)], flags=flags,
+                             masks=[mask] if mask is not None else None, outs=outs)[0]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, images, training=True, keep=True):
+        """images: logical [B,3,H,W] fp32 (any strides).  Returns (cls_levels, reg_levels)."""
+        p = self.p
+        ctx = {} if keep else None
+        b, _, h, w = images.shape
+        # stem: explicit im2col (Cin=3) + GEMM, BN, ReLU, 3x3/s2 max pool
+        ho, wo = _out_hw(h, w, 7, 2, 3)
+        col = ops.im2col_stem(images, ho, wo)
+        wst = ops.pack_weight(p['backbone.conv1.layer.0.weight'], PACK_STEM)
+        y = ops.conv_gemm([col], wst, 64, 1, 1, 1, 0, 0, [(ho, wo)])[0]
+        z, c = self._bn_fwd(col, y, 'backbone.conv1', 7, 2, 3, True, training, None, keep)
+        x, pool_idx = ops.maxpool_fwd(z, 3, 2, 1, want_idx=keep)
+        if keep:
+            ctx['stem'] = c
+            ctx['pool_idx'] = pool_idx
+            ctx['pool_in_shape'] = tuple(z.shape)
+        feats = []
+        blocks = []
+        for li, n in enumerate(RESNET50_LAYERS, start=1):
+            for bi in range(n):
+                pre = f'backbone.layer{li}.{bi}'
+                stride = 2 if (bi == 0 and li > 1) else 1
+                has_ds = (pre + '.downsample_conv.layer.0.weight') in p
+                z1, c1 = self._cba_fwd(x, pre + '.conv1', 1, 1, 0, True, training, keep=keep)
+                z2, c2 = self._cba_fwd(z1, pre + '.conv2', 3, stride, 1, True, training, keep=keep)
+                if has_ds:
+                    idt, cd = self._cba_fwd(x, pre + '.downsample_conv', 1, stride, 0, False, training, keep=keep)
+                else:
+                    idt, cd = x, None
+                out, c3 = self._cba_fwd(z2, pre + '.conv3', 1, 1, 0, True, training, residual=idt, keep=keep)
+                blocks.append((c1, c2, c3, cd, li, bi))
+                x = out
+            feats.append(x)
+        c3f, c4f, c5f = feats[1], feats[2], feats[3]
+        fpn = self._fpn_fwd(c3f, c4f, c5f, ctx)
+        cls_levels, reg_levels = self._heads_fwd(fpn, ctx)
+        if keep:
+            ctx['blocks'] = blocks
+            self.ctx = ctx
+        return cls_levels, reg_levels
+
+    def _conv_bias(self, x, name, k, stride, pad, flags=0):
+        w = self.p[name + '.weight']
+        wp = ops.pack_weight(w, PACK_FWD)
+        hw = _out_hw(x.shape[1], x.shape[2], k, stride, pad)
+        return ops.conv_gemm([x], wp, w.shape[0], k, k, stride, pad, 0, [hw], bias=self.p[name + '.bias'],
+                             flags=flags)[0]
+
+    def _fpn_fwd(self, c3, c4, c5, ctx):
+        p5 = self._conv_bias(c5, 'fpn.P5_1', 1, 1, 0)
+        p4l = self._conv_bias(c4, 'fpn.P4_1', 1, 1, 0)
+        p4 = ops.upsample_add_fwd(p5, p4l)
+        p3l = self._conv_bias(c3, 'fpn.P3_1', 1, 1, 0)
+        p3 = ops.upsample_add_fwd(p4, p3l)
+        p5o = self._conv_bias(p5, 'fpn.P5_2', 3, 1, 1)
+        p4o = self._conv_bias(p4, 'fpn.P4_2', 3, 1, 1)
+        p3o = self._conv_bias(p3, 'fpn.P3_2', 3, 1, 1)
+        p6 = self._conv_bias(c5, 'fpn.P6', 3, 2, 1)
+        p6r = ops.eltwise(ops.EW_RELU, p6)
+        p7 = self._conv_bias(p6r, 'fpn.P7.1', 3, 2, 1)
+        if ctx is not None:
+            ctx['fpn'] = dict(c3=c3, c4=c4, c5=c5, p5=p5, p4=p4, p3=p3, p6=p6, p6r=p6r)
+        return [p3o, p4o, p5o, p6, p7]
+
+    def _tower_fwd(self, feats, tower, out_name, n_out, out_flags, ctx):
+        p = self.p
+        xs = feats
+        hw = [(f.shape[1], f.shape[2]) for f in feats]
+        saved = []
+        for i in (0, 2, 4, 6):
+            name = f'{tower}.{i}'
+            wp = ops.pack_weight(p[name + '.weight'], PACK_FWD)
+            saved.append(xs)
+            xs = ops.conv_gemm(xs, wp, self.planes, 3, 3, 1, 1, 0, hw, bias=p[name + '.bias'], flags=CF_RELU)
+        saved.append(xs)
+        wp = ops.pack_weight(p[out_name + '.weight'], PACK_FWD)
+        outs = ops.conv_gemm(xs, wp, n_out, 3, 3, 1, 1, 0, hw, bias=p[out_name + '.bias'], flags=out_flags)
+        if ctx is not None:
+            ctx[tower] = saved
+        return outs
+
+    def _heads_fwd(self, feats, ctx):
+        a, nc = self.num_anchors, self.num_classes
+        cls = self._tower_fwd(feats, 'cls_head.cls_head', 'cls_head.cls_out', a * nc, CF_SIGMOID, ctx)
+        reg = self._tower_fwd(feats, 'reg_head.reg_head', 'reg_head.reg_out', a * 4, 0, ctx)
+        if ctx is not None:
+            ctx['cls_probs'] = cls
+            ctx['feat_shapes'] = [tuple(f.shape) for f in feats]
+        cls_levels = [t.view(t.shape[0], t.shape[1], t.shape[2], a, nc) for t in cls]
+        reg_levels = [t.view(t.shape[0], t.shape[1], t.shape[2], a, 4) for t in reg]
+        return cls_levels, reg_levels
+
+    # ------------------------------------------------------------------ backward
+    def _bias_grad(self, dys, name):
+        gb = self.g[name + '.bias']
+        c = gb.numel()
+        for i, d in enumerate(dys):
+            ops.colsum(d, c, gb, accumulate=i > 0)
+
+    def _tower_bwd(self, dys, tower, out_name, accum_into=None):
+        """dys: per-level grads w.r.t. the tower's output conv result (pre-activation)."""
+        p, g = self.p, self.g
+        saved = self.ctx[tower]
+        xs = saved[4]
+        w = p[out_name + '.weight']
+        ops.conv_wgrad(dys, xs, g[out_name + '.weight'], w.shape[1], 3, 3, 1, 1)
+        self._bias_grad(dys, out_name)
+        hw = [(x.shape[1], x.shape[2]) for x in xs]
+        cur = ops.conv_gemm(dys, ops.pack_weight(w, PACK_DGRAD), w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_MASK,
+                            masks=xs)
+        for li, i in reversed(list(enumerate((0, 2, 4, 6)))):
+            name = f'{tower}.{i}'
+            w = p[name + '.weight']
+            xs = saved[li]
+            ops.conv_wgrad(cur, xs, g[name + '.weight'], w.shape[1], 3, 3, 1, 1)
+            self._bias_grad(cur, name)
+            wd = ops.pack_weight(w, PACK_DGRAD)
+            if li > 0:
+                cur = ops.conv_gemm(cur, wd, w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_MASK, masks=xs)
+            elif accum_into is not None:
+                cur = ops.conv_gemm(cur, wd, w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_ACCUM, outs=accum_into)
+            else:
+                cur = ops.conv_gemm(cur, wd, w.shape[1], 3, 3, 1, 1, 1, hw)
+        return cur
+
+    def _conv_bias_bwd(self, dy, x, name, k, stride, pad, need_dx=True, out=None, accumulate=False, mask=None):
+        w = self.p[name + '.weight']
+        ops.conv_wgrad([dy], [x], self.g[name + '.weight'], w.shape[1], k, k, stride, pad)
+        self._bias_grad([dy], name)
+        if need_dx:
+            return self._dgrad(dy, w, x.shape, k, stride, pad, out=out, accumulate=accumulate, mask=mask)
+        return None
+
+    def backward(self, dcls_levels, dreg_levels, grad_scale=1.0):
+        """dcls: grads w.r.t. the class PROBABILITIES, dreg: w.r.t. the box regressions (per level,
+        same shapes as the forward outputs).  Fills every entry of self.g (overwrite semantics)."""
+        ctx = self.ctx
+        if ctx is None:
+            raise RuntimeError('backward() without a preceding forward(keep=True)')
+        a, nc = self.num_anchors, self.num_classes
+        probs = ctx['cls_probs']
+        # sigmoid backward (and the upstream scalar) fused in one pass per level
+        dz_cls = []
+        for dprob, pr in zip(dcls_levels, probs):
+            d = dprob.reshape(pr.shape)
+            dz_cls.append(ops.eltwise(ops.EW_SCALE_SIGMOID_BWD, d, pr, scalar=grad_scale))
+        if grad_scale != 1.0:
+            dz_reg = [ops.eltwise(ops.EW_SCALE, d.reshape(d.shape[0], d.shape[1], d.shape[2], a * 4),
+                                  scalar=grad_scale) for d in dreg_levels]
+        else:
+            dz_reg = [d.reshape(d.shape[0], d.shape[1], d.shape[2], a * 4) for d in dreg_levels]
+        dfeat = self._tower_bwd(dz_cls, 'cls_head.cls_head', 'cls_head.cls_out')
+        dfeat = self._tower_bwd(dz_reg, 'reg_head.reg_head', 'reg_head.reg_out', accum_into=dfeat)
+        dc3, dc4, dc5 = self._fpn_bwd(dfeat)
+        # backbone, last block first
+        blocks = ctx['blocks']
+        dout = dc5
+        for c1, c2, c3, cd, li, bi in reversed(blocks):
+            accum_target = None
+            if bi == 0 and li == 4:
+                accum_target = dc4
+            elif bi == 0 and li == 3:
+                accum_target = dc3
+            dout = self._bottleneck_bwd(c1, c2, c3, cd, dout, accum_target)
+        # max pool + stem
+        dpool = ops.maxpool_bwd(dout, ctx['pool_idx'], ctx['pool_in_shape'], 3, 2, 1)
+        st = ctx['stem']
+        bn = 'backbone.conv1.layer.1.'
+        dy, _ = ops.bn_train_bwd(dpool, st.z, st.y, st.mean, st.invstd, self.p[bn + 'weight'], self.g[bn + 'weight'],
+                                 self.g[bn + 'bias'])
+        ops.conv_wgrad([dy], [st.x], self.g['backbone.conv1.layer.0.weight'], 3, 1, 1, 1, 0,
+                       cin_pad=ops.STEM_KPAD, dw_taps=49)
+        self.ctx = None
+
+    def _bottleneck_bwd(self, c1, c2, c3, cd, dout, accum_target):
+        # out = relu(bn3(conv3(z2)) + idt): g is the masked gradient shared by both branches
+        dz2, gshared = self._cba_bwd(c3, dout, want_g=True)
+        dz1, _ = self._cba_bwd(c2, dz2)
+        if cd is None:
+            # identity shortcut: dx = g + dgrad(conv1)
+            dx, _ = self._cba_bwd(c1, dz1, dx_out=gshared, dx_accum=True)
+            return dx
+        if accum_target is not None:
+            dx, _ = self._cba_bwd(c1, dz1, dx_out=accum_target, dx_accum=True)
+        else:
+            dx, _ = self._cba_bwd(c1, dz1)
+        self._cba_bwd(cd, gshared, dx_out=dx, dx_accum=True)
+        return dx
+
+    def _fpn_bwd(self, dfeat):
+        f = self.ctx['fpn']
+        dp3o, dp4o, dp5o, dp6, dp7 = dfeat
+        # P7 = conv(relu(P6)); P6 also feeds the heads directly
+        t = self._conv_bias_bwd(dp7, f['p6r'], 'fpn.P7.1', 3, 2, 1, mask=f['p6'])
+        dp6 = ops.eltwise(ops.EW_ADD, dp6, t, out=dp6)
+        dc5 = self._conv_bias_bwd(dp6, f['c5'], 'fpn.P6', 3, 2, 1)
+        dp5 = self._conv_bias_bwd(dp5o, f['p5'], 'fpn.P5_2', 3, 1, 1)
+        dp4 = self._conv_bias_bwd(dp4o, f['p4'], 'fpn.P4_2', 3, 1, 1)
+        dp3 = self._conv_bias_bwd(dp3o, f['p3'], 'fpn.P3_2', 3, 1, 1)
+        # P3 = up(P4) + P3_1(C3)
+        ops.upsample_bwd(dp3, dp4, accumulate=True)
+        dc3 = self._conv_bias_bwd(dp3, f['c3'], 'fpn.P3_1', 1, 1, 0)
+        # P4 = up(P5) + P4_1(C4)
+        ops.upsample_bwd(dp4, dp5, accumulate=True)
+        dc4 = self._conv_bias_bwd(dp4, f['c4'], 'fpn.P4_1', 1, 1, 0)
+        self._conv_bias_bwd(dp5, f['c5'], 'fpn.P5_1', 1, 1, 0, out=dc5, accumulate=True)
+        return dc3, dc4, dc5

@@ -1,0 +1,317 @@
+"""Tensor-level wrappers over the C ABI (libsacv_hip.so).
+
+torch is used for device memory and the current HIP stream only; every computation below is
+a hand-written gfx950 kernel reached through ctypes on raw device pointers.  All activations
+are NHWC-contiguous fp32 tensors of logical shape [N, H, W, C].
+"""
+import torch
+
+from . import _lib
+from ._lib import lib, check, iarr, farr, parr
+
+CF_BIAS, CF_RELU, CF_SIGMOID, CF_ACCUM, CF_MASK = 1, 2, 4, 8, 16
+PACK_FWD, PACK_DGRAD, PACK_STEM = 0, 1, 2
+STEM_KPAD = 160  # 7*7*3 = 147 padded to a multiple of 32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, name='tensor'):
+    if t.device.type != 'cuda' or t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError(f'{name}: expected a contiguous fp32 CUDA(HIP) tensor, got {t.dtype} {t.device} '
+                         f'contiguous={t.is_contiguous()}')
+    return t
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+# ------------------------------------------------------------------------------------------ conv
+def pack_weight(w_oihw, kind, out=None):
+    _chk(w_oihw, 'weight')
+    co, ci, kh, kw = w_oihw.shape
+    if kind == PACK_STEM:
+        shape, kpad = (co, STEM_KPAD), STEM_KPAD
+    elif kind == PACK_FWD:
+        shape, kpad = (co, kh * kw * ci), 0
+    else:
+        shape, kpad = (ci, kh * kw * co), 0
+    if out is None:
+        out = torch.empty(shape, device=w_oihw.device, dtype=torch.float32)
+    check(lib.sacv_pack_weight(_ptr(w_oihw), _ptr(out), co, ci, kh, kw, kind, kpad, _stream()), 'pack_weight')
+    return out
+
+
+def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=None, flags=0, masks=None,
+              outs=None, remap=None):
+    """Grouped implicit-GEMM conv.  srcs: list of NHWC tensors sharing the channel count.
+
+    mode 0: forward (out_hw[i] = output H,W);  mode 1: data gradient (out_hw[i] = input H,W).
+    remap = (s, Hr, Wr): single-problem strided scatter of the GEMM rows into a [N,Hr,Wr,n_out]
+    tensor (used for the 1x1 stride-s data gradient), requires outs and CF_ACCUM semantics.
+    """
+    n = len(srcs)
+    cs = srcs[0].shape[3]
+    if outs is None:
+        outs = [torch.empty((s.shape[0], hw[0], hw[1], n_out), device=s.device, dtype=torch.float32)
+                for s, hw in zip(srcs, out_hw)]
+    for s in srcs:
+        _chk(s, 'conv src')
+    if bias is not None:
+        flags |= CF_BIAS
+    rs, hr, wr = remap if remap else (0, 0, 0)
+    check(lib.sacv_conv2d_gemm(
+        n, parr([s.data_ptr() for s in srcs]), parr([o.data_ptr() for o in outs]),
+        parr([m.data_ptr() for m in masks]) if masks else None,
+        iarr([s.shape[0] for s in srcs]), iarr([s.shape[1] for s in srcs]), iarr([s.shape[2] for s in srcs]),
+        iarr([hw[0] for hw in out_hw]), iarr([hw[1] for hw in out_hw]),
+        _ptr(w_packed), _ptr(bias), cs, n_out, kh, kw, stride, pad, mode, flags, rs, hr, wr, _stream()),
+        'conv2d_gemm')
+    return outs
+
+
+def _wgrad_chunk(npix_total, cout, n2, target_blocks=1024):
+    bm = 64 if cout <= 64 else 128
+    bn = 64 if n2 <= 64 else 128
+    tiles = -(-cout // bm) * -(-n2 // bn)
+    chunks = max(1, min(target_blocks // tiles, -(-npix_total // 128)))
+    chunk = -(-npix_total // chunks)
+    return max(32, -(-chunk // 32) * 32)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag='ws'):
+    """Grow-only scratch buffer per tag (kernels on one stream reuse it in order)."""
+    key = (tag, device)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), device=device, dtype=torch.uint8)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, accumulate=False, cin_pad=None, dw_taps=0):
+    """dw (OIHW, contiguous view into the gradient arena) (+)= sum over problems of x (*) dy."""
+    n = len(dys)
+    cin_pad = cin_pad or cin
+    cout = dys[0].shape[3]
+    nb = [d.shape[0] for d in dys]
+    ho = [d.shape[1] for d in dys]
+    wo = [d.shape[2] for d in dys]
+    npix = sum(b * h * w for b, h, w in zip(nb, ho, wo))
+    chunk = _wgrad_chunk(npix, cout, kh * kw * cin_pad)
+    nbytes = lib.sacv_conv2d_wgrad_workspace_bytes(n, iarr(nb), iarr(ho), iarr(wo), cin_pad, cout, kh, kw, chunk)
+    ws = workspace(nbytes, dys[0].device, 'wgrad')
+    check(lib.sacv_conv2d_wgrad(
+        n, parr([d.data_ptr() for d in dys]), parr([x.data_ptr() for x in xs]), iarr(nb),
+        iarr([x.shape[1] for x in xs]), iarr([x.shape[2] for x in xs]), iarr(ho), iarr(wo),
+        _ptr(dw), ws.data_ptr(), cin, cin_pad, cout, kh, kw, stride, pad, chunk, int(accumulate), dw_taps,
+        _stream()), 'conv2d_wgrad')
+    return dw
+
+
+def im2col_stem(x_nchw_logical, ho, wo, kh=7, kw=7, stride=2, pad=3):
+    """x: logical [N,3,H,W] in ANY strides (NCHW-contiguous or channels_last) -> [N,ho,wo,STEM_KPAD]."""
+    x = x_nchw_logical
+    if x.device.type != 'cuda' or x.dtype != torch.float32:
+        raise ValueError('im2col_stem: expected an fp32 CUDA(HIP) tensor')
+    n, c, h, w = x.shape
+    col = torch.empty((n, ho, wo, STEM_KPAD), device=x.device, dtype=torch.float32)
+    sn, sc, sh, sw = x.stride()
+    check(lib.sacv_im2col_stem(_ptr(x), _ptr(col), n, c, h, w, sn, sc, sh, sw, ho, wo, kh, kw, stride, pad,
+                               STEM_KPAD, _stream()), 'im2col_stem')
+    return col
+
+
+# ------------------------------------------------------------------------------------------ norm
+def _bn_ws(r, c, device):
+    return workspace(lib.sacv_bn_workspace_floats(r, c) * 4, device, 'bn')
+
+
+def bn_train_stats(y, eps, momentum, running_mean, running_var, num_batches_tracked):
+    c = y.shape[-1]
+    r = y.numel() // c
+    mean = torch.empty(c, device=y.device, dtype=torch.float32)
+    invstd = torch.empty(c, device=y.device, dtype=torch.float32)
+    check(lib.sacv_bn_train_stats(_ptr(y), r, c, eps, momentum, _ptr(mean), _ptr(invstd), _ptr(running_mean),
+                                  _ptr(running_var), _ptr(num_batches_tracked), _bn_ws(r, c, y.device).data_ptr(),
+                                  _stream()), 'bn_train_stats')
+    return mean, invstd
+
+
+def bn_apply(y, mean, invstd_or_var, gamma, beta, residual=None, relu=False, stat_is_var=False, eps=1e-5,
+             out=None):
+    z = out if out is not None else torch.empty_like(y)
+    check(lib.sacv_bn_apply(_ptr(y), _ptr(mean), _ptr(invstd_or_var), _ptr(gamma), _ptr(beta), _ptr(residual),
+                            _ptr(z), y.numel(), y.shape[-1], int(relu), int(stat_is_var), eps, _stream()), 'bn_apply')
+    return z
+
+
+def bn_train_bwd(dz, zmask, y, mean, invstd, gamma, dgamma, dbeta, want_g=False, accumulate=False, dy_out=None):
+    c = y.shape[-1]
+    r = y.numel() // c
+    dy = dy_out if dy_out is not None else torch.empty_like(y)
+    g = torch.empty_like(y) if want_g else None
+    check(lib.sacv_bn_train_bwd(_ptr(dz), _ptr(zmask), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(dy),
+                                _ptr(g), _ptr(dgamma), _ptr(dbeta), r, c, int(accumulate),
+                                _bn_ws(r, c, y.device).data_ptr(), _stream()), 'bn_train_bwd')
+    return dy, g
+
+
+# ------------------------------------------------------------------------------------------ pointwise
+def maxpool_fwd(x, k=3, s=2, p=1, want_idx=True):
+    n, h, w, c = x.shape
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    y = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32)
+    idx = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8) if want_idx else None
+    check(lib.sacv_maxpool_fwd(_ptr(x), _ptr(y), _ptr(idx), n, h, w, c, ho, wo, k, s, p, _stream()), 'maxpool_fwd')
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, in_shape, k=3, s=2, p=1):
+    n, h, w, c = in_shape
+    dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
+    check(lib.sacv_maxpool_bwd(_ptr(dy), _ptr(idx), _ptr(dx), n, h, w, c, dy.shape[1], dy.shape[2], k, s, p,
+                               _stream()), 'maxpool_bwd')
+    return dx
+
+
+def upsample_add_fwd(top, lateral):
+    n, hs, ws_, c = top.shape
+    _, hd, wd, _ = lateral.shape
+    out = torch.empty_like(lateral)
+    check(lib.sacv_upsample_bilinear_add_fwd(_ptr(top), _ptr(lateral), _ptr(out), n, hs, ws_, hd, wd, c, _stream()),
+          'upsample_add_fwd')
+    return out
+
+
+def upsample_bwd(dout, dtop, accumulate):
+    n, hs, ws_, c = dtop.shape
+    _, hd, wd, _ = dout.shape
+    check(lib.sacv_upsample_bilinear_bwd(_ptr(dout), _ptr(dtop), n, hs, ws_, hd, wd, c, int(accumulate), _stream()),
+          'upsample_bwd')
+    return dtop
+
+
+EW_RELU, EW_RELU_BWD, EW_SIGMOID_BWD, EW_ADD, EW_SCALE, EW_SCALE_SIGMOID_BWD = 0, 1, 2, 3, 4, 5
+
+
+def eltwise(op, a, b=None, out=None, scalar=1.0):
+    out = out if out is not None else torch.empty_like(a)
+    check(lib.sacv_eltwise(_ptr(a), _ptr(b), _ptr(out), a.numel(), op, scalar, _stream()), 'eltwise')
+    return out
+
+
+def colsum(x2d_rows, c, out, accumulate=False):
+    r = x2d_rows.numel() // c
+    ws = workspace(lib.sacv_colsum_workspace_floats(r, c) * 4, x2d_rows.device, 'colsum')
+    check(lib.sacv_colsum(_ptr(x2d_rows), _ptr(out), r, c, int(accumulate), ws.data_ptr(), _stream()), 'colsum')
+    return out
+
+
+def fill(t, value):
+    check(lib.sacv_fill(_ptr(t), t.numel(), value, _stream()), 'fill')
+    return t
+
+
+# ------------------------------------------------------------------------------------------ detection
+def retina_anchors(feature_sizes, areas, ratios, scales, strides, device):
+    """feature_sizes: [[W,H],...] -> [A_total,4] fp32 on device (bit-exact vs the NumPy reference)."""
+    import numpy as np
+    nlev = len(feature_sizes)
+    a = len(ratios) * len(scales)
+    total = sum(w * h * a for w, h in feature_sizes)
+    out = torch.empty((total, 4), device=device, dtype=torch.float32)
+    f32 = lambda v: [float(x) for x in np.asarray(v, dtype=np.float32).reshape(-1)]
+    check(lib.sacv_retina_anchors(nlev, iarr([w for w, h in feature_sizes]), iarr([h for w, h in feature_sizes]),
+                                  farr(f32(areas)), farr(f32(ratios)), len(ratios), farr(f32(scales)), len(scales),
+                                  farr(f32(strides)), _ptr(out), _stream()), 'retina_anchors')
+    return out
+
+
+def fcos_points(feature_sizes, strides, device):
+    total = sum(w * h for w, h in feature_sizes)
+    out = torch.empty((total, 2), device=device, dtype=torch.float32)
+    check(lib.sacv_fcos_points(len(feature_sizes), iarr([w for w, h in feature_sizes]),
+                               iarr([h for w, h in feature_sizes]), farr(strides), _ptr(out), _stream()),
+          'fcos_points')
+    return out
+
+
+def retina_assign(anchors, annots, smooth_l1=True):
+    """-> (targets [B,A,5] fp32, counts int32[2] = (#positive, #label>=0))."""
+    _chk(anchors, 'anchors')
+    _chk(annots, 'annotations')
+    b, g, _ = annots.shape
+    a = anchors.shape[0]
+    targets = torch.empty((b, a, 5), device=anchors.device, dtype=torch.float32)
+    counts = torch.empty(2, device=anchors.device, dtype=torch.int32)
+    check(lib.sacv_retina_assign(_ptr(anchors), _ptr(annots), _ptr(targets), _ptr(counts), b, a, g, int(smooth_l1),
+                                 _stream()), 'retina_assign')
+    return targets, counts
+
+
+def _level_off(levels, per_row):
+    off = [0]
+    for t in levels:
+        off.append(off[-1] + t.numel() // (t.shape[0] * per_row))
+    return off
+
+
+def focal_loss(cls_levels, targets, counts, alpha, gamma, weight, loss_out, slot, want_grad=True, tstride=5):
+    """cls_levels: list of [B, ..., C] probability tensors.  Returns list of grad tensors (or None)."""
+    b = cls_levels[0].shape[0]
+    c = cls_levels[0].shape[-1]
+    off = _level_off(cls_levels, c)
+    grads = [torch.empty_like(t) for t in cls_levels] if want_grad else None
+    ws = workspace(lib.sacv_loss_workspace_floats() * 4, targets.device, 'loss')
+    check(lib.sacv_focal_loss_fwd_bwd(
+        len(cls_levels), parr([_chk(t, 'cls').data_ptr() for t in cls_levels]),
+        parr([g.data_ptr() for g in grads]) if grads else None, iarr(off), _ptr(targets), tstride, b, off[-1], c,
+        alpha, gamma, weight, _ptr(counts), ws.data_ptr(), _ptr(loss_out), slot, _stream()), 'focal_loss')
+    return grads
+
+
+BOX_SMOOTH_L1, BOX_IOU, BOX_GIOU = 0, 1, 2
+
+
+def retina_box_loss(reg_levels, targets, anchors, counts, box_type, beta, weight, loss_out, slot, want_grad=True):
+    b = reg_levels[0].shape[0]
+    off = _level_off(reg_levels, 4)
+    grads = [torch.empty_like(t) for t in reg_levels] if want_grad else None
+    ws = workspace(lib.sacv_loss_workspace_floats() * 4, targets.device, 'loss')
+    check(lib.sacv_retina_box_loss_fwd_bwd(
+        len(reg_levels), parr([_chk(t, 'reg').data_ptr() for t in reg_levels]),
+        parr([g.data_ptr() for g in grads]) if grads else None, iarr(off), _ptr(targets), _ptr(anchors), b, off[-1],
+        box_type, beta, weight, _ptr(counts), ws.data_ptr(), _ptr(loss_out), slot, _stream()), 'retina_box_loss')
+    return grads
+
+
+def decode_topk_nms(kind, cls_levels, reg_levels, ctr_levels, geom, min_score, topn, nms_type, nms_thr, max_obj):
+    b = cls_levels[0].shape[0]
+    c = cls_levels[0].shape[-1]
+    off = _level_off(reg_levels, 4)
+    a = off[-1]
+    dev = geom.device
+    ws = workspace(lib.sacv_decode_workspace_bytes(b, a, topn), dev, 'decode')
+    out_s = torch.empty((b, max_obj), device=dev, dtype=torch.float32)
+    out_c = torch.empty((b, max_obj), device=dev, dtype=torch.float32)
+    out_b = torch.empty((b, max_obj, 4), device=dev, dtype=torch.float32)
+    check(lib.sacv_decode_topk_nms(
+        kind, len(cls_levels), parr([_chk(t, 'cls').data_ptr() for t in cls_levels]),
+        parr([_chk(t, 'reg').data_ptr() for t in reg_levels]),
+        parr([_chk(t, 'ctr').data_ptr() for t in ctr_levels]) if ctr_levels else None, iarr(off), _ptr(geom), b, a, c,
+        min_score, topn, nms_type, nms_thr, max_obj, ws.data_ptr(), _ptr(out_s), _ptr(out_c), _ptr(out_b),
+        _stream()), 'decode_topk_nms')
+    return out_s, out_c, out_b
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, split, lr, beta1, beta2, eps, wd_lo, wd_hi, step,
+               grad_scale=1.0):
+    check(lib.sacv_adamw_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), split,
+                              lr, beta1, beta2, eps, wd_lo, wd_hi, step, grad_scale, _stream()), 'adamw_step')

@@ -1,0 +1,58 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/sacv_hip.h declares, and the Python mirror honours the reference's class contract
+(constructor kwargs, state_dict keys/shapes/order, parameter groups) captured from the reference
+in tests/golden/contract.json.  No kernels are launched here."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'sacv_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(sacv_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from sacv_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f'{s} declared in include/sacv_hip.h but not exported'
+    assert sorted(_lib.SIGNATURES) == syms, 'ctypes binding and header disagree'
+    assert _lib.lib.sacv_abi_version() == 1
+
+
+def test_state_dict_contract(golden_dir):
+    from sacv_amd.detection import models
+    c = json.load(open(os.path.join(golden_dir, 'contract.json')))['resnet50_retinanet']
+    m = models.__dict__['resnet50_retinanet'](backbone_pretrained_path='', num_classes=80)
+    sd = m.state_dict()
+    assert [(k, list(v.shape), str(v.dtype).replace('torch.', '')) for k, v in sd.items()] == \
+        [tuple(x) if False else (x[0], x[1], x[2]) for x in c['keys']]
+    assert [k for k, _ in m.named_parameters()] == [k for k, _ in c['params']]
+    assert sum(p.numel() for p in m.parameters()) == c['n_params'] == 37968692
+    one_d = [k for k, p in m.named_parameters() if p.ndim == 1]
+    assert one_d == c['one_dim_params'] and len(one_d) == 124
+
+
+def test_no_cpu_fallback():
+    import torch
+    from sacv_amd.detection import models, losses, decode
+    m = models.__dict__['resnet50_retinanet']()
+    with pytest.raises(RuntimeError, match='MI355X'):
+        m(torch.zeros(1, 3, 64, 64))
+    crit = losses.__dict__['RetinaLoss']()
+    with pytest.raises(RuntimeError, match='MI355X'):
+        crit([[torch.zeros(1, 2, 2, 9, 80)], [torch.zeros(1, 2, 2, 9, 4)]], torch.zeros(1, 3, 5))
+    dec = decode.__dict__['RetinaDecoder']()
+    with pytest.raises(RuntimeError, match='MI355X'):
+        dec([[torch.zeros(1, 2, 2, 9, 80)], [torch.zeros(1, 2, 2, 9, 4)]])
+    with pytest.raises(NotImplementedError):
+        decode.__dict__['RetinaDecoder'](nms_type='torch_nms')

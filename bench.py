@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the RetinaNet-ResNet50 COCO training step (forward, RetinaLoss,
+backward, gradient all-reduce, AdamW) at 1333x800, batch 2 per GPU, fp32, synthetic data.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU (RCCL).  Prints ONE JSON line on rank 0 (contract in the repo README / DESIGN.md).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, BATCH = 800, 1333, 2
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, fp32 matrix
+
+
+def cpu_baseline(max_steps=2):
+    """The CPU oracle's training step (torch-CPU fp32 restatement of the reference step, pinned to the
+    reference by tests/golden) timed on this host's cores: 1 warm-up + `max_steps` timed steps of the
+    SAME workload (B=2, 800x1333)."""
+    import torch
+    from oracle import losses as olosses, model as omodel, synth
+    sd = omodel.init_retinanet_state(0)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+              if v.dtype.is_floating_point and 'running_' not in k}
+    state = {k: v.clone() for k, v in sd.items()}
+    state.update(params)
+    opt = torch.optim.AdamW([{'params': [p for p in params.values() if p.ndim == 1], 'weight_decay': 0.0},
+                             {'params': [p for p in params.values() if p.ndim != 1], 'weight_decay': 1e-3}],
+                            lr=1e-4)
+    crit = olosses.RetinaLossOracle()
+    images = torch.tensor(synth.images(0, BATCH, H, W))
+    annots = torch.tensor(synth.annotations(0, BATCH, H, W, boxes_per_image=8))
+    times = []
+    for it in range(1 + max_steps):
+        t0 = time.perf_counter()
+        ld = crit(omodel.retinanet_forward(state, images, training=True), annots)
+        opt.zero_grad()
+        sum(ld.values()).backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = sum(times[1:]) / max_steps
+    return dict(value=BATCH / t, unit='images/sec', cores=torch.get_num_threads(), kind='port',
+                sample=f'{max_steps} timed steps (after 1 warm-up) of the same workload: B=2, 800x1333, '
+                       f'RetinaNet-R50 fwd+RetinaLoss+bwd+AdamW, torch-CPU fp32 oracle, {t:.2f} s/step')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timer', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs one process per GPU: launch with torch.distributed.run '
+                         f'--nproc-per-node {args.gpus} (WORLD_SIZE={world})')
+    torch.cuda.set_device(local_rank)
+    group = None
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', init_method='env://', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
+        group = dist.group.WORLD
+
+    from oracle import synth  # input generator only (numpy); the oracle model is used by cpu_baseline alone
+    from sacv_amd import ops
+    from sacv_amd.detection import models, losses
+    from sacv_amd.train import DetectionTrainer
+
+    torch.manual_seed(0)
+    net = models.__dict__['resnet50_retinanet'](backbone_pretrained_path='', num_classes=80).cuda().train()
+    crit = losses.__dict__['RetinaLoss'](box_loss_type='SmoothL1')
+    trainer = DetectionTrainer(net, crit, lr=1e-4, weight_decay=1e-3, process_group=group)
+    images = torch.tensor(synth.images(rank, BATCH, H, W)).cuda()
+    annots = torch.tensor(synth.annotations(rank, BATCH, H, W, boxes_per_image=8)).cuda()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = trainer.step(images, annots)
+    timer = None
+    if not args.no_kernel_timer:
+        timer = ops.TIMER = ops.KernelTimer()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(images, annots)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    losses_host = trainer.finish_step(out)
+    if world > 1:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * BATCH * args.steps / elapsed
+
+    roofline = None
+    if timer is not None:
+        agg = timer.summary()
+        k = agg.get('conv_nt_128x128')
+        if k:
+            per_launch_flops = k['flops'] / k['launches']
+            per_launch_ms = k['ms'] / k['launches']
+            achieved = per_launch_flops / (per_launch_ms * 1e-3) / 1e12
+            roofline = dict(kernel='conv_nt_kernel<128,128> (implicit-GEMM conv fwd+dgrad, fp32 MFMA 32x32x2)',
+                            bound='mfma', achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
+                            frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                            launches_per_step=k['launches'] // args.steps,
+                            avg_launch_ms=round(per_launch_ms, 4), algorithmic_gflop_per_launch=round(
+                                per_launch_flops / 1e9, 2),
+                            share_of_step_ms=round(k['ms'] / args.steps, 2))
+    if rank == 0:
+        line = {
+            'metric': 'images/sec/node RetinaNet-R50 COCO 1333x800 bs=2/GPU',
+            'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'RetinaNet-ResNet50 COCO training step (fwd + RetinaLoss SmoothL1 + bwd + '
+                                   'grad all-reduce + AdamW), images [2,3,800,1333]/GPU, 8 GT boxes/image, '
+                                   'random init', 'global_batch': world * BATCH, 'parallelism': f'dp{world}'},
+            'loss': losses_host,
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

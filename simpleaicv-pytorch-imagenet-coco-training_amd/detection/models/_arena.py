@@ -48,6 +48,20 @@ class ParamArena:
                 self.grad_views[n] = self.grads[o:o + p.numel()].view(p.shape)
                 self._ptrs[n] = view.data_ptr()
         self.module_params = dict(self.order)
+        # floating-point buffers (BatchNorm running statistics) in one flat block as well
+        fbufs = [(n, b) for n, b in module.named_buffers() if b.dtype == torch.float32]
+        self.buffer_order = fbufs
+        total = sum(_pad4(b.numel()) for _, b in fbufs)
+        self.buffers = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        modules = dict(module.named_modules())
+        with torch.no_grad():
+            for n, b in fbufs:
+                view = self.buffers[off:off + b.numel()].view(b.shape)
+                view.copy_(b)
+                owner, _, leaf = n.rpartition('.')
+                modules[owner]._buffers[leaf] = view
+                off += _pad4(b.numel())
 
     def is_current(self):
         """False when something (.to(), .cuda(), load via assignment) re-allocated a parameter."""

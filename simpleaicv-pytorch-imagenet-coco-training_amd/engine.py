@@ -130,14 +130,7 @@ class DetectorEngine:
             for bi in range(n):
                 pre = f'backbone.layer{li}.{bi}'
                 stride = 2 if (bi == 0 and li > 1) else 1
-                has_ds = (pre + '.downsample_conv.layer.0.weight') in p
-                z1, c1 = self._cba_fwd(x, pre + '.conv1', 1, 1, 0, True, training, keep=keep)
-                z2, c2 = self._cba_fwd(z1, pre + '.conv2', 3, stride, 1, True, training, keep=keep)
-                if has_ds:
-                    idt, cd = self._cba_fwd(x, pre + '.downsample_conv', 1, stride, 0, False, training, keep=keep)
-                else:
-                    idt, cd = x, None
-                out, c3 = self._cba_fwd(z2, pre + '.conv3', 1, 1, 0, True, training, residual=idt, keep=keep)
+                out, (c1, c2, c3, cd) = self._bottleneck_fwd(x, pre, stride, training, keep)
                 blocks.append((c1, c2, c3, cd, li, bi))
                 x = out
             feats.append(x)
@@ -148,6 +141,19 @@ class DetectorEngine:
             ctx['blocks'] = blocks
             self.ctx = ctx
         return cls_levels, reg_levels
+
+    def _bottleneck_fwd(self, x, pre, stride, training, keep=True):
+        """Bottleneck.forward (classification/backbones/resnet.py:141-155): 1x1 -> 3x3(stride) -> 1x1,
+        shortcut (1x1 conv + BN when the shape changes), add + ReLU fused into the last BN pass."""
+        has_ds = (pre + '.downsample_conv.layer.0.weight') in self.p
+        z1, c1 = self._cba_fwd(x, pre + '.conv1', 1, 1, 0, True, training, keep=keep)
+        z2, c2 = self._cba_fwd(z1, pre + '.conv2', 3, stride, 1, True, training, keep=keep)
+        if has_ds:
+            idt, cd = self._cba_fwd(x, pre + '.downsample_conv', 1, stride, 0, False, training, keep=keep)
+        else:
+            idt, cd = x, None
+        out, c3 = self._cba_fwd(z2, pre + '.conv3', 1, 1, 0, True, training, residual=idt, keep=keep)
+        return out, (c1, c2, c3, cd)
 
     def _conv_bias(self, x, name, k, stride, pad, flags=0):
         w = self.p[name + '.weight']
@@ -241,7 +247,7 @@ class DetectorEngine:
             return self._dgrad(dy, w, x.shape, k, stride, pad, out=out, accumulate=accumulate, mask=mask)
         return None
 
-    def backward(self, dcls_levels, dreg_levels, grad_scale=1.0):
+    def backward(self, dcls_levels, dreg_levels, grad_scale=1.0, on_stage=None):
         """dcls: grads w.r.t. the class PROBABILITIES, dreg: w.r.t. the box regressions (per level,
         same shapes as the forward outputs).  Fills every entry of self.g (overwrite semantics)."""
         ctx = self.ctx
@@ -261,6 +267,8 @@ class DetectorEngine:
             dz_reg = [d.reshape(d.shape[0], d.shape[1], d.shape[2], a * 4) for d in dreg_levels]
         dfeat = self._tower_bwd(dz_cls, 'cls_head.cls_head', 'cls_head.cls_out')
         dfeat = self._tower_bwd(dz_reg, 'reg_head.reg_head', 'reg_head.reg_out', accum_into=dfeat)
+        if on_stage:
+            on_stage('heads')  # head gradients are final: their all-reduce can start now
         dc3, dc4, dc5 = self._fpn_bwd(dfeat)
         # backbone, last block first
         blocks = ctx['blocks']
@@ -272,6 +280,8 @@ class DetectorEngine:
             elif bi == 0 and li == 3:
                 accum_target = dc3
             dout = self._bottleneck_bwd(c1, c2, c3, cd, dout, accum_target)
+            if on_stage and li == 4 and bi == 0:
+                on_stage('neck')  # fpn + layer4 gradients are final
         # max pool + stem
         dpool = ops.maxpool_bwd(dout, ctx['pool_idx'], ctx['pool_in_shape'], 3, 2, 1)
         st = ctx['stem']
@@ -280,6 +290,8 @@ class DetectorEngine:
                                  self.g[bn + 'bias'])
         ops.conv_wgrad([dy], [st.x], self.g['backbone.conv1.layer.0.weight'], 3, 1, 1, 1, 0,
                        cin_pad=ops.STEM_KPAD, dw_taps=49)
+        if on_stage:
+            on_stage('rest')
         self.ctx = None
 
     def _bottleneck_bwd(self, c1, c2, c3, cd, dout, accum_target):

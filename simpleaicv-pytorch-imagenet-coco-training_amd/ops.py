@@ -18,6 +18,36 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class KernelTimer:
+    """HIP-event timing of individual launches on the launch stream (torch's current stream).
+    bench.py installs one as ops.TIMER to measure the conv kernels' achieved FLOP/s live."""
+
+    def __init__(self):
+        self.records = []
+
+    def time(self, key, flops, launch):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = launch()
+        e1.record()
+        self.records.append((key, flops, e0, e1))
+        return out
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, e0, e1 in self.records:
+            a = agg.setdefault(key, dict(launches=0, flops=0.0, ms=0.0))
+            a['launches'] += 1
+            a['flops'] += flops
+            a['ms'] += e0.elapsed_time(e1)
+        return agg
+
+
+TIMER = None
+
+
 def _chk(t, name='tensor'):
     if t.device.type != 'cuda' or t.dtype != torch.float32 or not t.is_contiguous():
         raise ValueError(f'{name}: expected a contiguous fp32 CUDA(HIP) tensor, got {t.dtype} {t.device} '
@@ -63,13 +93,25 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
     if bias is not None:
         flags |= CF_BIAS
     rs, hr, wr = remap if remap else (0, 0, 0)
-    check(lib.sacv_conv2d_gemm(
-        n, parr([s.data_ptr() for s in srcs]), parr([o.data_ptr() for o in outs]),
-        parr([m.data_ptr() for m in masks]) if masks else None,
-        iarr([s.shape[0] for s in srcs]), iarr([s.shape[1] for s in srcs]), iarr([s.shape[2] for s in srcs]),
-        iarr([hw[0] for hw in out_hw]), iarr([hw[1] for hw in out_hw]),
-        _ptr(w_packed), _ptr(bias), cs, n_out, kh, kw, stride, pad, mode, flags, rs, hr, wr, _stream()),
-        'conv2d_gemm')
+
+    def launch():
+        check(lib.sacv_conv2d_gemm(
+            n, parr([s.data_ptr() for s in srcs]), parr([o.data_ptr() for o in outs]),
+            parr([m.data_ptr() for m in masks]) if masks else None,
+            iarr([s.shape[0] for s in srcs]), iarr([s.shape[1] for s in srcs]), iarr([s.shape[2] for s in srcs]),
+            iarr([hw[0] for hw in out_hw]), iarr([hw[1] for hw in out_hw]),
+            _ptr(w_packed), _ptr(bias), cs, n_out, kh, kw, stride, pad, mode, flags, rs, hr, wr, _stream()),
+            'conv2d_gemm')
+
+    if TIMER is not None:
+        # ALGORITHMIC flops of the convolution (forward-equivalent MACs x 2), not the padded GEMM's
+        if mode == 0:
+            pix = sum(s.shape[0] * hw[0] * hw[1] for s, hw in zip(srcs, out_hw))
+        else:
+            pix = sum(s.shape[0] * s.shape[1] * s.shape[2] for s in srcs)
+        TIMER.time('conv_nt_128x128' if n_out > 64 else 'conv_nt_128x64', 2.0 * pix * n_out * kh * kw * cs, launch)
+    else:
+        launch()
     return outs
 
 

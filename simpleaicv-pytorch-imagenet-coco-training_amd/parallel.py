@@ -1,0 +1,77 @@
+"""Data-parallel gradient exchange over RCCL (torch.distributed backend "nccl" on ROCm).
+
+One process per GPU.  The gradient arena is a single flat fp32 buffer whose >=2-D section is
+laid out in module order (backbone ... fpn, cls_head, reg_head), i.e. in REVERSE of the order
+the backward pass finishes them.  The exchanger cuts it into a few large contiguous stages
+(heads | fpn + layer4 | rest) and launches one asynchronous all-reduce per stage as soon as
+the backward pass has produced that stage, so the transfer over xGMI runs under the remaining
+backward convolutions; the optimizer waits for all of them.  Stages are zero-copy slices, so
+there is no bucket packing.  Replaces the DDP wrapper of tools/utils.py:178-180 (mean of the
+gradients over ranks; the 1/world factor is folded into the fused AdamW kernel) and DDP's
+per-forward broadcast of the BatchNorm buffers from rank 0.
+
+The class is device-agnostic (works on CPU tensors with the gloo backend) so that the
+world_size>1 logic is covered by CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def stage_ranges(arena_order, offsets, numel, split):
+    """Contiguous [begin, end) element ranges of the gradient arena per backward stage.
+
+    arena_order: [(name, tensor)] in arena order (1-D tensors first, then >=2-D in module order).
+    Returns dict stage -> (begin, end):  'heads' (cls_head/reg_head weights), 'neck' (fpn + backbone
+    layer4 weights), 'rest' (everything else including the whole 1-D section)."""
+    multi = [(n, offsets[n]) for n, t in arena_order if t.ndim != 1]
+
+    def first(prefixes):
+        for n, o in multi:
+            if n.startswith(prefixes):
+                return o
+        return numel
+
+    heads_begin = first(('cls_head.', 'reg_head.', 'clsregcnt_head.'))
+    neck_begin = min(first(('backbone.layer4.',)), first(('fpn.',)))
+    neck_begin = min(neck_begin, heads_begin)
+    return {'heads': (heads_begin, numel), 'neck': (neck_begin, heads_begin), 'rest': (0, neck_begin)}
+
+
+class GradExchanger:
+
+    def __init__(self, grads_flat, ranges, group=None):
+        self.g = grads_flat
+        self.ranges = ranges
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.pending = []
+
+    def stage_done(self, stage):
+        """Called by the backward pass when every gradient of `stage` has been enqueued."""
+        if self.world == 1:
+            return
+        b, e = self.ranges[stage]
+        if e > b:
+            self.pending.append(dist.all_reduce(self.g[b:e], op=dist.ReduceOp.SUM, group=self.group,
+                                                async_op=True))
+
+    def wait(self):
+        """Make the current stream wait for all outstanding all-reduces (sums; divide by world)."""
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+
+def broadcast_buffers(flat_buffers, group=None, src=0):
+    """DDP's broadcast_buffers=True: rank 0's BatchNorm running statistics overwrite every rank's
+    before each forward (one flat 208 KB broadcast instead of 106 tensors)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1 and flat_buffers.numel() > 0:
+        dist.broadcast(flat_buffers, src=src, group=group)
+
+
+def vote_and_reduce_scalars(values, group=None):
+    """tools/scripts.py:963-966 (skip-batch vote) and :1017-1029 (loss terms averaged over ranks)
+    folded into ONE small all-reduce: `values` is a float tensor [k]; returns its sum over ranks."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
+    return values

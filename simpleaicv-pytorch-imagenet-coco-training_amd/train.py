@@ -2,22 +2,24 @@
 for one step, with the optimizer of tools/utils.py:480-582 (AdamW, lr 1e-4, wd 1e-3 on ndim>1
 tensors, 0 on 1-D tensors) as ONE fused kernel over the flat parameter arena.
 
-Per step, in the reference's order: H2D-resident batch -> inf/nan input guard -> forward -> loss
-dict -> sum -> inf/nan/zero-loss guard -> backward (gradient all-reduce, mean over ranks) ->
-cross-rank skip vote -> AdamW -> loss terms averaged over ranks.  The guards are evaluated on
-the device and voted on together with the loss terms in ONE small all-reduce, so a step costs
-one host synchronisation instead of the reference's ten.
+Per step, in the reference's order: H2D-resident batch -> forward (rank-0 BN buffers broadcast
+first, as DDP does) -> loss dict -> backward with the gradient all-reduce of each finished stage
+overlapped under the remaining backward kernels -> AdamW (mean over ranks folded in) -> loss
+terms.  The reference's inf/nan guards, skip vote and loss averaging (:880-884, :918-930,
+:963-974, :1017-1029) are evaluated on the device and exchanged in one small all-reduce by
+`finish_step`, so a step costs one host synchronisation instead of the reference's ten.
 """
 import torch
 import torch.distributed as dist
 
 from . import ops
+from .parallel import GradExchanger, stage_ranges, broadcast_buffers, vote_and_reduce_scalars
 
 
 class DetectionTrainer:
 
     def __init__(self, model, criterion, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-3,
-                 accumulation_steps=1, process_group=None, bucket_mb=32):
+                 accumulation_steps=1, process_group=None):
         self.model, self.criterion = model, criterion
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.accumulation_steps = accumulation_steps
@@ -27,31 +29,33 @@ class DetectionTrainer:
         arena = model.arena
         self.exp_avg = torch.zeros_like(arena.params)
         self.exp_avg_sq = torch.zeros_like(arena.params)
-        self.bucket_elems = bucket_mb * (1 << 20) // 4
-        self.comm_stream = torch.cuda.Stream() if self.world > 1 else None
-
-    def _allreduce_grads(self):
-        """Mean of the flat gradient arena over ranks: RCCL all-reduce of zero-copy arena slices."""
-        arena = self.model.arena
-        g = arena.grads
-        n = g.numel()
-        self.comm_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.comm_stream):
-            for s in range(0, n, self.bucket_elems):
-                dist.all_reduce(g[s:min(n, s + self.bucket_elems)], op=dist.ReduceOp.SUM, group=self.group)
-        torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.exchanger = GradExchanger(arena.grads, stage_ranges(arena.order, arena.offsets, arena.numel, arena.split),
+                                       process_group)
+        if self.world > 1:  # DDP init_sync: every rank starts from rank 0's parameters and buffers
+            dist.broadcast(arena.params, src=0, group=process_group)
+            broadcast_buffers(arena.buffers, process_group)
 
     def step(self, images, annots):
+        """One optimizer step on a device-resident batch.  Returns the loss terms as 0-d device tensors
+        (no host synchronisation here)."""
         model, crit = self.model, self.criterion
-        engine = model.engine
-        arena = model.arena
+        engine, arena = model.engine, model.arena
+        if self.world > 1:
+            broadcast_buffers(arena.buffers, self.group)
         cls, reg = engine.forward(images, training=True, keep=True)
         values, counts, dcls, dreg = crit.fused([cls, reg], annots, want_grad=True)
-        engine.backward(dcls, dreg, grad_scale=1.0 / self.accumulation_steps)
-        if self.world > 1:
-            self._allreduce_grads()
+        engine.backward(dcls, dreg, grad_scale=1.0 / self.accumulation_steps, on_stage=self.exchanger.stage_done)
+        self.exchanger.wait()
         self.step_count += 1
         ops.adamw_step(arena.params, arena.grads, self.exp_avg, self.exp_avg_sq, arena.split, self.lr,
                        self.betas[0], self.betas[1], self.eps, 0.0, self.weight_decay, self.step_count,
                        grad_scale=1.0 / self.world)
         return {'cls_loss': values[0], 'reg_loss': values[1]}
+
+    def finish_step(self, loss_dict):
+        """Loss terms averaged over ranks as python floats (the caller's logging values): one tiny
+        all-reduce and ONE host synchronisation."""
+        v = torch.stack([loss_dict['cls_loss'], loss_dict['reg_loss']]).float()
+        v = vote_and_reduce_scalars(v, self.group) / self.world
+        c, r = v.tolist()
+        return {'cls_loss': c, 'reg_loss': r, 'loss': c + r}

@@ -33,6 +33,8 @@ int sacv_abi_version(void);
 #define SACV_CF_SIGMOID 4  /* nn.Sigmoid fused (head.py:50)               */
 #define SACV_CF_ACCUM 8    /* dst += result (gradient fan-in)             */
 #define SACV_CF_MASK 16    /* result *= (mask > 0)  (ReLU backward fused) */
+#define SACV_CF_STATS 32   /* per-M-tile column sum / sum of squares of the stored values -> stats
+                              (BatchNorm batch statistics of y; bias gradient when the output is a dy) */
 
 /* Grouped implicit-GEMM convolution on the fp32 matrix cores.  mode 0 = forward
  * (src = x, w = pack kind 0), mode 1 = data gradient (src = dy, w = pack kind 1).
@@ -44,7 +46,13 @@ int sacv_conv2d_gemm(int nprob, const float* const* src /*host array*/, float* c
                      const float* const* mask /*host array or NULL*/, const int* Nb, const int* Hs, const int* Ws,
                      const int* Hd, const int* Wd /*host arrays*/, const float* w, const float* bias, int Cs, int N,
                      int KH, int KW, int stride, int pad, int mode, int flags, int remap_s, int Hr, int Wr,
-                     void* stream);
+                     float* workspace /*sacv_conv2d_gemm_workspace_bytes() or NULL*/,
+                     float* stats /*[sacv_conv2d_gemm_stats_rows()][2][N], SACV_CF_STATS only*/, void* stream);
+/* The kernel is persistent (2 workgroups per CU): whole output tiles are dealt round-robin and the
+ * tiles left over after the last full round are split along K over the idle workgroups; the K-slices
+ * meet in `workspace` and are summed in a fixed order (deterministic). */
+long long sacv_conv2d_gemm_workspace_bytes(void);
+int sacv_conv2d_gemm_stats_rows(int nprob, const int* Nb, const int* Hd, const int* Wd);
 
 long long sacv_conv2d_wgrad_workspace_bytes(int nseg, const int* Nb, const int* Ho, const int* Wo, int Cin_pad,
                                             int Cout, int KH, int KW, int chunk);
@@ -73,6 +81,10 @@ long long sacv_bn_workspace_floats(int R, int C);
 int sacv_bn_train_stats(const float* y, int R, int C, float eps, float momentum, float* mean, float* invstd,
                         float* running_mean, float* running_var, long long* num_batches_tracked, float* workspace,
                         void* stream);
+/* second stage only, from the [nblocks][2][C] partials of a SACV_CF_STATS convolution */
+int sacv_bn_finalize_stats(const float* partial, int nblocks, int R, int C, float eps, float momentum, float* mean,
+                           float* invstd, float* running_mean, float* running_var, long long* num_batches_tracked,
+                           void* stream);
 /* z = act((y-mean)*invstd*gamma + beta [+ residual]); stat_is_var=1: eval mode with running_var. */
 int sacv_bn_apply(const float* y, const float* mean, const float* invstd_or_var, const float* gamma,
                   const float* beta, const float* residual, float* z, long long numel, int C, int relu,
@@ -98,6 +110,8 @@ int sacv_upsample_bilinear_bwd(const float* dout, float* dtop, int Nb, int Hs, i
 int sacv_eltwise(const float* a, const float* b, float* out, long long n, int op, float scalar, void* stream);
 long long sacv_colsum_workspace_floats(int R, int C);
 int sacv_colsum(const float* x, float* out, int R, int C, int accumulate, float* workspace, void* stream);
+int sacv_colsum_finalize(const float* partial, int nblocks, int stride, int C, float* out, int accumulate,
+                         void* stream);
 
 /* ---- targets and losses (detection/models/anchor.py, detection/losses.py) ---------------------------- */
 /* RetinaAnchors.__call__ (anchor.py:18-86): bit-exact vs NumPy fp32; fw/fh/areas/... are host arrays */

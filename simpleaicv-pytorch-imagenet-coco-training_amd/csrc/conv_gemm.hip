@@ -29,6 +29,7 @@
 #define CF_SIGMOID 4
 #define CF_ACCUM 8
 #define CF_MASK 16
+#define CF_STATS 32
 
 struct ConvProb {
   const float* src;
@@ -52,9 +53,105 @@ struct ConvArgs {
   int KH, KW, stride_log2, pad;
   int mode;
   int flags;
+  // persistent schedule (hybrid data-parallel + split-K):
+  //   phase 1: block b owns whole tiles b, b+grid, ... (base rounds)
+  //   phase 2: the remaining rem_tiles (< grid) tiles are each split along K over bpt blocks
+  //            whose partial accumulators go to `partial` and are summed by conv_fixup_kernel
+  int grid, base, rem_tiles, bpt;
+  float* partial;  // [slots][BM][BN] row-major K-slice tiles
+  float* stats;    // [total_mtiles][2][N] column sum / sum of squares (CF_STATS)
+};
+
+struct TileCoord {
+  int pi, m0, n0;
 };
 
 template <int BM, int BN>
+__device__ __forceinline__ TileCoord tile_coord(const ConvArgs& a, int tile) {
+  const int ntn = (a.N + BN - 1) / BN;
+  const int nt = tile % ntn;
+  const int mt = tile / ntn;
+  int pi = 0;
+  for (int i = 1; i < a.nprob; ++i)
+    if (mt >= a.p[i].tile_begin) pi = i;
+  TileCoord t;
+  t.pi = pi;
+  t.m0 = (mt - a.p[pi].tile_begin) * BM;
+  t.n0 = nt * BN;
+  return t;
+}
+
+// Vectorised tile epilogue shared by the main kernel (whole tiles, rows staged in LDS) and the fix-up
+// kernel (split tiles, rows summed from the K-slice slabs).  NT threads walk the BM x BN tile as rows of
+// float4: thread -> (column group c4 = t % (BN/4), row lane rr = t / (BN/4)), rows rr, rr+RS, ...
+// Per float4: + bias, (+ dst), ReLU, sigmoid, (* mask > 0), optional strided row scatter, 16-byte store.
+// CF_STATS: per-column sum and sum of squares of the STORED values over the tile's valid rows go to
+// stats[mt][0][n] / stats[mt][1][n] (mt = global M-tile index) -- the BatchNorm batch statistics of a
+// forward conv, or the bias gradient when the stored value is a dy.  Fixed order => deterministic.
+template <int BM, int BN, int NT, typename RowFn>
+__device__ __forceinline__ void vec_epilogue(const ConvArgs& a, const TileCoord& tc, int mt, RowFn get_row,
+                                             float* red /* LDS scratch, 2*(NT/(BN/4))*BN floats, CF_STATS only */) {
+  constexpr int CG = BN / 4;
+  constexpr int RS = NT / CG;  // row lanes
+  const int t = threadIdx.x;
+  const int c4 = t % CG, rr = t / CG;
+  const ConvProb& P = a.p[tc.pi];
+  const int flags = a.flags;
+  float* __restrict__ dst = P.dst;
+  const int N = a.N, M = P.M;
+  const int n = tc.n0 + c4 * 4;
+  const bool nok = n < N;  // N % 4 == 0
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if ((flags & CF_BIAS) && nok) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+  f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+  const int hw = P.Hd * P.Wd;
+#pragma unroll 4
+  for (int row = rr; row < BM; row += RS) {
+    const int m = tc.m0 + row;
+    if (!(nok && m < M)) continue;
+    f32x4 v = get_row(row, c4) + bv;
+    size_t orow = (size_t)m;
+    if (P.remap_s > 0) {
+      int nn = m / hw;
+      int rem = m - nn * hw;
+      int hd = rem / P.Wd;
+      int wd = rem - hd * P.Wd;
+      orow = ((size_t)nn * P.Hr + (size_t)hd * P.remap_s) * P.Wr + (size_t)wd * P.remap_s;
+    }
+    const size_t o = orow * N + n;
+    if (flags & CF_ACCUM) v += *reinterpret_cast<const f32x4*>(dst + o);
+    if (flags & CF_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (flags & CF_SIGMOID) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+    }
+    if (flags & CF_MASK) {
+      f32x4 mk = *reinterpret_cast<const f32x4*>(P.mask + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(dst + o) = v;
+    ssum += v;
+    ssq += v * v;
+  }
+  if (flags & CF_STATS) {
+    __syncthreads();  // callers' row sources (LDS stage) are dead from here on
+    *reinterpret_cast<f32x4*>(red + (size_t)rr * BN + c4 * 4) = ssum;
+    *reinterpret_cast<f32x4*>(red + (size_t)(RS + rr) * BN + c4 * 4) = ssq;
+    __syncthreads();
+    for (int c = t; c < 2 * BN; c += NT) {
+      const int which = c / BN, col = c - which * BN;
+      float acc = 0.f;
+      for (int l = 0; l < RS; ++l) acc += red[(size_t)(which * RS + l) * BN + col];
+      if (tc.n0 + col < N) a.stats[((size_t)mt * 2 + which) * N + tc.n0 + col] = acc;
+    }
+  }
+}
+
+template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
   constexpr int LS = 36;
   constexpr int RA = BM / 32, RB = BN / 32;
@@ -67,87 +164,119 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
-  const int ntn = (a.N + BN - 1) / BN;
   const int bid = blockIdx.x;
-  const int nt = bid % ntn;
-  const int mt = bid / ntn;
-  int pi = 0;
-  for (int i = 1; i < a.nprob; ++i)
-    if (mt >= a.p[i].tile_begin) pi = i;
-  const ConvProb& P = a.p[pi];
-  const int m0 = (mt - P.tile_begin) * BM;
-  const int n0 = nt * BN;
-  const int Hs = P.Hs, Ws = P.Ws, M = P.M, Cs = a.Cs;
-  const float* __restrict__ src = P.src;
+  const int Cs = a.Cs;
   const float* __restrict__ wgt = a.w;
-
-  // per-thread gather rows
-  const int kq = tid & 7;
-  const int r0 = tid >> 3;
-  int hb[RA], wb[RA], nb[RA];
-#pragma unroll
-  for (int i = 0; i < RA; ++i) {
-    int m = m0 + r0 + 32 * i;
-    if (m < M) {
-      int hw = P.Hd * P.Wd;
-      int n = m / hw;
-      int rem = m - n * hw;
-      int hd = rem / P.Wd;
-      int wd = rem - hd * P.Wd;
-      nb[i] = n * Hs * Ws;
-      if (a.mode == 0) {
-        hb[i] = (hd << a.stride_log2) - a.pad;
-        wb[i] = (wd << a.stride_log2) - a.pad;
-      } else {
-        hb[i] = hd + a.pad;
-        wb[i] = wd + a.pad;
-      }
-    } else {
-      nb[i] = 0;
-      hb[i] = -100000;  // never valid in either mode
-      wb[i] = -100000;
-    }
-  }
   const int cpt = (Cs + 31) >> 5;  // K tiles per tap (last one zero-padded when Cs % 32 != 0)
   const int KT = a.KH * a.KW * cpt;
   const int smask = (1 << a.stride_log2) - 1;
 
-  f32x4 ra[RA], rb[RB];
-  auto load_tile = [&](int kt) {
-    int tap = kt / cpt;
-    int c0 = (kt - tap * cpt) << 5;
-    int kh = tap / a.KW;
-    int kw = tap - kh * a.KW;
-    const bool kok = (c0 + kq * 4) < Cs;
+  // segments of this block: `base` whole tiles, then at most one K-slice of a remainder tile
+  const int nrem = a.rem_tiles * a.bpt;
+  const int nseg = a.base + (bid < nrem ? 1 : 0);
+  if (nseg == 0) return;
+
+  // per-thread gather state of the CURRENT segment
+  const int kq = tid & 7;
+  const int r0 = tid >> 3;
+  int hb[RA], wb[RA], nb[RA];
+  const float* src;
+  int Hs, Ws, n0;
+  TileCoord tc;
+  int k_begin, k_end, slot;
+
+  auto setup = [&](int sidx) {
+    int tile;
+    if (sidx < a.base) {
+      tile = bid + sidx * a.grid;
+      k_begin = 0;
+      k_end = KT;
+      slot = -1;
+    } else {
+      int rt = bid / a.bpt, part = bid - rt * a.bpt;
+      tile = a.base * a.grid + rt;
+      k_begin = (int)(((long long)part * KT) / a.bpt);
+      k_end = (int)(((long long)(part + 1) * KT) / a.bpt);
+      slot = (a.bpt > 1) ? bid : -1;
+    }
+    tc = tile_coord<BM, BN>(a, tile);
+    const ConvProb& P = a.p[tc.pi];
+    src = P.src;
+    Hs = P.Hs;
+    Ws = P.Ws;
+    n0 = tc.n0;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      int hs, ws;
-      bool ok;
-      if (a.mode == 0) {
-        hs = hb[i] + kh;
-        ws = wb[i] + kw;
-        ok = ((unsigned)hs < (unsigned)Hs) && ((unsigned)ws < (unsigned)Ws);
+      int m = tc.m0 + r0 + 32 * i;
+      if (m < P.M) {
+        int hw = P.Hd * P.Wd;
+        int n = m / hw;
+        int rem = m - n * hw;
+        int hd = rem / P.Wd;
+        int wd = rem - hd * P.Wd;
+        nb[i] = n * Hs * Ws;
+        if (MODE == 0) {
+          hb[i] = (hd << a.stride_log2) - a.pad;
+          wb[i] = (wd << a.stride_log2) - a.pad;
+        } else {
+          hb[i] = hd + a.pad;
+          wb[i] = wd + a.pad;
+        }
       } else {
-        int th = hb[i] - kh, tw = wb[i] - kw;
-        ok = (th >= 0) && (tw >= 0) && (((th | tw) & smask) == 0);
-        hs = th >> a.stride_log2;
-        ws = tw >> a.stride_log2;
-        ok = ok && (hs < Hs) && (ws < Ws);
+        nb[i] = 0;
+        hb[i] = -100000;  // never valid in either mode
+        wb[i] = -100000;
       }
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok && kok) {
-        size_t off = ((size_t)(nb[i] + hs * Ws + ws)) * Cs + c0 + kq * 4;
-        v = *reinterpret_cast<const f32x4*>(src + off);
-      }
-      ra[i] = v;
     }
+  };
+
+  f32x4 ra[RA], rb[RB];
+  // coordinates of the K slab being fetched (wave-uniform)
+  int lt_tap = 0, lt_c0 = 0, lt_kh = 0, lt_kw = 0;
+  bool lt_kok = false;
+  auto load_begin = [&](int kt, bool enable) {
+    lt_tap = kt / cpt;
+    lt_c0 = (kt - lt_tap * cpt) << 5;
+    lt_kh = lt_tap / a.KW;
+    lt_kw = lt_tap - lt_kh * a.KW;
+    lt_kok = enable && ((lt_c0 + kq * 4) < Cs);
+  };
+  // branch-free gathers: always load (offset 0 of the tensor when predicated off), then select.  A
+  // branch per load makes hipcc wait vmcnt(0) after each one and serialises the loads.
+  auto load_a = [&](int i) {
+    int hs, ws;
+    bool ok;
+    if (MODE == 0) {
+      hs = hb[i] + lt_kh;
+      ws = wb[i] + lt_kw;
+      ok = ((unsigned)hs < (unsigned)Hs) && ((unsigned)ws < (unsigned)Ws);
+    } else {
+      int th = hb[i] - lt_kh, tw = wb[i] - lt_kw;
+      ok = (th >= 0) && (tw >= 0) && (((th | tw) & smask) == 0);
+      hs = th >> a.stride_log2;
+      ws = tw >> a.stride_log2;
+      ok = ok && (hs < Hs) && (ws < Ws);
+    }
+    ok = ok && lt_kok;
+    size_t off = ok ? ((size_t)(nb[i] + hs * Ws + ws)) * Cs + lt_c0 + kq * 4 : (size_t)0;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src + off);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    ra[i] = ok ? v : z;
+  };
+  auto load_b = [&](int i) {
+    int n = n0 + r0 + 32 * i;
+    bool ok = (n < a.N) && lt_kok;
+    size_t off = ok ? (size_t)n * a.K + lt_tap * Cs + lt_c0 + kq * 4 : (size_t)0;
+    f32x4 v = *reinterpret_cast<const f32x4*>(wgt + off);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    rb[i] = ok ? v : z;
+  };
+  auto load_tile = [&](int kt) {
+    load_begin(kt, true);
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      int n = n0 + r0 + 32 * i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n < a.N && kok) v = *reinterpret_cast<const f32x4*>(wgt + (size_t)n * a.K + tap * Cs + c0 + kq * 4);
-      rb[i] = v;
-    }
+    for (int i = 0; i < RA; ++i) load_a(i);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) load_b(i);
   };
   auto store_tile = [&](int buf) {
     float* dA = sA + buf * BM * LS;
@@ -159,81 +288,135 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
   };
 
   f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const int wm0 = (wid >> 1) * WTM;
   const int wn0 = (wid & 1) * WTN;
   const int l31 = lane & 31;
   const int lh = lane >> 5;
 
-  load_tile(0);
+  setup(0);
+  load_tile(k_begin);
   store_tile(0);
   __syncthreads();
   int cur = 0;
-  for (int kt = 0; kt < KT; ++kt) {
-    if (kt + 1 < KT) load_tile(kt + 1);
-    const float* cA = sA + cur * BM * LS + (wm0 + l31) * LS + 4 * lh;
-    const float* cB = sB + cur * BN * LS + (wn0 + l31) * LS + 4 * lh;
+  for (int sidx = 0; sidx < nseg; ++sidx) {
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      f32x4 fa[TM], fb[TN];
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * LS + jj * 8);
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * LS + jj * 8);
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const TileCoord my_tc = tc;
+    const int my_slot = slot;
+    const int kb = k_begin, ke = k_end;
+    const bool more = (sidx + 1) < nseg;
+    for (int kt = kb; kt < ke; ++kt) {
+      const bool last = (kt + 1 == ke);
+      const bool have_next = !last || more;
+      if (last && more) setup(sidx + 1);  // switch the gather state to the next segment
+      load_begin(last ? k_begin : kt + 1, have_next);
+      const float* cA = sA + cur * BM * LS + (wm0 + l31) * LS + 4 * lh;
+      const float* cB = sB + cur * BN * LS + (wn0 + l31) * LS + 4 * lh;
+      // The next slab's gathers (address arithmetic + 16-byte loads) and the next fragments' LDS reads
+      // are issued in the shadow of the current MFMAs (an fp32 32x32x2 MFMA occupies the matrix pipe
+      // for 64 cycles but the issue port for 8), so a wave keeps the pipe busy on its own instead of
+      // alternating a load phase with a math phase in lockstep with its SIMD partner.
+      f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * LS);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * LS);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int cb = jj & 1, nbuf = cb ^ 1;
+        if (jj < 3) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            fa[nbuf][i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * LS + (jj + 1) * 8);
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < KT) store_tile(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  // epilogue
-  const int flags = a.flags;
-  float* __restrict__ dst = P.dst;
-  const int ldd = a.N;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    int n = n0 + wn0 + j * 32 + l31;
-    bool nok = n < a.N;
-    float bv = ((flags & CF_BIAS) && nok) ? a.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (nok && m < M) {
-          size_t row = (size_t)m;
-          if (P.remap_s > 0) {
-            int hw = P.Hd * P.Wd;
-            int nn = m / hw;
-            int rem = m - nn * hw;
-            int hd = rem / P.Wd;
-            int wd = rem - hd * P.Wd;
-            row = ((size_t)nn * P.Hr + (size_t)hd * P.remap_s) * P.Wr + (size_t)wd * P.remap_s;
-          }
-          size_t o = row * ldd + n;
-          float v = acc[i][j][r] + bv;
-          if (flags & CF_ACCUM) v += dst[o];
-          if (flags & CF_RELU) v = fmaxf(v, 0.f);
-          if (flags & CF_SIGMOID) v = 1.f / (1.f + __expf(-v));
-          if (flags & CF_MASK) v = (P.mask[o] > 0.f) ? v : 0.f;
-          dst[o] = v;
+            fb[nbuf][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * LS + (jj + 1) * 8);
         }
+        if (jj < RA) load_a(jj);
+        if (jj < RB) load_b(jj);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][i][e], fb[cb][j][e], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < 4 * TM * TN; ++m) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
+          if (m < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 LDS read
+          __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                       // address VALU
+          if (m == 5 || m == 10) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 global load
+        }
+      }
+      // the slab of the NEXT segment stays in registers across the epilogue (the LDS is needed to stage
+      // the output tile); within a segment it goes straight to the other LDS buffer
+      if (!last) store_tile(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+    // ---- epilogue: accumulators -> LDS [BM][BN+4] -> 16-byte row-major stores
+    {
+      constexpr int CS = BN + 4;
+      float* stage = smem;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            stage[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CS + wn0 + j * 32 + l31] = acc[i][j][r];
+      __syncthreads();
+      if (my_slot < 0) {
+        const int ntn = (a.N + BN - 1) / BN;
+        const int my_tile = (sidx < a.base) ? (bid + sidx * a.grid) : (a.base * a.grid + bid / a.bpt);
+        vec_epilogue<BM, BN, 256>(
+            a, my_tc, my_tile / ntn,
+            [&](int row, int c4) { return *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4); },
+            smem + BM * CS);
+      } else {
+        // K-slice of a split tile: row-major slab for the fix-up kernel
+        float* dst = a.partial + (size_t)my_slot * (BM * BN);
+        constexpr int CG = BN / 4, RS = 256 / CG;
+        const int c4 = tid % CG, rr = tid / CG;
+#pragma unroll 4
+        for (int row = rr; row < BM; row += RS)
+          *reinterpret_cast<f32x4*>(dst + row * BN + c4 * 4) =
+              *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4);
+      }
+      if (more) {
+        __syncthreads();  // stage fully consumed
+        store_tile(0);    // first slab of the next segment (gathered under the last MFMAs)
+        __syncthreads();
+        cur = 0;
       }
     }
   }
+}
+
+// Sums the K-slices of each split tile in a fixed order (deterministic) and applies the epilogue.
+template <int BM, int BN>
+__global__ __launch_bounds__(1024) void conv_fixup_kernel(const ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[2 * (1024 / (BN / 4)) * BN];
+  const int rt = blockIdx.x;
+  const int ntn = (a.N + BN - 1) / BN;
+  const int tile = a.base * a.grid + rt;
+  const TileCoord tc = tile_coord<BM, BN>(a, tile);
+  const float* base = a.partial + (size_t)rt * a.bpt * (BM * BN);
+  const int bpt = a.bpt;
+  vec_epilogue<BM, BN, 1024>(
+      a, tc, tile / ntn,
+      [&](int row, int c4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int part = 0; part < bpt; ++part)
+          v += *reinterpret_cast<const f32x4*>(base + (size_t)part * (BM * BN) + row * BN + c4 * 4);
+        return v;
+      },
+      red);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -305,25 +488,26 @@ __global__ __launch_bounds__(256, 2) void conv_tn_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       int pix = p0 + rra + i * RSA;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (co_ok && pix < pix1) v = *reinterpret_cast<const f32x4*>(dy + (size_t)pix * a.Cout + co);
-      ra[i] = v;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      bool ok = co_ok && pix < pix1;
+      size_t off = ok ? (size_t)pix * a.Cout + co : (size_t)0;
+      f32x4 v = *reinterpret_cast<const f32x4*>(dy + off);
+      ra[i] = ok ? v : z;
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       int pix = p0 + rrb + i * RSB;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (n2_ok && pix < pix1) {
-        int n = pix / HoWo;
-        int rem = pix - n * HoWo;
-        int ho = rem / S.Wo;
-        int wo = rem - ho * S.Wo;
-        int hi = ho * a.stride - a.pad + kh;
-        int wi = wo * a.stride - a.pad + kw;
-        if ((unsigned)hi < (unsigned)S.Hx && (unsigned)wi < (unsigned)S.Wx)
-          v = *reinterpret_cast<const f32x4*>(x + ((size_t)(n * S.Hx + hi) * S.Wx + wi) * a.Cin + ci);
-      }
-      rb[i] = v;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      int n = pix / HoWo;
+      int rem = pix - n * HoWo;
+      int ho = rem / S.Wo;
+      int wo = rem - ho * S.Wo;
+      int hi = ho * a.stride - a.pad + kh;
+      int wi = wo * a.stride - a.pad + kw;
+      bool ok = n2_ok && pix < pix1 && (unsigned)hi < (unsigned)S.Hx && (unsigned)wi < (unsigned)S.Wx;
+      size_t off = ok ? ((size_t)(n * S.Hx + hi) * S.Wx + wi) * a.Cin + ci : (size_t)0;
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
+      rb[i] = ok ? v : z;
     }
   };
   auto store_tile = [&](int buf) {
@@ -498,18 +682,56 @@ static int log2_exact(int v) {
   return ((1 << l) == v) ? l : -1;
 }
 
-template <int BM, int BN>
-static int launch_nt(const ConvArgs& a, hipStream_t st) {
+static int g_num_cus = 0;
+static int num_cus() {
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      g_num_cus = prop.multiProcessorCount;
+    if (g_num_cus <= 0) g_num_cus = 256;
+  }
+  return g_num_cus;
+}
+
+#define SACV_NT_BLOCKS_PER_CU 2
+
+template <int BM, int BN, int MODE>
+static int launch_nt(ConvArgs& a, float* workspace, hipStream_t st) {
   int ntn = (a.N + BN - 1) / BN;
+  int tiles = a.total_mtiles * ntn;
+  int grid = num_cus() * SACV_NT_BLOCKS_PER_CU;
+  a.grid = grid;
+  a.base = tiles / grid;
+  a.rem_tiles = tiles - a.base * grid;
+  int cpt = (a.Cs + 31) / 32;
+  int KT = a.KH * a.KW * cpt;
+  a.bpt = 1;
+  if (a.rem_tiles > 0) {
+    int bpt = grid / a.rem_tiles;
+    if (bpt > KT) bpt = KT;
+    // split only when it pays: keep >= 4 K-iterations per slice, and no split without a workspace
+    while (bpt > 1 && KT / bpt < 4) --bpt;
+    if (!workspace) bpt = 1;
+    a.bpt = bpt < 1 ? 1 : bpt;
+  }
+  a.partial = workspace;
   size_t lds = (size_t)2 * (BM + BN) * 36 * sizeof(float);
+  size_t lds_epi = ((size_t)BM * (BN + 4) + 2 * (256 / (BN / 4)) * BN) * sizeof(float);
+  if (lds_epi > lds) lds = lds_epi;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN, MODE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_nt_kernel<BM, BN>), dim3(a.total_mtiles * ntn), dim3(256), lds, st, a);
+  int launch_blocks = a.base > 0 ? grid : a.rem_tiles * a.bpt;
+  hipLaunchKernelGGL((conv_nt_kernel<BM, BN, MODE>), dim3(launch_blocks), dim3(256), lds, st, a);
   SACV_CHECK_LAUNCH("conv_nt_kernel");
+  if (a.rem_tiles > 0 && a.bpt > 1) {
+    hipLaunchKernelGGL((conv_fixup_kernel<BM, BN>), dim3(a.rem_tiles), dim3(1024), 0, st, a);
+    SACV_CHECK_LAUNCH("conv_fixup_kernel");
+  }
   return SACV_OK;
 }
 
@@ -536,7 +758,7 @@ extern "C" {
 int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, const float* const* mask,
                      const int* Nb, const int* Hs, const int* Ws, const int* Hd, const int* Wd, const float* w,
                      const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode, int flags,
-                     int remap_s, int Hr, int Wr, void* stream) {
+                     int remap_s, int Hr, int Wr, float* workspace, float* stats, void* stream) {
   SACV_CHECK_ARG(nprob >= 1 && nprob <= SACV_MAXP, "conv2d_gemm: nprob %d out of range", nprob);
   SACV_CHECK_ARG(Cs % 4 == 0 && Cs > 0, "conv2d_gemm: Cs=%d must be a positive multiple of 4", Cs);
   SACV_CHECK_ARG(N > 0 && KH > 0 && KW > 0, "conv2d_gemm: bad N/KH/KW");
@@ -545,6 +767,8 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
   SACV_CHECK_ARG(mode == 0 || mode == 1, "conv2d_gemm: mode");
   SACV_CHECK_ARG(!(flags & CF_BIAS) || bias, "conv2d_gemm: bias flag without bias pointer");
   SACV_CHECK_ARG(remap_s == 0 || nprob == 1, "conv2d_gemm: remap only for single problems");
+  SACV_CHECK_ARG(N % 4 == 0, "conv2d_gemm: N=%d must be a multiple of 4", N);
+  SACV_CHECK_ARG(!(flags & CF_STATS) || stats, "conv2d_gemm: CF_STATS without a stats buffer");
   ConvArgs a;
   const bool small_n = N <= 64;
   const int BM = 128;
@@ -586,8 +810,22 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
   a.pad = pad;
   a.mode = mode;
   a.flags = flags;
-  if (small_n) return launch_nt<128, 64>(a, (hipStream_t)stream);
-  return launch_nt<128, 128>(a, (hipStream_t)stream);
+  a.stats = stats;
+  hipStream_t st = (hipStream_t)stream;
+  if (small_n) return mode == 0 ? launch_nt<128, 64, 0>(a, workspace, st) : launch_nt<128, 64, 1>(a, workspace, st);
+  return mode == 0 ? launch_nt<128, 128, 0>(a, workspace, st) : launch_nt<128, 128, 1>(a, workspace, st);
+}
+
+// Rows of the CF_STATS buffer ([rows][2][N] floats): the number of 128-row M tiles over all problems.
+int sacv_conv2d_gemm_stats_rows(int nprob, const int* Nb, const int* Hd, const int* Wd) {
+  int rows = 0;
+  for (int i = 0; i < nprob; ++i) rows += (int)(((long long)Nb[i] * Hd[i] * Wd[i] + 127) / 128);
+  return rows;
+}
+
+// Bytes of split-K workspace sacv_conv2d_gemm wants (it runs unsplit when given NULL).
+long long sacv_conv2d_gemm_workspace_bytes(void) {
+  return (long long)num_cus() * SACV_NT_BLOCKS_PER_CU * 128 * 128 * (long long)sizeof(float);
 }
 
 // Workspace (bytes) needed by sacv_conv2d_wgrad for the given problem list.

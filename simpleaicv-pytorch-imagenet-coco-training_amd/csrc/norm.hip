@@ -57,18 +57,44 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_partial_kernel(const floa
   }
 }
 
-__global__ void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblocks, int R, int C, float eps,
-                                         float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var,
-                                         long long* __restrict__ num_batches_tracked) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
-    s += (double)partial[(size_t)b * 2 * C + c];
-    q += (double)partial[(size_t)b * 2 * C + C + c];
+// Second stage: 16 channels per 256-thread block, 16 threads per channel each summing a fixed strided
+// subset of the per-block partials (coalesced 64-byte rows), then a fixed-order fp64 combine in LDS.
+#define FIN_CH 16
+#define FIN_PARTS 16
+__device__ __forceinline__ void finalize_sums(const float* __restrict__ partial, int nblocks, int C, int c, int part,
+                                              bool valid, double* red, double& s, double& q) {
+  double ls = 0.0, lq = 0.0;
+  if (valid) {
+    for (int b = part; b < nblocks; b += FIN_PARTS) {
+      ls += (double)partial[(size_t)b * 2 * C + c];
+      lq += (double)partial[(size_t)b * 2 * C + C + c];
+    }
   }
+  const int cl = threadIdx.x % FIN_CH;
+  red[(part * FIN_CH + cl) * 2 + 0] = ls;
+  red[(part * FIN_CH + cl) * 2 + 1] = lq;
+  __syncthreads();
+  s = 0.0;
+  q = 0.0;
+  if (part == 0) {
+    for (int k = 0; k < FIN_PARTS; ++k) {
+      s += red[(k * FIN_CH + cl) * 2 + 0];
+      q += red[(k * FIN_CH + cl) * 2 + 1];
+    }
+  }
+}
+
+__global__ __launch_bounds__(FIN_CH* FIN_PARTS) void bn_stats_finalize_kernel(
+    const float* __restrict__ partial, int nblocks, int R, int C, float eps, float momentum, float* __restrict__ mean,
+    float* __restrict__ invstd, float* __restrict__ running_mean, float* __restrict__ running_var,
+    long long* __restrict__ num_batches_tracked) {
+  __shared__ double red[FIN_CH * FIN_PARTS * 2];
+  const int cl = threadIdx.x % FIN_CH, part = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  double s, q;
+  finalize_sums(partial, nblocks, C, c, part, c < C, red, s, q);
+  if (part != 0 || c >= C) return;
   double m = s / R;
   double var = q / R - m * m;
   if (var < 0.0) var = 0.0;
@@ -168,16 +194,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float*
 
 // dgamma/dbeta (assign or accumulate) + per-channel means kept in `coef` for the apply pass:
 // coef[0][c] = sum_g / R, coef[1][c] = sum_gx / R
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int R, int C,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ coef, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
-    s += (double)partial[(size_t)b * 2 * C + c];
-    q += (double)partial[(size_t)b * 2 * C + C + c];
-  }
+__global__ __launch_bounds__(FIN_CH* FIN_PARTS) void bn_bwd_finalize_kernel(const float* __restrict__ partial,
+                                                                              int nblocks, int R, int C,
+                                                                              float* __restrict__ dgamma,
+                                                                              float* __restrict__ dbeta,
+                                                                              float* __restrict__ coef,
+                                                                              int accumulate) {
+  __shared__ double red[FIN_CH * FIN_PARTS * 2];
+  const int cl = threadIdx.x % FIN_CH, part = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
+  double s, q;
+  finalize_sums(partial, nblocks, C, c, part, c < C, red, s, q);
+  if (part != 0 || c >= C) return;
   if (accumulate) {
     dbeta[c] += (float)s;
     dgamma[c] += (float)q;
@@ -221,7 +249,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 static int pick_blocks(int R, int* rows_per_block) {
-  int nb = R < 1024 ? (R + 7) / 8 : 1024;
+  int nb = R < 512 ? (R + 7) / 8 : 512;
   if (nb < 1) nb = 1;
   int rpb = (R + nb - 1) / nb;
   nb = (R + rpb - 1) / rpb;
@@ -256,8 +284,22 @@ int sacv_bn_train_stats(const float* y, int R, int C, float eps, float momentum,
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(BN_THREADS), lds_for(C), st, y, workspace, R, C, rpb);
   SACV_CHECK_LAUNCH("bn_stats_partial");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, workspace, nb, R, C, eps,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, st,
+                     workspace, nb, R, C, eps,
                      momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
+  SACV_CHECK_LAUNCH("bn_stats_finalize");
+  return SACV_OK;
+}
+
+// Second stage alone: `partial` is [nblocks][2][C] column sums / sums of squares produced elsewhere
+// (the CF_STATS epilogue of sacv_conv2d_gemm), R = number of rows they cover.
+int sacv_bn_finalize_stats(const float* partial, int nblocks, int R, int C, float eps, float momentum, float* mean,
+                           float* invstd, float* running_mean, float* running_var, long long* num_batches_tracked,
+                           void* stream) {
+  SACV_CHECK_ARG(partial && mean && invstd && nblocks > 0 && R > 0 && C > 0, "bn_finalize_stats: bad args");
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0,
+                     (hipStream_t)stream, partial, nblocks, R, C, eps, momentum, mean, invstd, running_mean,
+                     running_var, num_batches_tracked);
   SACV_CHECK_LAUNCH("bn_stats_finalize");
   return SACV_OK;
 }
@@ -289,7 +331,8 @@ int sacv_bn_train_bwd(const float* dz, const float* zmask, const float* y, const
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(BN_THREADS), lds_for(C), st, dz, zmask, y, mean, invstd,
                      workspace, R, C, rpb);
   SACV_CHECK_LAUNCH("bn_bwd_partial");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, workspace, nb, R, C, dgamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, st,
+                     workspace, nb, R, C, dgamma,
                      dbeta, coef, accumulate);
   SACV_CHECK_LAUNCH("bn_bwd_finalize");
   size_t n4 = (size_t)R * C / 4;

@@ -225,13 +225,22 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     partial[(size_t)blockIdx.x * C + c] = s;
   }
 }
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, float* __restrict__ out,
-                                       int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ partial, int nblocks,
+                                                               int stride, int C, float* __restrict__ out,
+                                                               int accumulate) {
+  __shared__ double red[256];
+  const int cl = threadIdx.x % 16, part = threadIdx.x / 16;
+  const int c = blockIdx.x * 16 + cl;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += (double)partial[(size_t)b * C + c];
-  out[c] = accumulate ? out[c] + (float)s : (float)s;
+  if (c < C)
+    for (int b = part; b < nblocks; b += 16) s += (double)partial[(size_t)b * stride + c];
+  red[part * 16 + cl] = s;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += red[k * 16 + cl];
+    out[c] = accumulate ? out[c] + (float)t : (float)t;
+  }
 }
 
 static int grid_for(size_t work, int cap = 8192) {
@@ -301,20 +310,31 @@ int sacv_eltwise(const float* a, const float* b, float* out, long long n, int op
 }
 
 long long sacv_colsum_workspace_floats(int R, int C) {
-  int nb = R < 256 ? 1 : (R < 65536 ? 64 : 512);
+  int nb = R < 256 ? 1 : (R < 4096 ? 64 : 512);
   return (long long)nb * C;
 }
 
 int sacv_colsum(const float* x, float* out, int R, int C, int accumulate, float* workspace, void* stream) {
   SACV_CHECK_ARG(x && out && workspace && R > 0 && C > 0, "colsum: bad args");
-  int nb = R < 256 ? 1 : (R < 65536 ? 64 : 512);
+  int nb = R < 256 ? 1 : (R < 4096 ? 64 : 512);
   int rpb = (R + nb - 1) / nb;
   nb = (R + rpb - 1) / rpb;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, x, workspace, R, C, rpb);
   SACV_CHECK_LAUNCH("colsum_partial");
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, st, workspace, nb, C, out,
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, nb, C, C, out,
                      accumulate);
+  SACV_CHECK_LAUNCH("colsum_finalize");
+  return SACV_OK;
+}
+
+// out[c] (+)= sum_b partial[b*stride + c]: second stage for column sums produced elsewhere (the CF_STATS
+// epilogue of sacv_conv2d_gemm: stride = 2*N) -- the bias gradient of the convolution that consumes that dy.
+int sacv_colsum_finalize(const float* partial, int nblocks, int stride, int C, float* out, int accumulate,
+                         void* stream) {
+  SACV_CHECK_ARG(partial && out && nblocks > 0 && C > 0 && stride >= C, "colsum_finalize: bad args");
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial,
+                     nblocks, stride, C, out, accumulate);
   SACV_CHECK_LAUNCH("colsum_finalize");
   return SACV_OK;
 }

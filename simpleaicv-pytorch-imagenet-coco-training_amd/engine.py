@@ -51,15 +51,23 @@ class DetectorEngine:
         cout = w.shape[0]
         wp = ops.pack_weight(w, PACK_FWD)
         hw = _out_hw(x.shape[1], x.shape[2], k, stride, pad)
-        y = ops.conv_gemm([x], wp, cout, k, k, stride, pad, 0, [hw])[0]
-        return self._bn_fwd(x, y, prefix, k, stride, pad, relu, training, residual, keep)
+        if training:  # batch statistics come out of the conv epilogue (no extra pass over y)
+            (y,), st = ops.conv_gemm([x], wp, cout, k, k, stride, pad, 0, [hw], stats=True)
+        else:
+            y, st = ops.conv_gemm([x], wp, cout, k, k, stride, pad, 0, [hw])[0], None
+        return self._bn_fwd(x, y, prefix, k, stride, pad, relu, training, residual, keep, st)
 
-    def _bn_fwd(self, x, y, prefix, k, stride, pad, relu, training, residual, keep):
+    def _bn_fwd(self, x, y, prefix, k, stride, pad, relu, training, residual, keep, stats=None):
         p = self.p
         bn = prefix + '.layer.1.'
         if training:
-            mean, invstd = ops.bn_train_stats(y, BN_EPS, BN_MOMENTUM, p[bn + 'running_mean'], p[bn + 'running_var'],
-                                              p[bn + 'num_batches_tracked'])
+            if stats is not None:
+                mean, invstd = ops.bn_finalize_stats(stats, y.numel() // y.shape[-1], BN_EPS, BN_MOMENTUM,
+                                                     p[bn + 'running_mean'], p[bn + 'running_var'],
+                                                     p[bn + 'num_batches_tracked'])
+            else:
+                mean, invstd = ops.bn_train_stats(y, BN_EPS, BN_MOMENTUM, p[bn + 'running_mean'],
+                                                  p[bn + 'running_var'], p[bn + 'num_batches_tracked'])
             z = ops.bn_apply(y, mean, invstd, p[bn + 'weight'], p[bn + 'bias'], residual, relu)
         else:
             mean = invstd = None
@@ -117,8 +125,11 @@ class DetectorEngine:
         ho, wo = _out_hw(h, w, 7, 2, 3)
         col = ops.im2col_stem(images, ho, wo)
         wst = ops.pack_weight(p['backbone.conv1.layer.0.weight'], PACK_STEM)
-        y = ops.conv_gemm([col], wst, 64, 1, 1, 1, 0, 0, [(ho, wo)])[0]
-        z, c = self._bn_fwd(col, y, 'backbone.conv1', 7, 2, 3, True, training, None, keep)
+        if training:
+            (y,), st = ops.conv_gemm([col], wst, 64, 1, 1, 1, 0, 0, [(ho, wo)], stats=True)
+        else:
+            y, st = ops.conv_gemm([col], wst, 64, 1, 1, 1, 0, 0, [(ho, wo)])[0], None
+        z, c = self._bn_fwd(col, y, 'backbone.conv1', 7, 2, 3, True, training, None, keep, st)
         x, pool_idx = ops.maxpool_fwd(z, 3, 2, 1, want_idx=keep)
         if keep:
             ctx['stem'] = c
@@ -214,7 +225,11 @@ class DetectorEngine:
             ops.colsum(d, c, gb, accumulate=i > 0)
 
     def _tower_bwd(self, dys, tower, out_name, accum_into=None):
-        """dys: per-level grads w.r.t. the tower's output conv result (pre-activation)."""
+        """dys: per-level grads w.r.t. the tower's output conv result (pre-activation).
+
+        The bias gradient of tower conv i is the column sum of its dy, which is exactly what the data-
+        gradient kernel of conv i+1 stores: it is taken from that kernel's CF_STATS epilogue (all five
+        levels in one launch) instead of a separate pass over dy."""
         p, g = self.p, self.g
         saved = self.ctx[tower]
         xs = saved[4]
@@ -222,17 +237,17 @@ class DetectorEngine:
         ops.conv_wgrad(dys, xs, g[out_name + '.weight'], w.shape[1], 3, 3, 1, 1)
         self._bias_grad(dys, out_name)
         hw = [(x.shape[1], x.shape[2]) for x in xs]
-        cur = ops.conv_gemm(dys, ops.pack_weight(w, PACK_DGRAD), w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_MASK,
-                            masks=xs)
+        cur, st = ops.conv_gemm(dys, ops.pack_weight(w, PACK_DGRAD), w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_MASK,
+                                masks=xs, stats=True)
         for li, i in reversed(list(enumerate((0, 2, 4, 6)))):
             name = f'{tower}.{i}'
             w = p[name + '.weight']
             xs = saved[li]
             ops.conv_wgrad(cur, xs, g[name + '.weight'], w.shape[1], 3, 3, 1, 1)
-            self._bias_grad(cur, name)
+            ops.colsum_finalize(st, g[name + '.bias'])
             wd = ops.pack_weight(w, PACK_DGRAD)
             if li > 0:
-                cur = ops.conv_gemm(cur, wd, w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_MASK, masks=xs)
+                cur, st = ops.conv_gemm(cur, wd, w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_MASK, masks=xs, stats=True)
             elif accum_into is not None:
                 cur = ops.conv_gemm(cur, wd, w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_ACCUM, outs=accum_into)
             else:

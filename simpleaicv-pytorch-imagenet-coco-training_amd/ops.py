@@ -9,7 +9,7 @@ import torch
 from . import _lib
 from ._lib import lib, check, iarr, farr, parr
 
-CF_BIAS, CF_RELU, CF_SIGMOID, CF_ACCUM, CF_MASK = 1, 2, 4, 8, 16
+CF_BIAS, CF_RELU, CF_SIGMOID, CF_ACCUM, CF_MASK, CF_STATS = 1, 2, 4, 8, 16, 32
 PACK_FWD, PACK_DGRAD, PACK_STEM = 0, 1, 2
 STEM_KPAD = 160  # 7*7*3 = 147 padded to a multiple of 32
 
@@ -46,6 +46,7 @@ class KernelTimer:
 
 
 TIMER = None
+_GEMM_WS_BYTES = None
 
 
 def _chk(t, name='tensor'):
@@ -75,8 +76,15 @@ def pack_weight(w_oihw, kind, out=None):
     return out
 
 
+def _gemm_ws_bytes():
+    global _GEMM_WS_BYTES
+    if _GEMM_WS_BYTES is None:
+        _GEMM_WS_BYTES = lib.sacv_conv2d_gemm_workspace_bytes()  # queries the CU count: needs the GPU
+    return _GEMM_WS_BYTES
+
+
 def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=None, flags=0, masks=None,
-              outs=None, remap=None):
+              outs=None, remap=None, stats=False):
     """Grouped implicit-GEMM conv.  srcs: list of NHWC tensors sharing the channel count.
 
     mode 0: forward (out_hw[i] = output H,W);  mode 1: data gradient (out_hw[i] = input H,W).
@@ -93,6 +101,11 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
     if bias is not None:
         flags |= CF_BIAS
     rs, hr, wr = remap if remap else (0, 0, 0)
+    stats_buf = None
+    if stats:
+        rows = sum(-(-(s.shape[0] * hw[0] * hw[1]) // 128) for s, hw in zip(srcs, out_hw))
+        stats_buf = torch.empty((rows, 2, n_out), device=srcs[0].device, dtype=torch.float32)
+        flags |= CF_STATS
 
     def launch():
         check(lib.sacv_conv2d_gemm(
@@ -100,7 +113,8 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
             parr([m.data_ptr() for m in masks]) if masks else None,
             iarr([s.shape[0] for s in srcs]), iarr([s.shape[1] for s in srcs]), iarr([s.shape[2] for s in srcs]),
             iarr([hw[0] for hw in out_hw]), iarr([hw[1] for hw in out_hw]),
-            _ptr(w_packed), _ptr(bias), cs, n_out, kh, kw, stride, pad, mode, flags, rs, hr, wr, _stream()),
+            _ptr(w_packed), _ptr(bias), cs, n_out, kh, kw, stride, pad, mode, flags, rs, hr, wr,
+            workspace(_gemm_ws_bytes(), srcs[0].device, 'conv_gemm').data_ptr(), _ptr(stats_buf), _stream()),
             'conv2d_gemm')
 
     if TIMER is not None:
@@ -112,6 +126,8 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
         TIMER.time('conv_nt_128x128' if n_out > 64 else 'conv_nt_128x64', 2.0 * pix * n_out * kh * kw * cs, launch)
     else:
         launch()
+    if stats:
+        return outs, stats_buf
     return outs
 
 
@@ -184,6 +200,25 @@ def bn_train_stats(y, eps, momentum, running_mean, running_var, num_batches_trac
                                   _ptr(running_var), _ptr(num_batches_tracked), _bn_ws(r, c, y.device).data_ptr(),
                                   _stream()), 'bn_train_stats')
     return mean, invstd
+
+
+def bn_finalize_stats(stats_buf, rows, eps, momentum, running_mean, running_var, num_batches_tracked):
+    """mean / invstd (+ running statistics update) from the CF_STATS partials of the producing conv."""
+    nblocks, _, c = stats_buf.shape
+    mean = torch.empty(c, device=stats_buf.device, dtype=torch.float32)
+    invstd = torch.empty(c, device=stats_buf.device, dtype=torch.float32)
+    check(lib.sacv_bn_finalize_stats(_ptr(stats_buf), nblocks, rows, c, eps, momentum, _ptr(mean), _ptr(invstd),
+                                     _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _stream()),
+          'bn_finalize_stats')
+    return mean, invstd
+
+
+def colsum_finalize(stats_buf, out, accumulate=False):
+    """out[c] (+)= sum over M tiles of the CF_STATS column sums (bias gradient)."""
+    nblocks, _, c = stats_buf.shape
+    check(lib.sacv_colsum_finalize(_ptr(stats_buf), nblocks, 2 * c, c, _ptr(out), int(accumulate), _stream()),
+          'colsum_finalize')
+    return out
 
 
 def bn_apply(y, mean, invstd_or_var, gamma, beta, residual=None, relu=False, stat_is_var=False, eps=1e-5,

@@ -208,6 +208,34 @@ def test_conv_epilogues_and_grouping(ops):
         assert float((nchw(o) - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize('n,cin,h,w,cout,k', [(2, 64, 37, 41, 256, 1), (2, 128, 19, 23, 128, 3), (2, 256, 50, 84, 64, 1)])
+def test_conv_stats_epilogue(ops, n, cin, h, w, cout, k):
+    """CF_STATS: per-M-tile column sums / sums of squares of the conv output (BatchNorm statistics and
+    bias gradients come from here), for whole tiles and for K-split tiles (fix-up kernel)."""
+    x = rnd(1, n, cin, h, w)
+    wt = rnd(2, cout, cin, k, k, std=(1.0 / (cin * k * k))**0.5)
+    ref = F.conv2d(x, wt, None, 1, k // 2)
+    (y,), st = ops.conv_gemm([nhwc(x)], ops.pack_weight(wt.cuda(), ops.PACK_FWD), cout, k, k, 1, k // 2, 0,
+                             [(h, w)], stats=True)
+    assert float((nchw(y) - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    rows = n * h * w
+    assert st.shape == (-(-rows // 128), 2, cout)
+    s1 = st[:, 0].double().sum(0).cpu()
+    s2 = st[:, 1].double().sum(0).cpu()
+    r1 = ref.double().sum((0, 2, 3))
+    r2 = (ref.double()**2).sum((0, 2, 3))
+    np.testing.assert_allclose(s1.numpy(), r1.numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s2.numpy(), r2.numpy(), rtol=1e-4, atol=1e-3)
+    rm, rv, nbt = torch.zeros(cout).cuda(), torch.ones(cout).cuda(), torch.zeros((), dtype=torch.long).cuda()
+    mean, invstd = ops.bn_finalize_stats(st, rows, 1e-5, 0.1, rm, rv, nbt)
+    np.testing.assert_allclose(mean.cpu().numpy(), ref.mean((0, 2, 3)).numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(invstd.cpu().numpy(), (1.0 / torch.sqrt(ref.var((0, 2, 3), unbiased=False) + 1e-5)).numpy(),
+                               rtol=1e-4)
+    out = torch.zeros(cout).cuda()
+    ops.colsum_finalize(st, out)
+    np.testing.assert_allclose(out.cpu().numpy(), r1.float().numpy(), rtol=1e-4, atol=1e-3)
+
+
 def test_stem_conv(ops):
     """7x7/s2 stem through explicit im2col, for NCHW-contiguous and channels_last images."""
     x = torch.from_numpy(synth.images(3, 2, 70, 93))

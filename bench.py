@@ -27,6 +27,8 @@ def cpu_baseline(max_steps=2):
     SAME workload (B=2, 800x1333)."""
     import torch
     from oracle import losses as olosses, model as omodel, synth
+    # a 1-GPU box shares its host: 16 cores are this job's share (more threads only oversubscribe)
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
     sd = omodel.init_retinanet_state(0)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
               if v.dtype.is_floating_point and 'running_' not in k}

@@ -482,32 +482,61 @@ __global__ __launch_bounds__(256, 2) void conv_tn_kernel(const WgradArgs a) {
     kw = tap - kh * a.KW;
   }
   const int HoWo = S.Ho * S.Wo;
+  const int Wo = S.Wo, Ho = S.Ho;
+  const int dh = kh - a.pad, dw = kw - a.pad;
+
+  // pixel coordinates of this thread's RB gather rows, advanced incrementally by 32 pixels per K tile
+  int pn[RB], ph[RB], pw[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    int pix = pix0 + rrb + i * RSB;
+    pn[i] = pix / HoWo;
+    int rem = pix - pn[i] * HoWo;
+    ph[i] = rem / Wo;
+    pw[i] = rem - ph[i] * Wo;
+  }
+  const bool fast_adv = Wo >= 32;
 
   f32x4 ra[RA], rb[RB];
-  auto load_tile = [&](int p0) {
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      int pix = p0 + rra + i * RSA;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      bool ok = co_ok && pix < pix1;
-      size_t off = ok ? (size_t)pix * a.Cout + co : (size_t)0;
-      f32x4 v = *reinterpret_cast<const f32x4*>(dy + off);
-      ra[i] = ok ? v : z;
-    }
+  auto load_a = [&](int i, int p0, bool en) {
+    int pix = p0 + rra + i * RSA;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    bool ok = en && co_ok && pix < pix1;
+    size_t off = ok ? (size_t)pix * a.Cout + co : (size_t)0;
+    f32x4 v = *reinterpret_cast<const f32x4*>(dy + off);
+    ra[i] = ok ? v : z;
+  };
+  auto load_b = [&](int i, int p0, bool en) {
+    int pix = p0 + rrb + i * RSB;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    int hi = ph[i] * a.stride + dh;
+    int wi = pw[i] * a.stride + dw;
+    bool ok = en && n2_ok && pix < pix1 && (unsigned)hi < (unsigned)S.Hx && (unsigned)wi < (unsigned)S.Wx;
+    size_t off = ok ? ((size_t)(pn[i] * S.Hx + hi) * S.Wx + wi) * a.Cin + ci : (size_t)0;
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
+    rb[i] = ok ? v : z;
+  };
+  auto advance = [&]() {  // +32 pixels
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      int pix = p0 + rrb + i * RSB;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      int n = pix / HoWo;
-      int rem = pix - n * HoWo;
-      int ho = rem / S.Wo;
-      int wo = rem - ho * S.Wo;
-      int hi = ho * a.stride - a.pad + kh;
-      int wi = wo * a.stride - a.pad + kw;
-      bool ok = n2_ok && pix < pix1 && (unsigned)hi < (unsigned)S.Hx && (unsigned)wi < (unsigned)S.Wx;
-      size_t off = ok ? ((size_t)(n * S.Hx + hi) * S.Wx + wi) * a.Cin + ci : (size_t)0;
-      f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
-      rb[i] = ok ? v : z;
+      if (fast_adv) {
+        pw[i] += 32;
+        if (pw[i] >= Wo) {
+          pw[i] -= Wo;
+          ph[i] += 1;
+          if (ph[i] >= Ho) {
+            ph[i] = 0;
+            pn[i] += 1;
+          }
+        }
+      } else {
+        int lin = ph[i] * Wo + pw[i] + 32;
+        int q = lin / HoWo;
+        pn[i] += q;
+        lin -= q * HoWo;
+        ph[i] = lin / Wo;
+        pw[i] = lin - ph[i] * Wo;
+      }
     }
   };
   auto store_tile = [&](int buf) {
@@ -531,63 +560,109 @@ __global__ __launch_bounds__(256, 2) void conv_tn_kernel(const WgradArgs a) {
 
   const int KT = (pix1 - pix0 + 31) >> 5;
   if (KT > 0) {
-    load_tile(pix0);
+#pragma unroll
+    for (int i = 0; i < RA; ++i) load_a(i, pix0, true);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) load_b(i, pix0, true);
     store_tile(0);
   }
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < KT; ++kt) {
-    if (kt + 1 < KT) load_tile(pix0 + ((kt + 1) << 5));
+    const bool have_next = kt + 1 < KT;
+    const int pnext = pix0 + ((kt + 1) << 5);
+    advance();
     const float* cA = sA + cur * 32 * BM + wm0 + l31;
     const float* cB = sB + cur * 32 * BN + wn0 + l31;
+    // next slab's gathers are issued in the MFMA shadows, two per group of four k-steps
+    float fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = cA[lh * BM + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = cB[lh * BN + j * 32];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      float fa[TM], fb[TN];
+      const int cbuf = s & 1, nbuf = cbuf ^ 1;
+      if (s < 15) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = cA[(2 * s + lh) * BM + i * 32];
+        for (int i = 0; i < TM; ++i) fa[nbuf][i] = cA[(2 * (s + 1) + lh) * BM + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = cB[(2 * s + lh) * BN + j * 32];
+        for (int j = 0; j < TN; ++j) fb[nbuf][j] = cB[(2 * (s + 1) + lh) * BN + j * 32];
+      }
+      if ((s & 3) == 0 && (s >> 2) < RA) load_a(s >> 2, pnext, have_next);
+      if ((s & 3) == 2 && (s >> 2) < RB) load_b(s >> 2, pnext, have_next);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cbuf][i], fb[cbuf][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < TM * TN; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (m < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        if (m == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
     }
-    if (kt + 1 < KT) store_tile(cur ^ 1);
+    if (have_next) store_tile(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
+  // epilogue: accumulators -> LDS [BM][BN+4] -> row-major slab with 16-byte stores
+  constexpr int CS = BN + 4;
+  float* stage = smem;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CS + wn0 + j * 32 + l31] = acc[i][j][r];
+  __syncthreads();
   float* __restrict__ part = a.part + (size_t)ck * a.Cout * a.N2;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    int n = n0 + wn0 + j * 32 + l31;
-    if (n >= a.N2) continue;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < a.Cout) part[(size_t)m * a.N2 + n] = acc[i][j][r];
-      }
+  constexpr int CG = BN / 4, RS = 256 / CG;
+  const int c4 = tid % CG, rr = tid / CG;
+  const int n = n0 + c4 * 4;
+  if (n < a.N2) {
+#pragma unroll 4
+    for (int row = rr; row < BM; row += RS) {
+      int m = m0 + row;
+      if (m < a.Cout)
+        *reinterpret_cast<f32x4*>(part + (size_t)m * a.N2 + n) =
+            *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4);
+    }
   }
 }
 
 // dw_oihw[co][ci][kh][kw] (+)= sum_s part[s][co][(kh*KW+kw)*Cin_pad + ci]   (ci < Cin)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int nchunks,
-                                    int Cout, int Cin, int Cin_pad, int T, int accumulate) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                            int nchunks, int Cout, int Cin, int Cin_pad, int T,
+                                                            int accumulate) {
+  // 64 consecutive slab elements per block, 4 threads per element each summing every 4th chunk (coalesced
+  // 256-byte rows), fixed-order combine through LDS: short serial chains even for hundreds of chunks.
+  __shared__ float red[256];
   const int N2 = T * Cin_pad;
-  size_t total = (size_t)Cout * N2;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
-    int co = (int)(idx / N2);
-    int n2 = (int)(idx - (size_t)co * N2);
-    int tap = n2 / Cin_pad;
-    int ci = n2 - tap * Cin_pad;
-    if (ci >= Cin) continue;
+  const size_t total = (size_t)Cout * N2;
+  const int el = threadIdx.x & 63, part_id = threadIdx.x >> 6;
+  for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
+    size_t idx = base + el;
     float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += part[(size_t)c * total + idx];
-    size_t o = ((size_t)co * Cin + ci) * T + tap;
-    dw[o] = accumulate ? dw[o] + s : s;
+    if (idx < total)
+      for (int c = part_id; c < nchunks; c += 4) s += part[(size_t)c * total + idx];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (part_id == 0 && idx < total) {
+      float t = (red[el] + red[64 + el]) + (red[128 + el] + red[192 + el]);
+      int co = (int)(idx / N2);
+      int n2 = (int)(idx - (size_t)co * N2);
+      int tap = n2 / Cin_pad;
+      int ci = n2 - tap * Cin_pad;
+      if (ci < Cin) {
+        size_t o = ((size_t)co * Cin + ci) * T + tap;
+        dw[o] = accumulate ? dw[o] + t : t;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -739,6 +814,8 @@ template <int BM, int BN>
 static int launch_tn(const WgradArgs& a, int chunks, hipStream_t st) {
   int ntm = (a.Cout + BM - 1) / BM, ntn = (a.N2 + BN - 1) / BN;
   size_t lds = (size_t)2 * 32 * (BM + BN) * sizeof(float);
+  size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);
+  if (lds_epi > lds) lds = lds_epi;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tn_kernel<BM, BN>),
@@ -886,8 +963,8 @@ int sacv_conv2d_wgrad(int nseg, const float* const* dy, const float* const* x, c
   int T = dw_taps > 0 ? dw_taps : KH * KW;
   // for the stem (dw_taps = 49, KH=KW=1, Cin_pad = Kpad): part is [Cout][Kpad] with k = tap*Cin + ci
   size_t total = (size_t)Cout * KH * KW * Cin_pad;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  int blocks = (int)((total + 63) / 64);
+  if (blocks > 8192) blocks = 8192;
   if (dw_taps > 0) {
     // reinterpret: N2 = Kpad, real k < dw_taps*Cin laid out tap-major
     // handled by the generic reduce with T=dw_taps, Cin_pad=Cin when Kpad == padded T*Cin: use stem reducer

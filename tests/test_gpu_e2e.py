@@ -118,43 +118,52 @@ def test_full_size_against_reference_fixture(golden_dir):
 
 
 def test_trainer_step_matches_cpu_adamw():
-    """Three fused steps (forward, loss, backward, AdamW over the flat arena) vs the oracle model with
-    torch.optim.AdamW in the reference's two parameter groups (tools/utils.py:484-509)."""
+    """Fused trainer steps (forward, loss, backward, AdamW over the flat arena) vs the oracle model with
+    torch.optim.AdamW in the reference's two parameter groups (tools/utils.py:484-509).
+
+    Adam normalises every element's update to ~lr whatever the gradient's scale, so elements whose
+    gradient is rounding noise move by +-lr at random in BOTH implementations; the parameter check is
+    therefore restricted to elements with a significant gradient (|g| > 1 % of the tensor's max), where
+    the update must agree to a small fraction of lr.  (The AdamW kernel itself is checked element-exact
+    against torch in test_adamw_matches_torch.)"""
     from sacv_amd.detection import losses
     from sacv_amd.train import DetectionTrainer
-    H, W = gi.TINY
+    H, W = gi.MID
+    lr = 1e-4
     sd = omodel.init_retinanet_state(0)
     net = build_gpu_model(sd)
-    trainer = DetectionTrainer(net, losses.__dict__['RetinaLoss'](), lr=1e-4, weight_decay=1e-3)
+    trainer = DetectionTrainer(net, losses.__dict__['RetinaLoss'](), lr=lr, weight_decay=1e-3)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
               if v.dtype.is_floating_point and 'running_' not in k}
     state = {k: v.clone() for k, v in sd.items()}
     state.update(params)
     opt = torch.optim.AdamW([{'params': [p for p in params.values() if p.ndim == 1], 'weight_decay': 0.0},
                              {'params': [p for p in params.values() if p.ndim != 1], 'weight_decay': 1e-3}],
-                            lr=1e-4)
+                            lr=lr)
     ocrit = olosses.RetinaLossOracle()
-    for it in range(3):
+    for it in range(2):
         images = torch.tensor(synth.images(50 + it, 2, H, W))
         annots = torch.tensor(synth.annotations(60 + it, 2, H, W, boxes_per_image=8))
         got = trainer.step(images.cuda(), annots.cuda())
         ld = ocrit(omodel.retinanet_forward(state, images, training=True), annots)
         opt.zero_grad()
         sum(ld.values()).backward()
+        if it == 0:
+            grads0 = {k: p.grad.clone() for k, p in params.items()}
         opt.step()
-        # step 0 starts from identical weights: 1e-4.  Later steps start from weights that differ by up to
-        # 2*lr per element (see below), which moves the loss itself by ~1e-4: 1e-3 there.
-        tol = 1e-4 if it == 0 else 1e-3
+        # step 0 starts from identical weights: 1e-4; step 1 starts from weights that differ by up to 2*lr on
+        # the noise-gradient elements, which moves the loss itself: 2e-3
+        tol = 1e-4 if it == 0 else 2e-3
         for k in ('cls_loss', 'reg_loss'):
             assert abs(float(got[k]) - float(ld[k])) <= tol * max(1.0, abs(float(ld[k]))), (it, k)
-    tot_abs, tot_n = 0.0, 0
-    for name, p in net.named_parameters():
-        r = params[name].detach()
-        d = (p.detach().cpu() - r).abs()
-        # Adam normalises every update to ~lr per element whatever the gradient scale, so an element whose
-        # tiny gradient differs in sign moves by up to 2*lr per step: bound = 3 steps * 2 * lr, and the
-        # MEAN deviation must stay far below one lr
-        assert float(d.max()) <= 3 * 2 * 1e-4 + 1e-6, name
-        tot_abs += float(d.sum())
-        tot_n += d.numel()
-    assert tot_abs / tot_n <= 0.1 * 1e-4, tot_abs / tot_n
+        if it == 0:
+            checked = 0
+            for name, p in net.named_parameters():
+                g = grads0[name]
+                mask = g.abs() > 1e-2 * g.abs().max()
+                d = (p.detach().cpu() - params[name].detach()).abs()[mask]
+                checked += int(mask.sum())
+                assert float(d.max()) <= 0.1 * lr, (name, float(d.max()))
+            assert checked > 1_000_000
+    fin = trainer.finish_step(got)
+    assert set(fin) == {'cls_loss', 'reg_loss', 'loss'} and abs(fin['loss'] - fin['cls_loss'] - fin['reg_loss']) < 1e-6

@@ -1,0 +1,70 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel exchange used by the trainer: staged asynchronous
+all-reduce over zero-copy slices of the flat gradient arena, rank-0 buffer broadcast, fused scalar vote."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from sacv_amd.detection import models
+        from sacv_amd.parallel import GradExchanger, stage_ranges, broadcast_buffers, vote_and_reduce_scalars
+        m = models.__dict__['resnet50_retinanet']()
+        # arena layout without touching the GPU: reuse the arena's ordering logic on CPU parameters
+        from sacv_amd.detection.models._arena import ParamArena
+        arena = ParamArena(m)
+        ranges = stage_ranges(arena.order, arena.offsets, arena.numel, arena.split)
+        # stages tile the arena exactly, in backward order heads -> neck -> rest
+        assert ranges['rest'][0] == 0 and ranges['rest'][1] == ranges['neck'][0]
+        assert ranges['neck'][1] == ranges['heads'][0] and ranges['heads'][1] == arena.numel
+        for n, _ in arena.order:
+            o = arena.offsets[n]
+            st = 'heads' if ('head' in n and arena.module_params[n].ndim != 1) else None
+            if st:
+                assert ranges['heads'][0] <= o < ranges['heads'][1], n
+        g = arena.grads
+        g.copy_(torch.arange(g.numel(), dtype=torch.float32) % 97 + rank)
+        ex = GradExchanger(g, ranges)
+        for stage in ('heads', 'neck', 'rest'):
+            ex.stage_done(stage)
+        ex.wait()
+        expect = (torch.arange(g.numel(), dtype=torch.float32) % 97) * world + sum(range(world))
+        assert torch.equal(g, expect)
+        # p.grad views alias the arena (zero copy)
+        arena.attach_grads()
+        name, p = arena.order[-1]
+        assert p.grad.data_ptr() == arena.grad_views[name].data_ptr()
+        # buffer broadcast: rank 0 wins
+        arena.buffers.fill_(float(rank + 1))
+        broadcast_buffers(arena.buffers)
+        assert float(arena.buffers.min()) == 1.0 and float(arena.buffers.max()) == 1.0
+        assert float(m.backbone.conv1.layer[1].running_mean[0]) == 1.0  # module buffers are arena views
+        v = vote_and_reduce_scalars(torch.tensor([1.0 + rank, 0.5]))
+        assert v.tolist() == [sum(1.0 + r for r in range(world)), 0.5 * world]
+        ret[rank] = 'ok'
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_exchange_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: 'ok', 1: 'ok'}

@@ -119,12 +119,24 @@ def main():
     roofline = None
     if timer is not None:
         agg = timer.summary()
-        k = agg.get('conv_nt_128x128')
+        if os.environ.get('SACV_BENCH_DUMP') and rank == 0:  # per-launch table of the last step (tuning aid)
+            recs = timer.records[-(len(timer.records) // args.steps):]
+            with open(os.environ['SACV_BENCH_DUMP'], 'w') as f:
+                for key, flops, e0, e1 in recs:
+                    ms = e0.elapsed_time(e1)
+                    f.write(f'{key} {flops/1e9:.3f} GFLOP {ms*1e3:.1f} us {flops/(ms*1e-3)/1e12:.1f} TF\n')
+        k = None
+        for name, v in agg.items():  # keys carry a per-shape suffix after '|'
+            if name.startswith('conv_nt_'):
+                if k is None:
+                    k = dict(launches=0, flops=0.0, ms=0.0)
+                for f_ in ('launches', 'flops', 'ms'):
+                    k[f_] += v[f_]
         if k:
             per_launch_flops = k['flops'] / k['launches']
             per_launch_ms = k['ms'] / k['launches']
             achieved = per_launch_flops / (per_launch_ms * 1e-3) / 1e12
-            roofline = dict(kernel='conv_nt_kernel<128,128> (implicit-GEMM conv fwd+dgrad, fp32 MFMA 32x32x2)',
+            roofline = dict(kernel='conv_nt_kernel<128,{128|64},mode> (implicit-GEMM conv forward + data gradient, fp32 MFMA 32x32x2)',
                             bound='mfma', achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                             frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
                             launches_per_step=k['launches'] // args.steps,

@@ -46,11 +46,16 @@ int sacv_conv2d_gemm(int nprob, const float* const* src /*host array*/, float* c
                      const float* const* mask /*host array or NULL*/, const int* Nb, const int* Hs, const int* Ws,
                      const int* Hd, const int* Wd /*host arrays*/, const float* w, const float* bias, int Cs, int N,
                      int KH, int KW, int stride, int pad, int mode, int flags, int remap_s, int Hr, int Wr,
-                     float* workspace /*sacv_conv2d_gemm_workspace_bytes() or NULL*/,
+                     const int* ext /*host int[12] or NULL, see below*/, float* workspace /*sacv_conv2d_gemm_workspace_bytes() or NULL*/,
                      float* stats /*[sacv_conv2d_gemm_stats_rows()][2][N], SACV_CF_STATS only*/, void* stream);
 /* The kernel is persistent (2 workgroups per CU): whole output tiles are dealt round-robin and the
  * tiles left over after the last full round are split along K over the idle workgroups; the K-slices
  * meet in `workspace` and are summed in a fixed order (deterministic). */
+/* ext (optional) = {pad_h, pad_w, kh0, khs, kw0, kws, KHreal, KWreal, 0, remap_oh, remap_ow, 0}: the KH x KW
+ * tap loop reads weight taps (kh0 + khs*kh, kw0 + kws*kw) of a KHreal x KWreal panel, with separate pads and
+ * a row-scatter offset.  Used for the data gradient of a stride-2 3x3 convolution, which is run as four
+ * stride-1 problems, one per output-pixel parity class, each touching only the taps that reach it (2.25 taps
+ * per pixel on average instead of 9). */
 long long sacv_conv2d_gemm_workspace_bytes(void);
 int sacv_conv2d_gemm_stats_rows(int nprob, const int* Nb, const int* Hd, const int* Wd);
 

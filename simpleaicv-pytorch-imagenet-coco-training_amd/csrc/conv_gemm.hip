@@ -40,6 +40,7 @@ struct ConvProb {
   int M;           // Nb*Hd*Wd
   int tile_begin;  // first M-tile of this problem
   int remap_s, Hr, Wr;  // dst row remap (strided scatter) when remap_s > 0
+  int remap_oh, remap_ow;  // + offsets: row = ((n*Hr + h*remap_s + remap_oh)*Wr + w*remap_s + remap_ow)
 };
 
 struct ConvArgs {
@@ -50,7 +51,10 @@ struct ConvArgs {
   const float* bias;
   int Cs;  // channels of src
   int N, K;
-  int KH, KW, stride_log2, pad;
+  int KH, KW, stride_log2, pad_h, pad_w;
+  // tap subset (parity-class data gradient of a strided conv): loop tap (kh,kw) of the KH x KW loop reads
+  // weight tap (kh0 + khs*kh, kw0 + kws*kw) of a panel that is KWr taps wide
+  int kh0, khs, kw0, kws, KWr;
   int mode;
   int flags;
   // persistent schedule (hybrid data-parallel + split-K):
@@ -116,7 +120,7 @@ __device__ __forceinline__ void vec_epilogue(const ConvArgs& a, const TileCoord&
       int rem = m - nn * hw;
       int hd = rem / P.Wd;
       int wd = rem - hd * P.Wd;
-      orow = ((size_t)nn * P.Hr + (size_t)hd * P.remap_s) * P.Wr + (size_t)wd * P.remap_s;
+      orow = ((size_t)nn * P.Hr + (size_t)hd * P.remap_s + P.remap_oh) * P.Wr + (size_t)wd * P.remap_s + P.remap_ow;
     }
     const size_t o = orow * N + n;
     if (flags & CF_ACCUM) v += *reinterpret_cast<const f32x4*>(dst + o);
@@ -183,11 +187,13 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
   const float* src;
   int Hs, Ws, n0;
   TileCoord tc;
-  int k_begin, k_end, slot;
+  int k_begin, k_end, slot, cur_tile = 0;
 
   auto setup = [&](int sidx) {
     int tile;
     if (sidx < a.base) {
+      // plain round-robin.  (An XCD-contiguous order -- each XCD taking grid/8 consecutive tiles per
+      // round -- was measured: +2 % on a single large problem, -7 % on the grouped head launches.)
       tile = bid + sidx * a.grid;
       k_begin = 0;
       k_end = KT;
@@ -199,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
       k_end = (int)(((long long)(part + 1) * KT) / a.bpt);
       slot = (a.bpt > 1) ? bid : -1;
     }
+    cur_tile = tile;
     tc = tile_coord<BM, BN>(a, tile);
     const ConvProb& P = a.p[tc.pi];
     src = P.src;
@@ -216,11 +223,11 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
         int wd = rem - hd * P.Wd;
         nb[i] = n * Hs * Ws;
         if (MODE == 0) {
-          hb[i] = (hd << a.stride_log2) - a.pad;
-          wb[i] = (wd << a.stride_log2) - a.pad;
+          hb[i] = (hd << a.stride_log2) - a.pad_h;
+          wb[i] = (wd << a.stride_log2) - a.pad_w;
         } else {
-          hb[i] = hd + a.pad;
-          wb[i] = wd + a.pad;
+          hb[i] = hd + a.pad_h;
+          wb[i] = wd + a.pad_w;
         }
       } else {
         nb[i] = 0;
@@ -232,13 +239,14 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
 
   f32x4 ra[RA], rb[RB];
   // coordinates of the K slab being fetched (wave-uniform)
-  int lt_tap = 0, lt_c0 = 0, lt_kh = 0, lt_kw = 0;
+  int lt_tap = 0, lt_c0 = 0, lt_kh = 0, lt_kw = 0, lt_rtap = 0;
   bool lt_kok = false;
   auto load_begin = [&](int kt, bool enable) {
     lt_tap = kt / cpt;
     lt_c0 = (kt - lt_tap * cpt) << 5;
     lt_kh = lt_tap / a.KW;
     lt_kw = lt_tap - lt_kh * a.KW;
+    lt_rtap = (a.kh0 + a.khs * lt_kh) * a.KWr + (a.kw0 + a.kws * lt_kw);
     lt_kok = enable && ((lt_c0 + kq * 4) < Cs);
   };
   // branch-free gathers: always load (offset 0 of the tensor when predicated off), then select.  A
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
   auto load_b = [&](int i) {
     int n = n0 + r0 + 32 * i;
     bool ok = (n < a.N) && lt_kok;
-    size_t off = ok ? (size_t)n * a.K + lt_tap * Cs + lt_c0 + kq * 4 : (size_t)0;
+    size_t off = ok ? (size_t)n * a.K + lt_rtap * Cs + lt_c0 + kq * 4 : (size_t)0;
     f32x4 v = *reinterpret_cast<const f32x4*>(wgt + off);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     rb[i] = ok ? v : z;
@@ -307,6 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const TileCoord my_tc = tc;
     const int my_slot = slot;
+    const int my_tile = cur_tile;
     const int kb = k_begin, ke = k_end;
     const bool more = (sidx + 1) < nseg;
     for (int kt = kb; kt < ke; ++kt) {
@@ -373,7 +382,6 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
       __syncthreads();
       if (my_slot < 0) {
         const int ntn = (a.N + BN - 1) / BN;
-        const int my_tile = (sidx < a.base) ? (bid + sidx * a.grid) : (a.base * a.grid + bid / a.bpt);
         vec_epilogue<BM, BN, 256>(
             a, my_tc, my_tile / ntn,
             [&](int row, int c4) { return *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4); },
@@ -771,25 +779,52 @@ static int num_cus() {
 
 #define SACV_NT_BLOCKS_PER_CU 2
 
+struct NtPlan {
+  int base, rem, bpt;
+  double cost;  // in units of one 128x128 K-iteration
+};
+
+// Schedule of `tiles` equal tiles of KT K-iterations on `grid` persistent workgroups.  w = relative cost of
+// one K-iteration of this tile shape (1.0 for 128x128, ~0.6 for 128x64).
+static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w) {
+  const double epi = 3.0, epi_split = 7.0;  // epilogue / slab write + fix-up, in K-iterations
+  NtPlan p;
+  p.base = tiles / grid;
+  p.rem = tiles - p.base * grid;
+  p.bpt = 1;
+  if (p.rem == 0) {
+    p.cost = p.base * (KT + epi) * w;
+    return p;
+  }
+  int best = 1;
+  double best_c = (KT + epi);
+  if (has_ws) {
+    int max_bpt = KT / 4 > 0 ? KT / 4 : 1;
+    if (max_bpt > 64) max_bpt = 64;
+    for (int b = 2; b <= max_bpt; ++b) {
+      long long blocks = (long long)p.rem * b;
+      if (p.base > 0 && blocks > grid) break;          // phase 2 of a multi-round launch: one slice per workgroup
+      if (blocks > 4LL * grid) break;
+      int rounds = (int)((blocks + grid - 1) / grid);  // base == 0 may oversubscribe (plain extra rounds)
+      double c = rounds * ((KT + b - 1) / b + epi_split);
+      if (c < best_c) {
+        best_c = c;
+        best = b;
+      }
+    }
+  }
+  p.bpt = best;
+  p.cost = (p.base * (KT + epi) + best_c) * w;
+  return p;
+}
+
 template <int BM, int BN, int MODE>
-static int launch_nt(ConvArgs& a, float* workspace, hipStream_t st) {
-  int ntn = (a.N + BN - 1) / BN;
-  int tiles = a.total_mtiles * ntn;
+static int launch_nt(ConvArgs& a, const NtPlan& plan, float* workspace, hipStream_t st) {
   int grid = num_cus() * SACV_NT_BLOCKS_PER_CU;
   a.grid = grid;
-  a.base = tiles / grid;
-  a.rem_tiles = tiles - a.base * grid;
-  int cpt = (a.Cs + 31) / 32;
-  int KT = a.KH * a.KW * cpt;
-  a.bpt = 1;
-  if (a.rem_tiles > 0) {
-    int bpt = grid / a.rem_tiles;
-    if (bpt > KT) bpt = KT;
-    // split only when it pays: keep >= 4 K-iterations per slice, and no split without a workspace
-    while (bpt > 1 && KT / bpt < 4) --bpt;
-    if (!workspace) bpt = 1;
-    a.bpt = bpt < 1 ? 1 : bpt;
-  }
+  a.base = plan.base;
+  a.rem_tiles = plan.rem;
+  a.bpt = plan.bpt;
   a.partial = workspace;
   size_t lds = (size_t)2 * (BM + BN) * 36 * sizeof(float);
   size_t lds_epi = ((size_t)BM * (BN + 4) + 2 * (256 / (BN / 4)) * BN) * sizeof(float);
@@ -835,7 +870,7 @@ extern "C" {
 int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, const float* const* mask,
                      const int* Nb, const int* Hs, const int* Ws, const int* Hd, const int* Wd, const float* w,
                      const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode, int flags,
-                     int remap_s, int Hr, int Wr, float* workspace, float* stats, void* stream) {
+                     int remap_s, int Hr, int Wr, const int* ext, float* workspace, float* stats, void* stream) {
   SACV_CHECK_ARG(nprob >= 1 && nprob <= SACV_MAXP, "conv2d_gemm: nprob %d out of range", nprob);
   SACV_CHECK_ARG(Cs % 4 == 0 && Cs > 0, "conv2d_gemm: Cs=%d must be a positive multiple of 4", Cs);
   SACV_CHECK_ARG(N > 0 && KH > 0 && KW > 0, "conv2d_gemm: bad N/KH/KW");
@@ -847,7 +882,6 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
   SACV_CHECK_ARG(N % 4 == 0, "conv2d_gemm: N=%d must be a multiple of 4", N);
   SACV_CHECK_ARG(!(flags & CF_STATS) || stats, "conv2d_gemm: CF_STATS without a stats buffer");
   ConvArgs a;
-  const bool small_n = N <= 64;
   const int BM = 128;
   int tiles = 0;
   for (int i = 0; i < nprob; ++i) {
@@ -872,6 +906,8 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
     p.remap_s = remap_s;
     p.Hr = Hr;
     p.Wr = Wr;
+    p.remap_oh = ext ? ext[9] : 0;
+    p.remap_ow = ext ? ext[10] : 0;
     tiles += (p.M + BM - 1) / BM;
   }
   a.nprob = nprob;
@@ -880,17 +916,42 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
   a.bias = bias;
   a.Cs = Cs;
   a.N = N;
-  a.K = KH * KW * Cs;
   a.KH = KH;
   a.KW = KW;
   a.stride_log2 = sl;
-  a.pad = pad;
+  a.pad_h = pad;
+  a.pad_w = pad;
+  a.kh0 = 0;
+  a.khs = 1;
+  a.kw0 = 0;
+  a.kws = 1;
+  a.KWr = KW;
+  a.K = KH * KW * Cs;
+  if (ext) {
+    // ext = {pad_h, pad_w, kh0, khs, kw0, kws, KHreal, KWreal, 0, remap_oh, remap_ow, 0}
+    a.pad_h = ext[0];
+    a.pad_w = ext[1];
+    a.kh0 = ext[2];
+    a.khs = ext[3];
+    a.kw0 = ext[4];
+    a.kws = ext[5];
+    a.KWr = ext[7];
+    a.K = ext[6] * ext[7] * Cs;
+    SACV_CHECK_ARG(a.kh0 + a.khs * (KH - 1) < ext[6] && a.kw0 + a.kws * (KW - 1) < ext[7],
+                   "conv2d_gemm: tap subset exceeds the weight panel");
+  }
   a.mode = mode;
   a.flags = flags;
   a.stats = stats;
   hipStream_t st = (hipStream_t)stream;
-  if (small_n) return mode == 0 ? launch_nt<128, 64, 0>(a, workspace, st) : launch_nt<128, 64, 1>(a, workspace, st);
-  return mode == 0 ? launch_nt<128, 128, 0>(a, workspace, st) : launch_nt<128, 128, 1>(a, workspace, st);
+  const int grid = num_cus() * SACV_NT_BLOCKS_PER_CU;
+  const int KT = KH * KW * ((Cs + 31) / 32);
+  const bool ws = workspace != nullptr;
+  NtPlan p128 = plan_nt(tiles * ((N + 127) / 128), KT, grid, ws, 1.0);
+  NtPlan p64 = plan_nt(tiles * ((N + 63) / 64), KT, grid, ws, 0.6);
+  const bool use64 = (N <= 64) || (p64.cost < p128.cost);
+  if (use64) return mode == 0 ? launch_nt<128, 64, 0>(a, p64, workspace, st) : launch_nt<128, 64, 1>(a, p64, workspace, st);
+  return mode == 0 ? launch_nt<128, 128, 0>(a, p128, workspace, st) : launch_nt<128, 128, 1>(a, p128, workspace, st);
 }
 
 // Rows of the CF_STATS buffer ([rows][2][N] floats): the number of 128-row M tiles over all problems.

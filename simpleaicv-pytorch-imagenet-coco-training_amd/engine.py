@@ -111,9 +111,33 @@ class DetectorEngine:
             ops.conv_gemm([dy], wd, cin, 1, 1, 1, 0, 0, [(dy.shape[1], dy.shape[2])], flags=flags,
                           outs=[out], remap=(stride, h, wdt))
             return out
+        if stride == 2 and k > 1:
+            return self._dgrad_parity(dy, wd, cin, x_shape, k, pad, out, flags, mask)
         outs = [out] if out is not None else None
         return ops.conv_gemm([dy], wd, cin, k, k, stride, pad, 1, [(h, wdt)], flags=flags,
                              masks=[mask] if mask is not None else None, outs=outs)[0]
+
+    def _dgrad_parity(self, dy, wd, cin, x_shape, k, pad, out, flags, mask):
+        """Data gradient of a stride-2 k x k conv as four stride-1 problems, one per parity class of the
+        input pixel (h%2, w%2): class (ph, pw) is reached only by taps kh = (ph+pad)%2 (mod 2) and likewise
+        for kw, so the four launches together execute exactly the forward's MACs instead of 4x."""
+        n, h, w, _ = x_shape
+        if out is None:
+            out = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+        for ph in (0, 1):
+            for pw in (0, 1):
+                hc, wc = (h - ph + 1) // 2, (w - pw + 1) // 2
+                if hc <= 0 or wc <= 0:
+                    continue
+                kh0, kw0 = (ph + pad) & 1, (pw + pad) & 1
+                nkh, nkw = len(range(kh0, k, 2)), len(range(kw0, k, 2))
+                if nkh == 0 or nkw == 0:
+                    raise NotImplementedError('parity class without taps')
+                ah, aw = (ph + pad - kh0) // 2, (pw + pad - kw0) // 2
+                ext = [ah, aw, kh0, 2, kw0, 2, k, k, 0, ph, pw, 0]
+                ops.conv_gemm([dy], wd, cin, nkh, nkw, 1, 0, 1, [(hc, wc)], flags=flags,
+                              masks=[mask] if mask is not None else None, outs=[out], remap=(2, h, w), ext=ext)
+        return out
 
     # ------------------------------------------------------------------ forward
     def forward(self, images, training=True, keep=True):

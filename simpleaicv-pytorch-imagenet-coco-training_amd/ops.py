@@ -84,7 +84,7 @@ def _gemm_ws_bytes():
 
 
 def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=None, flags=0, masks=None,
-              outs=None, remap=None, stats=False):
+              outs=None, remap=None, stats=False, ext=None):
     """Grouped implicit-GEMM conv.  srcs: list of NHWC tensors sharing the channel count.
 
     mode 0: forward (out_hw[i] = output H,W);  mode 1: data gradient (out_hw[i] = input H,W).
@@ -114,6 +114,7 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
             iarr([s.shape[0] for s in srcs]), iarr([s.shape[1] for s in srcs]), iarr([s.shape[2] for s in srcs]),
             iarr([hw[0] for hw in out_hw]), iarr([hw[1] for hw in out_hw]),
             _ptr(w_packed), _ptr(bias), cs, n_out, kh, kw, stride, pad, mode, flags, rs, hr, wr,
+            iarr(ext) if ext is not None else None,
             workspace(_gemm_ws_bytes(), srcs[0].device, 'conv_gemm').data_ptr(), _ptr(stats_buf), _stream()),
             'conv2d_gemm')
 
@@ -123,7 +124,8 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
             pix = sum(s.shape[0] * hw[0] * hw[1] for s, hw in zip(srcs, out_hw))
         else:
             pix = sum(s.shape[0] * s.shape[1] * s.shape[2] for s in srcs)
-        TIMER.time('conv_nt_128x128' if n_out > 64 else 'conv_nt_128x64', 2.0 * pix * n_out * kh * kw * cs, launch)
+        TIMER.time(('conv_nt_128x128' if n_out > 64 else 'conv_nt_128x64') + f'|m{mode} k{kh} s{stride} cs{cs} n{n_out} np{n} pix{pix} f{flags}',
+                   2.0 * pix * n_out * kh * kw * cs, launch)
     else:
         launch()
     if stats:

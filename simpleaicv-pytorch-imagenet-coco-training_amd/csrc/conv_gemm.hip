@@ -180,10 +180,15 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
   const int nseg = a.base + (bid < nrem ? 1 : 0);
   if (nseg == 0) return;
 
-  // per-thread gather state of the CURRENT segment
+  // per-thread gather state of the CURRENT segment.  All offsets are 32-bit element indices (tensors are
+  // checked to be < 2^30 elements) relative to wave-uniform base pointers, so a gather is a handful of
+  // cheap VALU ops + one saddr global load: no 64-bit multiplies, no branches (both would fence the
+  // scheduler and cluster ~100 issue cycles of address arithmetic between two MFMAs).
   const int kq = tid & 7;
   const int r0 = tid >> 3;
-  int hb[RA], wb[RA], nb[RA];
+  int hb[RA], wb[RA], rowoff[RA];
+  int wrow[RB];
+  bool wok[RB];
   const float* src;
   int Hs, Ws, n0;
   TileCoord tc;
@@ -221,7 +226,6 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
         int rem = m - n * hw;
         int hd = rem / P.Wd;
         int wd = rem - hd * P.Wd;
-        nb[i] = n * Hs * Ws;
         if (MODE == 0) {
           hb[i] = (hd << a.stride_log2) - a.pad_h;
           wb[i] = (wd << a.stride_log2) - a.pad_w;
@@ -229,53 +233,67 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
           hb[i] = hd + a.pad_h;
           wb[i] = wd + a.pad_w;
         }
+        // element offset of source pixel (hb, wb) of image n, channel kq*4 (may be "negative": only used
+        // when the tap lands inside the image)
+        rowoff[i] = (n * Hs * Ws + hb[i] * Ws + wb[i]) * Cs + kq * 4;
+        if (MODE == 1 && a.stride_log2 > 0) rowoff[i] = n * Hs * Ws * Cs + kq * 4;
       } else {
-        nb[i] = 0;
         hb[i] = -100000;  // never valid in either mode
         wb[i] = -100000;
+        rowoff[i] = 0;
       }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int n = n0 + r0 + 32 * i;
+      wok[i] = n < a.N;
+      wrow[i] = n * a.K + kq * 4;
     }
   };
 
   f32x4 ra[RA], rb[RB];
   // coordinates of the K slab being fetched (wave-uniform)
-  int lt_tap = 0, lt_c0 = 0, lt_kh = 0, lt_kw = 0, lt_rtap = 0;
+  int lt_c0 = 0, lt_kh = 0, lt_kw = 0, lt_aoff = 0, lt_boff = 0;
   bool lt_kok = false;
   auto load_begin = [&](int kt, bool enable) {
-    lt_tap = kt / cpt;
-    lt_c0 = (kt - lt_tap * cpt) << 5;
-    lt_kh = lt_tap / a.KW;
-    lt_kw = lt_tap - lt_kh * a.KW;
-    lt_rtap = (a.kh0 + a.khs * lt_kh) * a.KWr + (a.kw0 + a.kws * lt_kw);
+    int tap = kt / cpt;
+    lt_c0 = (kt - tap * cpt) << 5;
+    lt_kh = tap / a.KW;
+    lt_kw = tap - lt_kh * a.KW;
+    int rtap = (a.kh0 + a.khs * lt_kh) * a.KWr + (a.kw0 + a.kws * lt_kw);
+    lt_boff = rtap * Cs + lt_c0;
+    // source offset of this tap relative to (hb, wb): scalar
+    lt_aoff = (MODE == 0 ? (lt_kh * Ws + lt_kw) : -(lt_kh * Ws + lt_kw)) * Cs + lt_c0;
     lt_kok = enable && ((lt_c0 + kq * 4) < Cs);
   };
-  // branch-free gathers: always load (offset 0 of the tensor when predicated off), then select.  A
-  // branch per load makes hipcc wait vmcnt(0) after each one and serialises the loads.
   auto load_a = [&](int i) {
-    int hs, ws;
     bool ok;
+    int off;
     if (MODE == 0) {
-      hs = hb[i] + lt_kh;
-      ws = wb[i] + lt_kw;
+      int hs = hb[i] + lt_kh, ws = wb[i] + lt_kw;
       ok = ((unsigned)hs < (unsigned)Hs) && ((unsigned)ws < (unsigned)Ws);
+      off = rowoff[i] + lt_aoff;
+    } else if (a.stride_log2 == 0) {
+      int hs = hb[i] - lt_kh, ws = wb[i] - lt_kw;
+      ok = ((unsigned)hs < (unsigned)Hs) && ((unsigned)ws < (unsigned)Ws);
+      off = rowoff[i] + lt_aoff;
     } else {
       int th = hb[i] - lt_kh, tw = wb[i] - lt_kw;
       ok = (th >= 0) && (tw >= 0) && (((th | tw) & smask) == 0);
-      hs = th >> a.stride_log2;
-      ws = tw >> a.stride_log2;
+      int hs = th >> a.stride_log2, ws = tw >> a.stride_log2;
       ok = ok && (hs < Hs) && (ws < Ws);
+      off = rowoff[i] + (hs * Ws + ws) * Cs + lt_c0;
     }
     ok = ok && lt_kok;
-    size_t off = ok ? ((size_t)(nb[i] + hs * Ws + ws)) * Cs + lt_c0 + kq * 4 : (size_t)0;
-    f32x4 v = *reinterpret_cast<const f32x4*>(src + off);
+    unsigned uoff = ok ? (unsigned)off : 0u;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src + uoff);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     ra[i] = ok ? v : z;
   };
   auto load_b = [&](int i) {
-    int n = n0 + r0 + 32 * i;
-    bool ok = (n < a.N) && lt_kok;
-    size_t off = ok ? (size_t)n * a.K + lt_rtap * Cs + lt_c0 + kq * 4 : (size_t)0;
-    f32x4 v = *reinterpret_cast<const f32x4*>(wgt + off);
+    bool ok = wok[i] && lt_kok;
+    unsigned uoff = ok ? (unsigned)(wrow[i] + lt_boff) : 0u;
+    f32x4 v = *reinterpret_cast<const f32x4*>(wgt + uoff);
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     rb[i] = ok ? v : z;
   };
@@ -322,9 +340,9 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
       const bool last = (kt + 1 == ke);
       const bool have_next = !last || more;
       if (last && more) setup(sidx + 1);  // switch the gather state to the next segment
-      load_begin(last ? k_begin : kt + 1, have_next);
-      const float* cA = sA + cur * BM * LS + (wm0 + l31) * LS + 4 * lh;
-      const float* cB = sB + cur * BN * LS + (wn0 + l31) * LS + 4 * lh;
+      load_begin(last ? k_begin : kt + 1, have_next && !(a.flags & 1024));
+      const float* cA = sA + ((a.flags & 8192) ? 0 : cur * BM * LS + (wm0 + l31) * LS + 4 * lh);
+      const float* cB = sB + ((a.flags & 8192) ? 0 : cur * BN * LS + (wn0 + l31) * LS + 4 * lh);
       // The next slab's gathers (address arithmetic + 16-byte loads) and the next fragments' LDS reads
       // are issued in the shadow of the current MFMAs (an fp32 32x32x2 MFMA occupies the matrix pipe
       // for 64 cycles but the issue port for 8), so a wave keeps the pipe busy on its own instead of
@@ -364,8 +382,8 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
       }
       // the slab of the NEXT segment stays in registers across the epilogue (the LDS is needed to stage
       // the output tile); within a segment it goes straight to the other LDS buffer
-      if (!last) store_tile(cur ^ 1);
-      __syncthreads();
+      if (!last && !(a.flags & 2048)) store_tile(cur ^ 1);
+      if (!(a.flags & 4096)) __syncthreads();
       cur ^= 1;
     }
     // ---- epilogue: accumulators -> LDS [BM][BN+4] -> 16-byte row-major stores
@@ -879,6 +897,7 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
   SACV_CHECK_ARG(mode == 0 || mode == 1, "conv2d_gemm: mode");
   SACV_CHECK_ARG(!(flags & CF_BIAS) || bias, "conv2d_gemm: bias flag without bias pointer");
   SACV_CHECK_ARG(remap_s == 0 || nprob == 1, "conv2d_gemm: remap only for single problems");
+  SACV_CHECK_ARG((long long)N * KH * KW * Cs < (1LL << 30), "conv2d_gemm: weight panel too large");
   SACV_CHECK_ARG(N % 4 == 0, "conv2d_gemm: N=%d must be a multiple of 4", N);
   SACV_CHECK_ARG(!(flags & CF_STATS) || stats, "conv2d_gemm: CF_STATS without a stats buffer");
   ConvArgs a;
@@ -889,9 +908,9 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
     SACV_CHECK_ARG(Nb[i] > 0 && Hs[i] > 0 && Ws[i] > 0 && Hd[i] > 0 && Wd[i] > 0, "conv2d_gemm: bad dims");
     SACV_CHECK_ARG(!(flags & CF_MASK) || (mask && mask[i]), "conv2d_gemm: mask flag without mask pointer");
     long long M = (long long)Nb[i] * Hd[i] * Wd[i];
-    SACV_CHECK_ARG(M * (long long)(N > Cs ? N : Cs) < (1LL << 31) &&
-                       (long long)Nb[i] * Hs[i] * Ws[i] * Cs < (1LL << 31),
-                   "conv2d_gemm: tensor too large for 32-bit pixel indexing");
+    SACV_CHECK_ARG(M * (long long)(N > Cs ? N : Cs) < (1LL << 30) &&
+                       (long long)Nb[i] * Hs[i] * Ws[i] * Cs < (1LL << 30),
+                   "conv2d_gemm: tensor too large for 32-bit element indexing (2^30 elements)");
     ConvProb& p = a.p[i];
     p.src = src[i];
     p.dst = dst[i];

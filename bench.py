@@ -60,6 +60,8 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--model', default='retinanet', choices=['retinanet', 'fcos'],
+                    help='retinanet = the headline metric; fcos = secondary workload (BASELINE config 4)')
     ap.add_argument('--no-kernel-timer', action='store_true')
     args = ap.parse_args()
 
@@ -85,8 +87,12 @@ def main():
     from sacv_amd.train import DetectionTrainer
 
     torch.manual_seed(0)
-    net = models.__dict__['resnet50_retinanet'](backbone_pretrained_path='', num_classes=80).cuda().train()
-    crit = losses.__dict__['RetinaLoss'](box_loss_type='SmoothL1')
+    if args.model == 'fcos':
+        net = models.__dict__['resnet50_fcos'](backbone_pretrained_path='', num_classes=80).cuda().train()
+        crit = losses.__dict__['FCOSLoss']()
+    else:
+        net = models.__dict__['resnet50_retinanet'](backbone_pretrained_path='', num_classes=80).cuda().train()
+        crit = losses.__dict__['RetinaLoss'](box_loss_type='SmoothL1')
     trainer = DetectionTrainer(net, crit, lr=1e-4, weight_decay=1e-3, process_group=group)
     images = torch.tensor(synth.images(rank, BATCH, H, W)).cuda()
     annots = torch.tensor(synth.annotations(rank, BATCH, H, W, boxes_per_image=8)).cuda()
@@ -155,7 +161,10 @@ def main():
             'loss': losses_host,
             'roofline': roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.model == 'fcos':
+            line['metric'] = 'images/sec/node FCOS-R50 COCO 1333x800 bs=2/GPU (secondary)'
+            line['config']['workload'] = line['config']['workload'].replace('RetinaNet-ResNet50', 'FCOS-ResNet50').replace('RetinaLoss SmoothL1', 'FCOSLoss GIoU')
+        if world == 1 and not args.no_cpu_baseline and args.model == 'retinanet':
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -100,6 +100,15 @@ int sacv_bn_train_bwd(const float* dz, const float* zmask, const float* y, const
                       const float* gamma, float* dy, float* g_out, float* dgamma, float* dbeta, int R, int C,
                       int accumulate, float* workspace, void* stream);
 
+/* ---- GroupNorm(32, C) + ReLU of the FCOS head towers (detection/models/head.py:110,125) --------------- */
+long long sacv_gn_workspace_floats(int N, int HW, int C);
+/* x [N][HW][C]; stats out [N][G][2] = (mean, invstd); z = relu?(groupnorm(x)) */
+int sacv_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* z, float* stats, int N, int HW,
+                       int C, int G, float eps, int relu, float* workspace, void* stream);
+int sacv_groupnorm_bwd(const float* x, const float* dz, const float* zmask, const float* stats, const float* gamma,
+                       float* dx, float* dgamma, float* dbeta, int N, int HW, int C, int G, int accumulate,
+                       float* workspace, void* stream);
+
 /* ---- pooling / resize / elementwise ------------------------------------------------------------------ */
 /* nn.MaxPool2d(3,2,1) (detection/models/backbones/resnet.py:50); idx = window position of the max */
 int sacv_maxpool_fwd(const float* x, float* y, unsigned char* idx, int Nb, int H, int W, int C, int Ho, int Wo,
@@ -140,6 +149,25 @@ int sacv_retina_box_loss_fwd_bwd(int nlev, const float* const* reg_in, float* co
                                  const float* targets, const float* anchors, int B, int A, int box_type, float beta,
                                  float weight, const int* counts, float* workspace, float* loss_out, int slot,
                                  void* stream);
+
+/* FCOSLoss.get_batch_position_annotations (losses.py:612-833): targets [B][P][8] =
+ * (l,t,r,b, cls+1 | 0, centerness, px, py); level_off/strides/mi are host arrays; counts int[2] */
+int sacv_fcos_assign(int nlev, const int* level_off, const float* strides, const float* mi, const float* points,
+                     const float* annots, float* targets, int* counts, int B, int P, int G,
+                     float center_sample_radius, int use_center_sample, void* stream);
+/* compute_batch_iou_loss (losses.py:550-586, iou_type 0 IoU / 1 GIoU, weighted by the centerness target) and
+ * compute_batch_centerness_loss (:588-610), forward + gradients */
+int sacv_fcos_reg_ctr_loss_fwd_bwd(int nlev, const float* const* reg_in, const float* const* ctr_in,
+                                   float* const* dreg, float* const* dctr, const int* level_off,
+                                   const float* targets, int B, int P, int iou_type, float w_reg, float w_ctr,
+                                   const int* counts, float* workspace, float* loss_out, int slot_reg, int slot_ctr,
+                                   void* stream);
+/* FCOS output split (fcos.py:70-80; head.py:176-179): y8 [R][8] = (reg_raw[4], centerness logit, pad) ->
+ * reg = reg_raw * exp(scale), ctr = sigmoid(logit); and its backward (+ d loss / d scale) */
+int sacv_fcos_split_fwd(const float* y8, const float* scale, float* reg, float* ctr, int R, void* stream);
+int sacv_fcos_split_bwd(const float* dreg, const float* dctr, const float* reg, const float* ctr, const float* scale,
+                        float gscale, float* dy8, float* dscale, int idx, int accumulate, int R, float* workspace,
+                        void* stream);
 
 /* ---- postprocess (detection/decode.py) -------------------------------------------------------------- */
 long long sacv_decode_workspace_bytes(int B, int A, int topn);

@@ -29,6 +29,13 @@ SIGNATURES = {
     'sacv_bn_train_stats': (I, [P, I, I, F, F, P, P, P, P, P, P, P]),
     'sacv_bn_apply': (I, [P, P, P, P, P, P, P, LL, I, I, I, F, P]),
     'sacv_bn_train_bwd': (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
+    'sacv_gn_workspace_floats': (LL, [I, I, I]),
+    'sacv_groupnorm_fwd': (I, [P, P, P, P, P, I, I, I, I, F, I, P, P]),
+    'sacv_groupnorm_bwd': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),
+    'sacv_fcos_assign': (I, [I, P, P, P, P, P, P, P, I, I, I, F, I, P]),
+    'sacv_fcos_reg_ctr_loss_fwd_bwd': (I, [I, P, P, P, P, P, P, I, I, I, F, F, P, P, P, I, I, P]),
+    'sacv_fcos_split_fwd': (I, [P, P, P, P, I, P]),
+    'sacv_fcos_split_bwd': (I, [P, P, P, P, P, F, P, P, I, I, I, P, P]),
     'sacv_maxpool_fwd': (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     'sacv_maxpool_bwd': (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     'sacv_upsample_bilinear_add_fwd': (I, [P, P, P, I, I, I, I, I, I, P]),

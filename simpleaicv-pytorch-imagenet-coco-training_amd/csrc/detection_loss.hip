@@ -383,6 +383,209 @@ __global__ __launch_bounds__(256) void retina_box_loss_kernel(const RegPtrs rp, 
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+
+// ------------------------------------------------------------------------------------------ FCOS
+// FCOSLoss.get_batch_position_annotations (losses.py:612-833): per (image, point) one pass over the GTs.
+struct FcosLevels {
+  int off[MAXL + 1];
+  float stride[MAXL];
+  float mi_lo[MAXL], mi_hi[MAXL];
+  int nlev;
+};
+
+// targets[b][p] = (l, t, r, b, cls+1 | 0, centerness, px, py);  counts[0] += #positive
+__global__ __launch_bounds__(256) void fcos_assign_kernel(const FcosLevels lv, const float* __restrict__ points,
+                                                           const float* __restrict__ annots,
+                                                           float* __restrict__ targets, int* __restrict__ counts,
+                                                           int P, int G, float radius, int use_center_sample) {
+  __shared__ float gt[MAXG][5];
+  __shared__ int ng_s;
+  __shared__ int cnt_s;
+  const int b = blockIdx.y;
+  if (threadIdx.x == 0) {
+    int n = 0;
+    const float* an = annots + (size_t)b * G * 5;
+    for (int j = 0; j < G; ++j) {
+      if (an[j * 5 + 4] >= 0.f) {
+        for (int e = 0; e < 5; ++e) gt[n][e] = an[j * 5 + e];
+        ++n;
+      }
+    }
+    ng_s = n;
+    cnt_s = 0;
+  }
+  __syncthreads();
+  const int ng = ng_s;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int is_pos = 0;
+  if (i < P) {
+    int l = 0;
+    for (int k = 1; k < lv.nlev; ++k)
+      if (i >= lv.off[k]) l = k;
+    const float px = points[(size_t)i * 2], py = points[(size_t)i * 2 + 1];
+    const float judge = lv.stride[l] * radius;
+    const float lo = lv.mi_lo[l], hi = lv.mi_hi[l];
+    float best_area = 100000000.f;
+    int bi = -1;
+    float bl = 0.f, bt = 0.f, br = 0.f, bb = 0.f;
+    for (int g = 0; g < ng; ++g) {
+      float cl = px - gt[g][0], ct = py - gt[g][1], cr = gt[g][2] - px, cb = gt[g][3] - py;
+      bool ok = fminf(fminf(cl, ct), fminf(cr, cb)) > 0.f;
+      if (use_center_sample) {
+        float cx = (gt[g][2] + gt[g][0]) / 2.f, cy = (gt[g][3] + gt[g][1]) / 2.f;
+        float dx = px - cx, dy = py - cy;
+        float dist = sqrtf(dx * dx + dy * dy);
+        ok = ok && (dist < judge);
+      }
+      float cmax = ok ? fmaxf(fmaxf(cl, ct), fmaxf(cr, cb)) : 0.f;
+      ok = ok && (cmax > lo) && (cmax < hi);
+      float gw = gt[g][2] - gt[g][0], gh = gt[g][3] - gt[g][1];
+      float area = ok ? gw * gh : 100000000.f;
+      // argmin over ALL columns with first-index ties (torch.min): an invalid column carries INF
+      if (g == 0 || area < best_area) {
+        best_area = area;
+        bi = ok ? g : -1;
+        bl = cl;
+        bt = ct;
+        br = cr;
+        bb = cb;
+      }
+    }
+    float* out = targets + ((size_t)b * P + i) * 8;
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, px, py};
+    if (bi >= 0) {
+      o0[0] = bl;
+      o0[1] = bt;
+      o0[2] = br;
+      o0[3] = bb;
+      o1[0] = gt[bi][4] + 1.f;
+      o1[1] = sqrtf((fminf(bl, br) / fmaxf(bl, br)) * (fminf(bt, bb) / fmaxf(bt, bb)));
+      is_pos = 1;
+    }
+    *reinterpret_cast<f32x4*>(out) = o0;
+    *reinterpret_cast<f32x4*>(out + 4) = o1;
+  }
+  unsigned long long mp = __ballot(is_pos);
+  if ((threadIdx.x & 63) == 0 && mp) atomicAdd(&cnt_s, __popcll(mp));
+  __syncthreads();
+  if (threadIdx.x == 0 && cnt_s) atomicAdd(&counts[0], cnt_s);
+}
+
+struct FcosPtrs {
+  const float* reg[MAXL];
+  const float* ctr[MAXL];
+  float* dreg[MAXL];
+  float* dctr[MAXL];
+  int off[MAXL + 1];
+  int nlev;
+};
+
+// FCOSLoss.compute_batch_iou_loss (losses.py:550-586) and compute_batch_centerness_loss (:588-610),
+// forward + gradients in one pass over the points.  partial[0][blk] = IoU-loss sum, partial[1][blk] = BCE sum.
+__global__ __launch_bounds__(256) void fcos_reg_ctr_loss_kernel(const FcosPtrs fp, const float* __restrict__ targets,
+                                                                 int B, int P, int iou_type, float w_reg,
+                                                                 float w_ctr, const int* __restrict__ counts,
+                                                                 float* __restrict__ partial, int nblk) {
+  const size_t total = (size_t)B * P;
+  const int npos = counts[0];
+  const float s_reg = npos > 0 ? w_reg / (float)npos : 0.f;
+  const float s_ctr = npos > 0 ? w_ctr / (float)npos : 0.f;
+  const float lo = 1e-4f, hi = (float)(1. - 1e-4);
+  float sum_r = 0.f, sum_c = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int a = (int)(i % P), b = (int)(i / P);
+    int l = 0;
+    for (int k = 1; k < fp.nlev; ++k)
+      if (a >= fp.off[k]) l = k;
+    int nl = fp.off[l + 1] - fp.off[l];
+    size_t row = (size_t)b * nl + (a - fp.off[l]);
+    const float* tg = targets + i * 8;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    float gc = 0.f;
+    if (tg[4] > 0.f) {
+      f32x4 r = *reinterpret_cast<const f32x4*>(fp.reg[l] + row * 4);
+      float e0 = expf(r[0]), e1 = expf(r[1]), e2 = expf(r[2]), e3 = expf(r[3]);
+      float px = tg[6], py = tg[7], ct = tg[5];
+      float p[4] = {px - e0, py - e1, px + e2, py + e3};
+      float gg[4] = {px - tg[0], py - tg[1], px + tg[2], py + tg[3]};
+      float dp[4];
+      float li = iou_loss_fwd_bwd(p, gg, iou_type, dp);
+      sum_r += li * ct;
+      g[0] = -dp[0] * e0 * ct * s_reg;
+      g[1] = -dp[1] * e1 * ct * s_reg;
+      g[2] = dp[2] * e2 * ct * s_reg;
+      g[3] = dp[3] * e3 * ct * s_reg;
+      float craw = fp.ctr[l][row];
+      float c = fminf(fmaxf(craw, lo), hi);
+      sum_c += -(ct * logf(c) + (1.f - ct) * logf(1.f - c));
+      bool inside = (craw >= lo) && (craw <= hi);
+      gc = inside ? (-(ct / c) + (1.f - ct) / (1.f - c)) * s_ctr : 0.f;
+    }
+    if (fp.dreg[l]) *reinterpret_cast<f32x4*>(fp.dreg[l] + row * 4) = g;
+    if (fp.dctr[l]) fp.dctr[l][row] = gc;
+  }
+  __shared__ float red[8];
+  float wr = wave_sum(sum_r), wc = wave_sum(sum_c);
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = wr;
+    red[4 + (threadIdx.x >> 6)] = wc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    partial[nblk + blockIdx.x] = red[4] + red[5] + red[6] + red[7];
+  }
+}
+
+// FCOS output head split (fcos.py:70-80, head.py:176-179): y8 [R][8] = (reg_raw[4], ctr_logit, pad[3])
+//   reg[R][4] = reg_raw * exp(scale),  ctr[R][1] = sigmoid(ctr_logit)
+__global__ __launch_bounds__(256) void fcos_split_fwd_kernel(const float* __restrict__ y8,
+                                                              const float* __restrict__ scale,
+                                                              float* __restrict__ reg, float* __restrict__ ctr,
+                                                              int R) {
+  const float es = expf(scale[0]);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R; i += gridDim.x * blockDim.x) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(y8 + (size_t)i * 8);
+    float c = y8[(size_t)i * 8 + 4];
+    *reinterpret_cast<f32x4*>(reg + (size_t)i * 4) = a * es;
+    ctr[i] = 1.f / (1.f + __expf(-c));
+  }
+}
+// dy8 = (dreg*exp(scale), dctr*c*(1-c), 0, 0, 0);  partial[blk] = sum dreg*reg  (= d loss / d scale)
+__global__ __launch_bounds__(256) void fcos_split_bwd_kernel(const float* __restrict__ dreg,
+                                                              const float* __restrict__ dctr,
+                                                              const float* __restrict__ reg,
+                                                              const float* __restrict__ ctr,
+                                                              const float* __restrict__ scale, float gscale,
+                                                              float* __restrict__ dy8, float* __restrict__ partial,
+                                                              int R) {
+  const float es = expf(scale[0]);
+  float s = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R; i += gridDim.x * blockDim.x) {
+    f32x4 d = *reinterpret_cast<const f32x4*>(dreg + (size_t)i * 4) * gscale;
+    f32x4 r = *reinterpret_cast<const f32x4*>(reg + (size_t)i * 4);
+    float c = ctr[i];
+    s += d[0] * r[0] + d[1] * r[1] + d[2] * r[2] + d[3] * r[3];
+    f32x4 o0 = d * es;
+    f32x4 o1 = {dctr[i] * gscale * c * (1.f - c), 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(dy8 + (size_t)i * 8) = o0;
+    *reinterpret_cast<f32x4*>(dy8 + (size_t)i * 8 + 4) = o1;
+  }
+  __shared__ float red[4];
+  float w = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// out[idx] (+)= sum(partial[0..n))
+__global__ void sum_to_scalar_kernel(const float* __restrict__ partial, int n, float* __restrict__ out, int idx,
+                                     int accumulate) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += (double)partial[i];
+  s = wave_sum_d(s);
+  if (threadIdx.x == 0) out[idx] = accumulate ? out[idx] + (float)s : (float)s;
+}
+
 // ------------------------------------------------------------------------------------------ host
 static void fill_anchor_args(AnchorArgs& a, int nlev, const int* fw, const int* fh, const float* strides, int A) {
   a.nlev = nlev;
@@ -529,6 +732,95 @@ int sacv_retina_box_loss_fwd_bwd(int nlev, const float* const* reg_in, float* co
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, blocks, counts, weight, loss_out,
                      slot);
   SACV_CHECK_LAUNCH("loss_finalize");
+  return SACV_OK;
+}
+
+// FCOSLoss.get_batch_position_annotations: targets [B][P][8]; level tables are host arrays.
+int sacv_fcos_assign(int nlev, const int* level_off, const float* strides, const float* mi /*[nlev][2]*/,
+                     const float* points, const float* annots, float* targets, int* counts, int B, int P, int G,
+                     float center_sample_radius, int use_center_sample, void* stream) {
+  SACV_CHECK_ARG(nlev >= 1 && nlev <= MAXL, "fcos_assign: nlev");
+  SACV_CHECK_ARG(points && annots && targets && counts, "fcos_assign: null pointer");
+  SACV_CHECK_ARG(G >= 0 && G <= MAXG, "fcos_assign: at most %d annotation rows per image (got %d)", MAXG, G);
+  SACV_CHECK_ARG(level_off[nlev] == P, "fcos_assign: level offsets do not sum to P");
+  FcosLevels lv;
+  lv.nlev = nlev;
+  for (int l = 0; l < nlev; ++l) {
+    lv.off[l] = level_off[l];
+    lv.stride[l] = strides[l];
+    lv.mi_lo[l] = mi[l * 2];
+    lv.mi_hi[l] = mi[l * 2 + 1];
+  }
+  lv.off[nlev] = level_off[nlev];
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(counts, 0, 2 * sizeof(int), st) != hipSuccess) {
+    sacv_set_error("fcos_assign: memset failed");
+    return SACV_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(fcos_assign_kernel, dim3(sacv_cdiv(P, 256), B), dim3(256), 0, st, lv, points, annots, targets,
+                     counts, P, G, center_sample_radius, use_center_sample);
+  SACV_CHECK_LAUNCH("fcos_assign");
+  return SACV_OK;
+}
+
+// IoU (type 0) / GIoU (type 1) regression loss weighted by the centerness target + centerness BCE.
+// loss_out[slot_reg], loss_out[slot_ctr]; gradients w.r.t. the (scaled) regression outputs and centerness probs.
+int sacv_fcos_reg_ctr_loss_fwd_bwd(int nlev, const float* const* reg_in, const float* const* ctr_in,
+                                   float* const* dreg, float* const* dctr, const int* level_off,
+                                   const float* targets, int B, int P, int iou_type, float w_reg, float w_ctr,
+                                   const int* counts, float* workspace, float* loss_out, int slot_reg, int slot_ctr,
+                                   void* stream) {
+  SACV_CHECK_ARG(nlev >= 1 && nlev <= MAXL, "fcos_loss: nlev");
+  SACV_CHECK_ARG(iou_type == 0 || iou_type == 1, "fcos_loss: iou_type %d unsupported (0 IoU, 1 GIoU)", iou_type);
+  SACV_CHECK_ARG(level_off[nlev] == P && targets && counts && workspace && loss_out, "fcos_loss: bad args");
+  FcosPtrs fp;
+  fp.nlev = nlev;
+  for (int l = 0; l < nlev; ++l) {
+    SACV_CHECK_ARG(reg_in[l] && ctr_in[l], "fcos_loss: null level pointer");
+    fp.reg[l] = reg_in[l];
+    fp.ctr[l] = ctr_in[l];
+    fp.dreg[l] = dreg ? dreg[l] : nullptr;
+    fp.dctr[l] = dctr ? dctr[l] : nullptr;
+    fp.off[l] = level_off[l];
+  }
+  fp.off[nlev] = level_off[nlev];
+  hipStream_t st = (hipStream_t)stream;
+  size_t total = (size_t)B * P;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > FOCAL_BLOCKS / 2) blocks = FOCAL_BLOCKS / 2;
+  hipLaunchKernelGGL(fcos_reg_ctr_loss_kernel, dim3(blocks), dim3(256), 0, st, fp, targets, B, P, iou_type, w_reg,
+                     w_ctr, counts, workspace, blocks);
+  SACV_CHECK_LAUNCH("fcos_reg_ctr_loss");
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, blocks, counts, w_reg, loss_out,
+                     slot_reg);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, workspace + blocks, blocks, counts, w_ctr,
+                     loss_out, slot_ctr);
+  SACV_CHECK_LAUNCH("loss_finalize");
+  return SACV_OK;
+}
+
+int sacv_fcos_split_fwd(const float* y8, const float* scale, float* reg, float* ctr, int R, void* stream) {
+  SACV_CHECK_ARG(y8 && scale && reg && ctr && R > 0, "fcos_split_fwd: bad args");
+  int blocks = sacv_cdiv(R, 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(fcos_split_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y8, scale, reg, ctr, R);
+  SACV_CHECK_LAUNCH("fcos_split_fwd");
+  return SACV_OK;
+}
+
+// dscale[idx] (+)= sum dreg*reg; workspace >= 1024 floats
+int sacv_fcos_split_bwd(const float* dreg, const float* dctr, const float* reg, const float* ctr, const float* scale,
+                        float gscale, float* dy8, float* dscale, int idx, int accumulate, int R, float* workspace,
+                        void* stream) {
+  SACV_CHECK_ARG(dreg && dctr && reg && ctr && scale && dy8 && dscale && workspace && R > 0, "fcos_split_bwd: bad args");
+  int blocks = sacv_cdiv(R, 256);
+  if (blocks > 1024) blocks = 1024;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(fcos_split_bwd_kernel, dim3(blocks), dim3(256), 0, st, dreg, dctr, reg, ctr, scale, gscale, dy8,
+                     workspace, R);
+  SACV_CHECK_LAUNCH("fcos_split_bwd");
+  hipLaunchKernelGGL(sum_to_scalar_kernel, dim3(1), dim3(64), 0, st, workspace, blocks, dscale, idx, accumulate);
+  SACV_CHECK_LAUNCH("sum_to_scalar");
   return SACV_OK;
 }
 

@@ -9,9 +9,9 @@ import numpy as np
 import torch
 
 from .. import ops
-from .losses import AnchorCache
+from .losses import AnchorCache, PointCache
 
-__all__ = ['RetinaDecoder']
+__all__ = ['RetinaDecoder', 'FCOSDecoder']
 
 _NMS = {'python_nms': 0, 'diou_python_nms': 1}
 
@@ -42,6 +42,36 @@ class RetinaDecoder:
         return ops.decode_topk_nms(0, cls_c, reg_c, None, anchors, float(np.float32(self.min_score_threshold)),
                                    self.topn, _NMS[self.nms_type], float(np.float32(self.nms_threshold)),
                                    self.max_object_num)
+
+    def __call__(self, preds):
+        s, c, b = self.device_call(preds)
+        return [s.cpu().numpy(), c.cpu().numpy(), b.cpu().numpy()]
+
+
+class FCOSDecoder:
+    """decode.py:274-364: score = sqrt(cls * centerness), boxes = point -/+ exp(ltrb) truncated to int32."""
+
+    def __init__(self, strides=[8, 16, 32, 64, 128], max_object_num=100, min_score_threshold=0.05, topn=1000,
+                 nms_type='python_nms', nms_threshold=0.6):
+        assert nms_type in ['torch_nms', 'python_nms', 'diou_python_nms'], 'wrong nms type!'
+        if nms_type not in _NMS:
+            raise NotImplementedError('nms_type=torch_nms needs torchvision (absent); use python_nms / '
+                                      'diou_python_nms, which run as HIP kernels')
+        self.positions = PointCache(strides)
+        self.max_object_num, self.min_score_threshold, self.topn = max_object_num, min_score_threshold, topn
+        self.nms_type, self.nms_threshold = nms_type, nms_threshold
+
+    def device_call(self, preds):
+        cls_preds, reg_preds, ctr_preds = preds
+        device = cls_preds[0].device
+        if device.type != 'cuda':
+            raise RuntimeError('sacv_amd FCOSDecoder runs on MI355X only (no CPU fallback)')
+        feature_sizes = [[p.shape[2], p.shape[1]] for p in cls_preds]
+        points = self.positions.get(feature_sizes, device)
+        f = lambda lst: [p.detach().float().contiguous() for p in lst]
+        return ops.decode_topk_nms(1, f(cls_preds), f(reg_preds), f(ctr_preds), points,
+                                   float(np.float32(self.min_score_threshold)), self.topn, _NMS[self.nms_type],
+                                   float(np.float32(self.nms_threshold)), self.max_object_num)
 
     def __call__(self, preds):
         s, c, b = self.device_call(preds)

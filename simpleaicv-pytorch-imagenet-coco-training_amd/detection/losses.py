@@ -1,5 +1,5 @@
-"""RetinaLoss with the reference's constructor / call contract (simpleAICV/detection/losses.py:
-126-429), computed by fused HIP kernels: device-side anchors (anchor.py:18-86), IoU target
+"""RetinaLoss / FCOSLoss with the reference's constructor / call contract (simpleAICV/detection/losses.py:
+126-429 and 432-833), computed by fused HIP kernels: device-side anchors (anchor.py:18-86), IoU target
 assignment (:322-409), focal loss with the [1e-4, 1-1e-4] probability clamp (:196, :220-261)
 and SmoothL1 / IoU / GIoU box loss (:263-320, :411-429).  Forward and the gradient w.r.t.
 the predictions are produced by the same kernel pass; autograd only scales them.
@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from .. import ops
 
-__all__ = ['RetinaLoss']
+__all__ = ['RetinaLoss', 'FCOSLoss']
 
 _BOX_TYPES = {'SmoothL1': ops.BOX_SMOOTH_L1, 'IoU': ops.BOX_IOU, 'GIoU': ops.BOX_GIOU}
 
@@ -97,3 +97,76 @@ class RetinaLoss(nn.Module):
         else:
             cls_loss, reg_loss = values[0].clone(), values[1].clone()
         return {'cls_loss': cls_loss, 'reg_loss': reg_loss}
+
+
+class PointCache:
+    """FCOS point centres per feature-map shape, generated once on the device (anchor.py:94-130)."""
+
+    def __init__(self, strides):
+        self.strides = strides
+        self._cache = {}
+
+    def get(self, feature_sizes, device):
+        key = (tuple(map(tuple, feature_sizes)), str(device))
+        if key not in self._cache:
+            self._cache[key] = ops.fcos_points(feature_sizes, self.strides, device)
+        return self._cache[key]
+
+
+class FCOSLoss(nn.Module):
+
+    def __init__(self, strides=[8, 16, 32, 64, 128],
+                 mi=[[-1, 64], [64, 128], [128, 256], [256, 512], [512, 100000000]], alpha=0.25, gamma=2.,
+                 cls_loss_weight=1., box_loss_weight=1., center_ness_loss_weight=1., box_loss_iou_type='GIoU',
+                 center_sample_radius=1.5, use_center_sample=True):
+        super().__init__()
+        assert box_loss_iou_type in ['IoU', 'GIoU', 'DIoU', 'CIoU', 'EIoU'], 'wrong IoU type!'
+        if box_loss_iou_type not in ('IoU', 'GIoU'):
+            raise NotImplementedError(f'box_loss_iou_type={box_loss_iou_type}: the HIP kernel implements IoU and GIoU')
+        self.positions = PointCache(strides)
+        self.alpha, self.gamma = alpha, gamma
+        self.strides, self.mi = strides, mi
+        self.cls_loss_weight, self.box_loss_weight = cls_loss_weight, box_loss_weight
+        self.center_ness_loss_weight = center_ness_loss_weight
+        self.box_loss_iou_type = box_loss_iou_type
+        self.center_sample_radius, self.use_center_sample = center_sample_radius, use_center_sample
+
+    def fused(self, preds, annotations, want_grad=True):
+        """-> (loss_values f32[3] = cls, reg, center_ness; counts; dcls, dreg, dctr).  No host sync."""
+        cls_preds, reg_preds, ctr_preds = preds
+        device = annotations.device
+        if device.type != 'cuda':
+            raise RuntimeError('sacv_amd FCOSLoss runs on MI355X only (no CPU fallback)')
+        feature_sizes = [[p.shape[2], p.shape[1]] for p in cls_preds]
+        points = self.positions.get(feature_sizes, device)
+        level_off = [0]
+        for w, h in feature_sizes:
+            level_off.append(level_off[-1] + w * h)
+        annotations = annotations.float().contiguous()
+        targets, counts = ops.fcos_assign(points, level_off, self.strides, self.mi, annotations,
+                                          float(self.center_sample_radius), self.use_center_sample)
+        values = torch.empty(3, device=device, dtype=torch.float32)
+        cls_c = [p if p.is_contiguous() else p.contiguous() for p in cls_preds]
+        reg_c = [p if p.is_contiguous() else p.contiguous() for p in reg_preds]
+        ctr_c = [p if p.is_contiguous() else p.contiguous() for p in ctr_preds]
+        dcls = ops.focal_loss(cls_c, targets, counts, self.alpha, float(self.gamma), self.cls_loss_weight, values, 0,
+                              want_grad=want_grad, tstride=8)
+        dreg, dctr = ops.fcos_reg_ctr_loss(reg_c, ctr_c, targets, counts, 0 if self.box_loss_iou_type == 'IoU' else 1,
+                                           self.box_loss_weight, self.center_ness_loss_weight, values, 1, 2,
+                                           want_grad=want_grad)
+        return values, counts, dcls, dreg, dctr
+
+    def forward(self, preds, annotations):
+        cls_preds, reg_preds, ctr_preds = preds
+        allp = list(cls_preds) + list(reg_preds) + list(ctr_preds)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in allp)
+        values, counts, dcls, dreg, dctr = self.fused(preds, annotations, want_grad=need_grad)
+        if int(counts[0].item()) == 0:  # reference: plain zeros without grad_fn (losses.py:523-524 etc.)
+            zero = torch.tensor(0.).to(annotations.device)
+            return {'cls_loss': self.cls_loss_weight * zero, 'reg_loss': self.box_loss_weight * zero.clone(),
+                    'center_ness_loss': self.center_ness_loss_weight * zero.clone()}
+        if need_grad:
+            return {'cls_loss': _ScaledGrad.apply(values[0], dcls, *cls_preds),
+                    'reg_loss': _ScaledGrad.apply(values[1], dreg, *reg_preds),
+                    'center_ness_loss': _ScaledGrad.apply(values[2], dctr, *ctr_preds)}
+        return {'cls_loss': values[0].clone(), 'reg_loss': values[1].clone(), 'center_ness_loss': values[2].clone()}

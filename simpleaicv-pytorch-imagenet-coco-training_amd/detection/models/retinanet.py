@@ -2,112 +2,16 @@
 (simpleAICV/detection/models/retinanet.py:30-120, backbones/resnet.py:27-113, fpn.py:14-58,
 head.py:15-85), executed by the HIP engine instead of torch.nn layers.
 
-The torch.nn modules below are parameter CONTAINERS only (they give the reference key names,
-`.cuda()`, DDP and checkpoint compatibility); their forward is never called.  The model
-fails loudly on CPU tensors: there is no non-HIP execution path.
+The torch.nn modules are parameter CONTAINERS only (they give the reference key names, `.cuda()`, DDP and
+checkpoint compatibility); their forward is never called.  The model fails loudly on CPU tensors: there is
+no non-HIP execution path.
 """
-import math
-
-import torch
-import torch.nn as nn
-
-from ...engine import DetectorEngine, RESNET50_LAYERS
-from ._arena import ParamArena
+from ._base import HipDetector, _resnet50_backbone, _fpn, _head
 
 __all__ = ['resnet50_retinanet', 'RetinaNet']
 
 
-def _conv_bn_act(cin, cout, k, stride, pad, act=True):
-    """Container with the key layout of ConvBnActBlock: layer.0 = conv (no bias), layer.1 = BN."""
-    blk = nn.Module()
-    blk.layer = nn.Sequential(nn.Conv2d(cin, cout, k, stride=stride, padding=pad, bias=False),
-                              nn.BatchNorm2d(cout), nn.ReLU(inplace=True) if act else nn.Sequential())
-    return blk
-
-
-def _bottleneck(cin, planes, stride):
-    blk = nn.Module()
-    blk.conv1 = _conv_bn_act(cin, planes, 1, 1, 0)
-    blk.conv2 = _conv_bn_act(planes, planes, 3, stride, 1)
-    blk.conv3 = _conv_bn_act(planes, planes * 4, 1, 1, 0, act=False)
-    if stride != 1 or cin != planes * 4:
-        blk.downsample_conv = _conv_bn_act(cin, planes * 4, 1, stride, 0, act=False)
-    return blk
-
-
-def _resnet50_backbone():
-    bb = nn.Module()
-    bb.conv1 = _conv_bn_act(3, 64, 7, 2, 3)
-    cin = 64
-    for li, (n, planes) in enumerate(zip(RESNET50_LAYERS, (64, 128, 256, 512)), start=1):
-        blocks = []
-        for bi in range(n):
-            blocks.append(_bottleneck(cin, planes, 2 if (bi == 0 and li > 1) else 1))
-            cin = planes * 4
-        setattr(bb, f'layer{li}', nn.Sequential(*blocks))
-    for m in bb.modules():  # backbones/resnet.py:76-83
-        if isinstance(m, nn.Conv2d):
-            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
-        elif isinstance(m, nn.BatchNorm2d):
-            nn.init.constant_(m.weight, 1)
-            nn.init.constant_(m.bias, 0)
-    bb.out_channels = [256, 512, 1024, 2048]
-    return bb
-
-
-def _fpn(inplanes, planes, use_p5):
-    f = nn.Module()
-    f.P3_1 = nn.Conv2d(inplanes[0], planes, 1)
-    f.P3_2 = nn.Conv2d(planes, planes, 3, padding=1)
-    f.P4_1 = nn.Conv2d(inplanes[1], planes, 1)
-    f.P4_2 = nn.Conv2d(planes, planes, 3, padding=1)
-    f.P5_1 = nn.Conv2d(inplanes[2], planes, 1)
-    f.P5_2 = nn.Conv2d(planes, planes, 3, padding=1)
-    f.P6 = nn.Conv2d(planes if use_p5 else inplanes[2], planes, 3, stride=2, padding=1)
-    f.P7 = nn.Sequential(nn.ReLU(), nn.Conv2d(planes, planes, 3, stride=2, padding=1))
-    return f
-
-
-def _head(planes, n_out, tower_name, out_name, cls_prior=None):
-    h = nn.Module()
-    layers = []
-    for _ in range(4):
-        layers += [nn.Conv2d(planes, planes, 3, padding=1), nn.ReLU(inplace=True)]
-    setattr(h, tower_name, nn.Sequential(*layers))
-    setattr(h, out_name, nn.Conv2d(planes, n_out, 3, padding=1))
-    for m in h.modules():  # head.py:36-44
-        if isinstance(m, nn.Conv2d):
-            nn.init.normal_(m.weight, std=0.01)
-            nn.init.constant_(m.bias, 0)
-    if cls_prior is not None:
-        getattr(h, out_name).bias.data.fill_(-math.log((1 - cls_prior) / cls_prior))
-    return h
-
-
-class _DetectorFunction(torch.autograd.Function):
-    """autograd boundary of the whole detector: one node, gradients come from engine.backward."""
-
-    @staticmethod
-    def forward(ctx, model, images, *params):
-        cls, reg = model._engine.forward(images, training=model.training, keep=True)
-        ctx.model = model
-        ctx.n_levels = len(cls)
-        ctx.mark_non_differentiable()
-        return tuple(cls) + tuple(reg)
-
-    @staticmethod
-    def backward(ctx, *grads):
-        model = ctx.model
-        n = ctx.n_levels
-        outs = model._last_outputs
-        gs = [g if g is not None else torch.zeros_like(o) for g, o in zip(grads, outs)]
-        gs = [g.contiguous() for g in gs]
-        model._engine.backward(gs[:n], gs[n:])
-        arena = model._arena
-        return (None, None) + tuple(arena.grad_views[name] for name, _ in model._param_list)
-
-
-class RetinaNet(nn.Module):
+class RetinaNet(HipDetector):
 
     def __init__(self, backbone_type='resnet50backbone', backbone_pretrained_path='', planes=256, num_anchors=9,
                  num_classes=80, use_gradient_checkpoint=False):
@@ -126,61 +30,7 @@ class RetinaNet(nn.Module):
             self._load_backbone(backbone_pretrained_path)
         else:
             print('no backbone pretrained model!')
-        self._arena = None
-        self._engine = None
-        self._param_list = None
-        self._last_outputs = None
-
-    def _load_backbone(self, path):
-        """Name-and-shape matched warm start (simpleAICV/classification/common.py:758-784)."""
-        saved = torch.load(path, map_location='cpu', weights_only=True)
-        own = self.backbone.state_dict()
-        keep = {k: v for k, v in saved.items() if k in own and v.shape == own[k].shape}
-        own.update(keep)
-        self.backbone.load_state_dict(own)
-
-    # ------------------------------------------------------------------ engine plumbing
-    def prepare(self):
-        """(Re)build the flat arenas and the executor; called lazily by forward."""
-        dev = next(self.parameters()).device
-        if dev.type != 'cuda':
-            raise RuntimeError('sacv_amd RetinaNet runs on MI355X only: move the model to the GPU (.cuda()); '
-                               'there is no CPU/PyTorch fallback path')
-        self._arena = ParamArena(self)
-        self._param_list = list(self._arena.order)
-        tensors = {n: p.data for n, p in self.named_parameters()}
-        tensors.update({n: b for n, b in self.named_buffers()})
-        self._engine = DetectorEngine(tensors, self._arena.grad_views, self.num_classes, self.num_anchors,
-                                      self.planes, fcos=False)
-        return self
-
-    def _ready(self):
-        if self._arena is None or not self._arena.is_current():
-            self.prepare()
-
-    @property
-    def arena(self):
-        self._ready()
-        return self._arena
-
-    @property
-    def engine(self):
-        self._ready()
-        return self._engine
-
-    def forward(self, inputs):
-        if inputs.device.type != 'cuda':
-            raise RuntimeError('sacv_amd RetinaNet runs on MI355X only: inputs must be on the GPU (no CPU fallback)')
-        self._ready()
-        inputs = inputs.float()
-        if torch.is_grad_enabled() and self.training:
-            params = [p for _, p in self._param_list]
-            outs = _DetectorFunction.apply(self, inputs, *params)
-            self._last_outputs = outs
-            n = len(outs) // 2
-            return [list(outs[:n]), list(outs[n:])]
-        cls, reg = self._engine.forward(inputs, training=self.training, keep=False)
-        return [cls, reg]
+        self._init_runtime()
 
 
 def resnet50_retinanet(backbone_pretrained_path='', **kwargs):

@@ -40,8 +40,6 @@ class DetectorEngine:
     def __init__(self, p, g, num_classes=80, num_anchors=9, planes=256, fcos=False):
         self.p, self.g = p, g
         self.num_classes, self.num_anchors, self.planes, self.fcos = num_classes, num_anchors, planes, fcos
-        if fcos:
-            raise NotImplementedError('FCOS execution is not built yet (next SURVEY.md 8 row)')
         self.ctx = None
 
     # ------------------------------------------------------------------ building blocks
@@ -171,11 +169,11 @@ class DetectorEngine:
             feats.append(x)
         c3f, c4f, c5f = feats[1], feats[2], feats[3]
         fpn = self._fpn_fwd(c3f, c4f, c5f, ctx)
-        cls_levels, reg_levels = self._heads_fwd(fpn, ctx)
+        outs = self._fcos_heads_fwd(fpn, ctx) if self.fcos else self._heads_fwd(fpn, ctx)
         if keep:
             ctx['blocks'] = blocks
             self.ctx = ctx
-        return cls_levels, reg_levels
+        return outs
 
     def _bottleneck_fwd(self, x, pre, stride, training, keep=True):
         """Bottleneck.forward (classification/backbones/resnet.py:141-155): 1x1 -> 3x3(stride) -> 1x1,
@@ -206,11 +204,11 @@ class DetectorEngine:
         p5o = self._conv_bias(p5, 'fpn.P5_2', 3, 1, 1)
         p4o = self._conv_bias(p4, 'fpn.P4_2', 3, 1, 1)
         p3o = self._conv_bias(p3, 'fpn.P3_2', 3, 1, 1)
-        p6 = self._conv_bias(c5, 'fpn.P6', 3, 2, 1)
+        p6 = self._conv_bias(p5o if self.fcos else c5, 'fpn.P6', 3, 2, 1)  # use_p5 (fpn.py:80)
         p6r = ops.eltwise(ops.EW_RELU, p6)
         p7 = self._conv_bias(p6r, 'fpn.P7.1', 3, 2, 1)
         if ctx is not None:
-            ctx['fpn'] = dict(c3=c3, c4=c4, c5=c5, p5=p5, p4=p4, p3=p3, p6=p6, p6r=p6r)
+            ctx['fpn'] = dict(c3=c3, c4=c4, c5=c5, p5=p5, p4=p4, p3=p3, p6=p6, p6r=p6r, p5o=p5o)
         return [p3o, p4o, p5o, p6, p7]
 
     def _tower_fwd(self, feats, tower, out_name, n_out, out_flags, ctx):
@@ -240,6 +238,106 @@ class DetectorEngine:
         cls_levels = [t.view(t.shape[0], t.shape[1], t.shape[2], a, nc) for t in cls]
         reg_levels = [t.view(t.shape[0], t.shape[1], t.shape[2], a, 4) for t in reg]
         return cls_levels, reg_levels
+
+    # ------------------------------------------------------------------ FCOS heads
+    # FCOSClsRegCntHead (head.py:88-181): two towers of 4 x (3x3 conv no bias, GroupNorm(32), ReLU) shared by
+    # the 5 levels; cls_out (sigmoid) on the cls tower; reg_out and center_out on the reg tower are run as ONE
+    # 8-channel conv (4 + 1 + 3 zero rows) and split; FCOS.forward scales reg by exp(scales[l]) (fcos.py:76).
+    def _gn_tower_fwd(self, feats, tower, ctx):
+        p = self.p
+        xs = feats
+        hw = [(f.shape[1], f.shape[2]) for f in feats]
+        saved = []
+        for i in (0, 3, 6, 9):
+            w = p[f'{tower}.{i}.weight']
+            ys = ops.conv_gemm(xs, ops.pack_weight(w, PACK_FWD), self.planes, 3, 3, 1, 1, 0, hw)
+            zs, sts = [], []
+            for y in ys:
+                z, st = ops.groupnorm_fwd(y, p[f'{tower}.{i + 1}.weight'], p[f'{tower}.{i + 1}.bias'], 32, 1e-5, True)
+                zs.append(z)
+                sts.append(st)
+            saved.append((xs, ys, sts, zs))
+            xs = zs
+        if ctx is not None:
+            ctx[tower] = saved
+        return xs
+
+    def _fcos_w8(self):
+        p = self.p
+        w8 = torch.zeros((8, self.planes, 3, 3), device=p['scales'].device, dtype=torch.float32)
+        b8 = torch.zeros(8, device=w8.device, dtype=torch.float32)
+        w8[0:4].copy_(p['clsregcnt_head.reg_out.weight'])
+        w8[4:5].copy_(p['clsregcnt_head.center_out.weight'])
+        b8[0:4].copy_(p['clsregcnt_head.reg_out.bias'])
+        b8[4:5].copy_(p['clsregcnt_head.center_out.bias'])
+        return w8, b8
+
+    def _fcos_heads_fwd(self, feats, ctx):
+        p = self.p
+        hw = [(f.shape[1], f.shape[2]) for f in feats]
+        cls_x = self._gn_tower_fwd(feats, 'clsregcnt_head.cls_head', ctx)
+        reg_x = self._gn_tower_fwd(feats, 'clsregcnt_head.reg_head', ctx)
+        w = p['clsregcnt_head.cls_out.weight']
+        cls = ops.conv_gemm(cls_x, ops.pack_weight(w, PACK_FWD), w.shape[0], 3, 3, 1, 1, 0, hw,
+                            bias=p['clsregcnt_head.cls_out.bias'], flags=CF_SIGMOID)
+        w8, b8 = self._fcos_w8()
+        y8 = ops.conv_gemm(reg_x, ops.pack_weight(w8, PACK_FWD), 8, 3, 3, 1, 1, 0, hw, bias=b8)
+        regs, ctrs = [], []
+        for l, y in enumerate(y8):
+            r, c = ops.fcos_split_fwd(y, p['scales'][l:l + 1])
+            regs.append(r)
+            ctrs.append(c)
+        if ctx is not None:
+            ctx['fcos_out'] = dict(cls=cls, reg=regs, ctr=ctrs, cls_x=cls_x, reg_x=reg_x, w8=w8)
+        return cls, regs, ctrs
+
+    def _gn_tower_bwd(self, dzs, tower, accum_into=None):
+        """dzs: per-level grads w.r.t. the tower output (after the last GN + ReLU)."""
+        p, g = self.p, self.g
+        saved = self.ctx[tower]
+        cur = dzs
+        for li, i in reversed(list(enumerate((0, 3, 6, 9)))):
+            xs, ys, sts, zs = saved[li]
+            gname, bname = f'{tower}.{i + 1}.weight', f'{tower}.{i + 1}.bias'
+            dys = [ops.groupnorm_bwd(y, dz, z, st, p[gname], g[gname], g[bname], 32, accumulate=l > 0)
+                   for l, (y, dz, z, st) in enumerate(zip(ys, cur, zs, sts))]
+            w = p[f'{tower}.{i}.weight']
+            ops.conv_wgrad(dys, xs, g[f'{tower}.{i}.weight'], w.shape[1], 3, 3, 1, 1)
+            hw = [(x.shape[1], x.shape[2]) for x in xs]
+            wd = ops.pack_weight(w, PACK_DGRAD)
+            if li == 0 and accum_into is not None:
+                cur = ops.conv_gemm(dys, wd, w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_ACCUM, outs=accum_into)
+            else:
+                cur = ops.conv_gemm(dys, wd, w.shape[1], 3, 3, 1, 1, 1, hw)
+        return cur
+
+    def _fcos_heads_bwd(self, dcls_levels, dreg_levels, dctr_levels, grad_scale):
+        p, g = self.p, self.g
+        o = self.ctx['fcos_out']
+        hw = [(x.shape[1], x.shape[2]) for x in o['cls_x']]
+        # classification branch
+        dz_cls = [ops.eltwise(ops.EW_SCALE_SIGMOID_BWD, d.reshape(pr.shape), pr, scalar=grad_scale)
+                  for d, pr in zip(dcls_levels, o['cls'])]
+        w = p['clsregcnt_head.cls_out.weight']
+        ops.conv_wgrad(dz_cls, o['cls_x'], g['clsregcnt_head.cls_out.weight'], w.shape[1], 3, 3, 1, 1)
+        self._bias_grad(dz_cls, 'clsregcnt_head.cls_out')
+        d_cls_x = ops.conv_gemm(dz_cls, ops.pack_weight(w, PACK_DGRAD), w.shape[1], 3, 3, 1, 1, 1, hw)
+        dfeat = self._gn_tower_bwd(d_cls_x, 'clsregcnt_head.cls_head')
+        # regression + centerness branch (8-channel combined output conv)
+        dy8 = [ops.fcos_split_bwd(dr.contiguous(), dc.contiguous(), r, c, p['scales'][l:l + 1], g['scales'], l,
+                                  gscale=grad_scale)
+               for l, (dr, dc, r, c) in enumerate(zip(dreg_levels, dctr_levels, o['reg'], o['ctr']))]
+        dw8 = torch.empty_like(o['w8'])
+        ops.conv_wgrad(dy8, o['reg_x'], dw8, self.planes, 3, 3, 1, 1)
+        g['clsregcnt_head.reg_out.weight'].copy_(dw8[0:4])
+        g['clsregcnt_head.center_out.weight'].copy_(dw8[4:5])
+        db8 = torch.empty(8, device=dw8.device, dtype=torch.float32)
+        for l, d in enumerate(dy8):
+            ops.colsum(d, 8, db8, accumulate=l > 0)
+        g['clsregcnt_head.reg_out.bias'].copy_(db8[0:4])
+        g['clsregcnt_head.center_out.bias'].copy_(db8[4:5])
+        d_reg_x = ops.conv_gemm(dy8, ops.pack_weight(o['w8'], PACK_DGRAD), self.planes, 3, 3, 1, 1, 1, hw)
+        return self._gn_tower_bwd(d_reg_x, 'clsregcnt_head.reg_head', accum_into=dfeat)
 
     # ------------------------------------------------------------------ backward
     def _bias_grad(self, dys, name):
@@ -286,12 +384,16 @@ class DetectorEngine:
             return self._dgrad(dy, w, x.shape, k, stride, pad, out=out, accumulate=accumulate, mask=mask)
         return None
 
-    def backward(self, dcls_levels, dreg_levels, grad_scale=1.0, on_stage=None):
+    def backward(self, dcls_levels, dreg_levels, dctr_levels=None, grad_scale=1.0, on_stage=None):
         """dcls: grads w.r.t. the class PROBABILITIES, dreg: w.r.t. the box regressions (per level,
-        same shapes as the forward outputs).  Fills every entry of self.g (overwrite semantics)."""
+        same shapes as the forward outputs), dctr (FCOS): w.r.t. the centerness probabilities.
+        Fills every entry of self.g (overwrite semantics)."""
         ctx = self.ctx
         if ctx is None:
             raise RuntimeError('backward() without a preceding forward(keep=True)')
+        if self.fcos:
+            dfeat = self._fcos_heads_bwd(dcls_levels, dreg_levels, dctr_levels, grad_scale)
+            return self._trunk_bwd(dfeat, on_stage)
         a, nc = self.num_anchors, self.num_classes
         probs = ctx['cls_probs']
         # sigmoid backward (and the upstream scalar) fused in one pass per level
@@ -306,6 +408,10 @@ class DetectorEngine:
             dz_reg = [d.reshape(d.shape[0], d.shape[1], d.shape[2], a * 4) for d in dreg_levels]
         dfeat = self._tower_bwd(dz_cls, 'cls_head.cls_head', 'cls_head.cls_out')
         dfeat = self._tower_bwd(dz_reg, 'reg_head.reg_head', 'reg_head.reg_out', accum_into=dfeat)
+        self._trunk_bwd(dfeat, on_stage)
+
+    def _trunk_bwd(self, dfeat, on_stage):
+        ctx = self.ctx
         if on_stage:
             on_stage('heads')  # head gradients are final: their all-reduce can start now
         dc3, dc4, dc5 = self._fpn_bwd(dfeat)
@@ -354,7 +460,11 @@ class DetectorEngine:
         # P7 = conv(relu(P6)); P6 also feeds the heads directly
         t = self._conv_bias_bwd(dp7, f['p6r'], 'fpn.P7.1', 3, 2, 1, mask=f['p6'])
         dp6 = ops.eltwise(ops.EW_ADD, dp6, t, out=dp6)
-        dc5 = self._conv_bias_bwd(dp6, f['c5'], 'fpn.P6', 3, 2, 1)
+        if self.fcos:  # P6 = conv(P5 smoothed): its data gradient joins dP5o
+            self._conv_bias_bwd(dp6, f['p5o'], 'fpn.P6', 3, 2, 1, out=dp5o, accumulate=True)
+            dc5 = None
+        else:
+            dc5 = self._conv_bias_bwd(dp6, f['c5'], 'fpn.P6', 3, 2, 1)
         dp5 = self._conv_bias_bwd(dp5o, f['p5'], 'fpn.P5_2', 3, 1, 1)
         dp4 = self._conv_bias_bwd(dp4o, f['p4'], 'fpn.P4_2', 3, 1, 1)
         dp3 = self._conv_bias_bwd(dp3o, f['p3'], 'fpn.P3_2', 3, 1, 1)
@@ -364,5 +474,8 @@ class DetectorEngine:
         # P4 = up(P5) + P4_1(C4)
         ops.upsample_bwd(dp4, dp5, accumulate=True)
         dc4 = self._conv_bias_bwd(dp4, f['c4'], 'fpn.P4_1', 1, 1, 0)
-        self._conv_bias_bwd(dp5, f['c5'], 'fpn.P5_1', 1, 1, 0, out=dc5, accumulate=True)
+        if dc5 is None:
+            dc5 = self._conv_bias_bwd(dp5, f['c5'], 'fpn.P5_1', 1, 1, 0)
+        else:
+            self._conv_bias_bwd(dp5, f['c5'], 'fpn.P5_1', 1, 1, 0, out=dc5, accumulate=True)
         return dc3, dc4, dc5

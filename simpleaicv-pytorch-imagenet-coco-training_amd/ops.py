@@ -242,6 +242,27 @@ def bn_train_bwd(dz, zmask, y, mean, invstd, gamma, dgamma, dbeta, want_g=False,
     return dy, g
 
 
+def groupnorm_fwd(x, gamma, beta, groups=32, eps=1e-5, relu=True):
+    """x: [N,H,W,C] -> (z, stats[N,G,2])."""
+    n, h, w, c = x.shape
+    z = torch.empty_like(x)
+    stats = torch.empty((n, groups, 2), device=x.device, dtype=torch.float32)
+    ws = workspace(lib.sacv_gn_workspace_floats(n, h * w, c) * 4, x.device, 'gn')
+    check(lib.sacv_groupnorm_fwd(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(z), _ptr(stats), n, h * w, c, groups, eps,
+                                 int(relu), ws.data_ptr(), _stream()), 'groupnorm_fwd')
+    return z, stats
+
+
+def groupnorm_bwd(x, dz, zmask, stats, gamma, dgamma, dbeta, groups=32, accumulate=False):
+    n, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    ws = workspace(lib.sacv_gn_workspace_floats(n, h * w, c) * 4, x.device, 'gn')
+    check(lib.sacv_groupnorm_bwd(_ptr(x), _ptr(dz), _ptr(zmask), _ptr(stats), _ptr(gamma), _ptr(dx), _ptr(dgamma),
+                                 _ptr(dbeta), n, h * w, c, groups, int(accumulate), ws.data_ptr(), _stream()),
+          'groupnorm_bwd')
+    return dx
+
+
 # ------------------------------------------------------------------------------------------ pointwise
 def maxpool_fwd(x, k=3, s=2, p=1, want_idx=True):
     n, h, w, c = x.shape
@@ -333,6 +354,57 @@ def retina_assign(anchors, annots, smooth_l1=True):
     check(lib.sacv_retina_assign(_ptr(anchors), _ptr(annots), _ptr(targets), _ptr(counts), b, a, g, int(smooth_l1),
                                  _stream()), 'retina_assign')
     return targets, counts
+
+
+def fcos_assign(points, level_off, strides, mi, annots, radius=1.5, use_center_sample=True):
+    """-> (targets [B,P,8], counts int32[2])."""
+    _chk(points, 'points')
+    _chk(annots, 'annotations')
+    b, g, _ = annots.shape
+    p = points.shape[0]
+    targets = torch.empty((b, p, 8), device=points.device, dtype=torch.float32)
+    counts = torch.empty(2, device=points.device, dtype=torch.int32)
+    flat_mi = [float(v) for pair in mi for v in pair]
+    check(lib.sacv_fcos_assign(len(strides), iarr(level_off), farr(strides), farr(flat_mi), _ptr(points),
+                               _ptr(annots), _ptr(targets), _ptr(counts), b, p, g, radius, int(use_center_sample),
+                               _stream()), 'fcos_assign')
+    return targets, counts
+
+
+def fcos_reg_ctr_loss(reg_levels, ctr_levels, targets, counts, iou_type, w_reg, w_ctr, loss_out, slot_reg, slot_ctr,
+                      want_grad=True):
+    b = reg_levels[0].shape[0]
+    off = _level_off(reg_levels, 4)
+    dreg = [torch.empty_like(t) for t in reg_levels] if want_grad else None
+    dctr = [torch.empty_like(t) for t in ctr_levels] if want_grad else None
+    ws = workspace(lib.sacv_loss_workspace_floats() * 4, targets.device, 'loss')
+    check(lib.sacv_fcos_reg_ctr_loss_fwd_bwd(
+        len(reg_levels), parr([_chk(t, 'reg').data_ptr() for t in reg_levels]),
+        parr([_chk(t, 'ctr').data_ptr() for t in ctr_levels]),
+        parr([g.data_ptr() for g in dreg]) if dreg else None, parr([g.data_ptr() for g in dctr]) if dctr else None,
+        iarr(off), _ptr(targets), b, off[-1], iou_type, w_reg, w_ctr, _ptr(counts), ws.data_ptr(), _ptr(loss_out),
+        slot_reg, slot_ctr, _stream()), 'fcos_reg_ctr_loss')
+    return dreg, dctr
+
+
+def fcos_split_fwd(y8, scale_elem):
+    """y8 [B,h,w,8] -> (reg [B,h,w,4] = raw*exp(scale), ctr [B,h,w,1] = sigmoid)."""
+    b, h, w, _ = y8.shape
+    reg = torch.empty((b, h, w, 4), device=y8.device, dtype=torch.float32)
+    ctr = torch.empty((b, h, w, 1), device=y8.device, dtype=torch.float32)
+    check(lib.sacv_fcos_split_fwd(_ptr(y8), _ptr(scale_elem), _ptr(reg), _ptr(ctr), b * h * w, _stream()),
+          'fcos_split_fwd')
+    return reg, ctr
+
+
+def fcos_split_bwd(dreg, dctr, reg, ctr, scale_elem, dscale, idx, gscale=1.0, accumulate=False):
+    b, h, w, _ = reg.shape
+    dy8 = torch.empty((b, h, w, 8), device=reg.device, dtype=torch.float32)
+    ws = workspace(4096, reg.device, 'split')
+    check(lib.sacv_fcos_split_bwd(_ptr(dreg), _ptr(dctr), _ptr(reg), _ptr(ctr), _ptr(scale_elem), gscale, _ptr(dy8),
+                                  _ptr(dscale), idx, int(accumulate), b * h * w, ws.data_ptr(), _stream()),
+          'fcos_split_bwd')
+    return dy8
 
 
 def _level_off(levels, per_row):

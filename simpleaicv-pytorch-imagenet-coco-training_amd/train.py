@@ -42,20 +42,24 @@ class DetectionTrainer:
         engine, arena = model.engine, model.arena
         if self.world > 1:
             broadcast_buffers(arena.buffers, self.group)
-        cls, reg = engine.forward(images, training=True, keep=True)
-        values, counts, dcls, dreg = crit.fused([cls, reg], annots, want_grad=True)
-        engine.backward(dcls, dreg, grad_scale=1.0 / self.accumulation_steps, on_stage=self.exchanger.stage_done)
+        outs = engine.forward(images, training=True, keep=True)
+        fused = crit.fused(list(outs), annots, want_grad=True)
+        values, counts, grads = fused[0], fused[1], fused[2:]
+        engine.backward(*grads, grad_scale=1.0 / self.accumulation_steps, on_stage=self.exchanger.stage_done)
         self.exchanger.wait()
         self.step_count += 1
         ops.adamw_step(arena.params, arena.grads, self.exp_avg, self.exp_avg_sq, arena.split, self.lr,
                        self.betas[0], self.betas[1], self.eps, 0.0, self.weight_decay, self.step_count,
                        grad_scale=1.0 / self.world)
-        return {'cls_loss': values[0], 'reg_loss': values[1]}
+        names = ('cls_loss', 'reg_loss', 'center_ness_loss')[:values.numel()]
+        return {k: values[i] for i, k in enumerate(names)}
 
     def finish_step(self, loss_dict):
         """Loss terms averaged over ranks as python floats (the caller's logging values): one tiny
         all-reduce and ONE host synchronisation."""
-        v = torch.stack([loss_dict['cls_loss'], loss_dict['reg_loss']]).float()
-        v = vote_and_reduce_scalars(v, self.group) / self.world
-        c, r = v.tolist()
-        return {'cls_loss': c, 'reg_loss': r, 'loss': c + r}
+        keys = list(loss_dict)
+        v = torch.stack([loss_dict[k] for k in keys]).float()
+        v = (vote_and_reduce_scalars(v, self.group) / self.world).tolist()
+        out = dict(zip(keys, v))
+        out['loss'] = sum(v)
+        return out

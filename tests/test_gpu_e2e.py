@@ -84,7 +84,7 @@ def test_forward_loss_backward_vs_oracle(tag, blt, channels_last):
     sdg = net.state_dict()
     for k in ('backbone.conv1.layer.1.running_mean', 'backbone.layer3.5.conv3.layer.1.running_var',
               'backbone.layer4.2.conv3.layer.1.running_mean'):
-        np.testing.assert_allclose(sdg[k].cpu().numpy(), state_r[k].numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(sdg[k].cpu().numpy(), state_r[k].numpy(), rtol=1e-4, atol=5e-6)
     assert int(sdg['backbone.conv1.layer.1.num_batches_tracked']) == 1
 
 

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libsacv_hip.so')
+LIB_PATH = os.environ.get('SACV_HIP_LIB') or os.path.join(_HERE, 'lib', 'libsacv_hip.so')  # override: tuning builds
 
 P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 

@@ -73,12 +73,16 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} needs one process per GPU: launch with torch.distributed.run '
                          f'--nproc-per-node {args.gpus} (WORLD_SIZE={world})')
-    torch.cuda.set_device(local_rank)
+    # SACV_DIST_BACKEND=gloo + SACV_SHARE_GPU=1: rehearsal of the multi-rank path on a one-GPU box (all ranks on
+    # cuda:0, collectives through the host).  The real run uses RCCL ("nccl") with one GPU per rank.
+    backend = os.environ.get('SACV_DIST_BACKEND', 'nccl')
+    dev_index = 0 if os.environ.get('SACV_SHARE_GPU') else local_rank
+    torch.cuda.set_device(dev_index)
     group = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', init_method='env://', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
+        kw = dict(device_id=torch.device('cuda', dev_index)) if backend == 'nccl' else {}
+        dist.init_process_group(backend, init_method='env://', rank=rank, world_size=world, **kw)
         group = dist.group.WORLD
 
     from oracle import synth  # input generator only (numpy); the oracle model is used by cpu_baseline alone

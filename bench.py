@@ -146,9 +146,15 @@ def main():
             per_launch_flops = k['flops'] / k['launches']
             per_launch_ms = k['ms'] / k['launches']
             achieved = per_launch_flops / (per_launch_ms * 1e-3) / 1e12
+            # HBM traffic per launch of the same kernel family from the PMC passes committed under profiles/
+            # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read-doubling applied there)
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+            if os.path.exists(tpath):
+                traffic = round(json.load(open(tpath))['hbm_bytes_per_launch'])
             roofline = dict(kernel='conv_nt_kernel<128,{128|64},mode> (implicit-GEMM conv forward + data gradient, fp32 MFMA 32x32x2)',
                             bound='mfma', achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                            frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                            frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
                             launches_per_step=k['launches'] // args.steps,
                             avg_launch_ms=round(per_launch_ms, 4), algorithmic_gflop_per_launch=round(
                                 per_launch_flops / 1e9, 2),

@@ -158,11 +158,13 @@ __device__ __forceinline__ void vec_epilogue(const ConvArgs& a, const TileCoord&
   }
 }
 
-template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
+template <int BM, int BN, int MODE, int WN>
+__global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a) {
   constexpr int LS = 36;
-  constexpr int RA = BM / 32, RB = BN / 32;
-  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int NT = 128 * WN;                 // 2 x WN waves
+  constexpr int RPP = NT / 8;                  // tile rows fetched per pass (8 threads x 16 B per row)
+  constexpr int RA = BM / RPP, RB = BN / RPP;
+  constexpr int WTM = BM / 2, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
     n0 = tc.n0;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      int m = tc.m0 + r0 + 32 * i;
+      int m = tc.m0 + r0 + RPP * i;
       if (m < P.M) {
         int hw = P.Hd * P.Wd;
         int n = m / hw;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      int n = n0 + r0 + 32 * i;
+      int n = n0 + r0 + RPP * i;
       wok[i] = n < a.N;
       wrow[i] = n * a.K + kq * 4;
     }
@@ -311,14 +313,14 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
     float* dA = sA + buf * BM * LS;
     float* dB = sB + buf * BN * LS;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(dA + (r0 + 32 * i) * LS + kq * 4) = ra[i];
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(dA + (r0 + RPP * i) * LS + kq * 4) = ra[i];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(dB + (r0 + 32 * i) * LS + kq * 4) = rb[i];
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(dB + (r0 + RPP * i) * LS + kq * 4) = rb[i];
   };
 
   f32x16 acc[TM][TN];
-  const int wm0 = (wid >> 1) * WTM;
-  const int wn0 = (wid & 1) * WTN;
+  const int wm0 = (wid / WN) * WTM;
+  const int wn0 = (wid % WN) * WTN;
   const int l31 = lane & 31;
   const int lh = lane >> 5;
 
@@ -411,14 +413,14 @@ __global__ __launch_bounds__(256, 2) void conv_nt_kernel(const ConvArgs a) {
       __syncthreads();
       if (my_slot < 0) {
         const int ntn = (a.N + BN - 1) / BN;
-        vec_epilogue<BM, BN, 256>(
+        vec_epilogue<BM, BN, NT>(
             a, my_tc, my_tile / ntn,
             [&](int row, int c4) { return *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4); },
             smem + BM * CS);
       } else {
         // K-slice of a split tile: row-major slab for the fix-up kernel
         float* dst = a.partial + (size_t)my_slot * (BM * BN);
-        constexpr int CG = BN / 4, RS = 256 / CG;
+        constexpr int CG = BN / 4, RS = NT / CG;
         const int c4 = tid % CG, rr = tid / CG;
 #pragma unroll 4
         for (int row = rr; row < BM; row += RS)
@@ -809,6 +811,9 @@ static int num_cus() {
 }
 
 #define SACV_NT_BLOCKS_PER_CU 2
+#ifndef SACV_NT_WN
+#define SACV_NT_WN 2  // waves along N of the 128x128 kernel: 2 -> 4 waves of 64x64, 4 -> 8 waves of 64x32
+#endif
 
 struct NtPlan {
   int base, rem, bpt;
@@ -849,7 +854,7 @@ static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w) {
   return p;
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int WN>
 static int launch_nt(ConvArgs& a, const NtPlan& plan, float* workspace, hipStream_t st) {
   int grid = num_cus() * SACV_NT_BLOCKS_PER_CU;
   a.grid = grid;
@@ -858,16 +863,16 @@ static int launch_nt(ConvArgs& a, const NtPlan& plan, float* workspace, hipStrea
   a.bpt = plan.bpt;
   a.partial = workspace;
   size_t lds = (size_t)2 * (BM + BN) * 36 * sizeof(float);
-  size_t lds_epi = ((size_t)BM * (BN + 4) + 2 * (256 / (BN / 4)) * BN) * sizeof(float);
+  size_t lds_epi = ((size_t)BM * (BN + 4) + 2 * (128 * WN / (BN / 4)) * BN) * sizeof(float);
   if (lds_epi > lds) lds = lds_epi;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN, MODE>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN, MODE, WN>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   int launch_blocks = a.base > 0 ? grid : a.rem_tiles * a.bpt;
-  hipLaunchKernelGGL((conv_nt_kernel<BM, BN, MODE>), dim3(launch_blocks), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_nt_kernel<BM, BN, MODE, WN>), dim3(launch_blocks), dim3(128 * WN), lds, st, a);
   SACV_CHECK_LAUNCH("conv_nt_kernel");
   if (a.rem_tiles > 0 && a.bpt > 1) {
     hipLaunchKernelGGL((conv_fixup_kernel<BM, BN>), dim3(a.rem_tiles), dim3(1024), 0, st, a);
@@ -982,8 +987,10 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
   NtPlan p128 = plan_nt(tiles * ((N + 127) / 128), KT, grid, ws, 1.0);
   NtPlan p64 = plan_nt(tiles * ((N + 63) / 64), KT, grid, ws, 0.6);
   const bool use64 = (N <= 64) || (p64.cost < p128.cost);
-  if (use64) return mode == 0 ? launch_nt<128, 64, 0>(a, p64, workspace, st) : launch_nt<128, 64, 1>(a, p64, workspace, st);
-  return mode == 0 ? launch_nt<128, 128, 0>(a, p128, workspace, st) : launch_nt<128, 128, 1>(a, p128, workspace, st);
+  if (use64)
+    return mode == 0 ? launch_nt<128, 64, 0, 2>(a, p64, workspace, st) : launch_nt<128, 64, 1, 2>(a, p64, workspace, st);
+  return mode == 0 ? launch_nt<128, 128, 0, SACV_NT_WN>(a, p128, workspace, st)
+                   : launch_nt<128, 128, 1, SACV_NT_WN>(a, p128, workspace, st);
 }
 
 // Rows of the CF_STATS buffer ([rows][2][N] floats): the number of 128-row M tiles over all problems.

@@ -85,8 +85,7 @@ def main():
         dist.init_process_group(backend, init_method='env://', rank=rank, world_size=world, **kw)
         group = dist.group.WORLD
 
-    from oracle import synth  # input generator only (numpy); the oracle model is used by cpu_baseline alone
-    from sacv_amd import ops
+    from sacv_amd import ops, synthetic as synth  # oracle/ is imported by the cpu_baseline leg only
     from sacv_amd.detection import models, losses
     from sacv_amd.train import DetectionTrainer
 

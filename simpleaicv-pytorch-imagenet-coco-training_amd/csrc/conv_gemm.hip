@@ -325,10 +325,26 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
   const int lh = lane >> 5;
 
   // (a static priority for the second-dispatched half of the grid was also measured: no gain)
+#ifdef SACV_STAMP
+  // diagnostic build: per-workgroup phase timestamps (s_memtime) into a.stats (never in the shipped library)
+  long long* stamp = reinterpret_cast<long long*>(a.stats) + (size_t)bid * 64;
+  int nstamp = 0;
+#define SACV_STAMP_HERE()                                                            \
+  do {                                                                               \
+    if (tid == 0 && nstamp < 64) stamp[nstamp] = (long long)__builtin_amdgcn_s_memtime(); \
+    ++nstamp;                                                                        \
+  } while (0)
+#else
+#define SACV_STAMP_HERE() do {} while (0)
+#endif
+  SACV_STAMP_HERE();
+  // (delaying half of the workgroups by half a K iteration at start-up -- by parity or by grid half -- to
+  // break the lockstep of the two workgroups of a CU was measured: no effect, they re-synchronise)
   setup(0);
   load_tile(k_begin);
   store_tile(0);
   __syncthreads();
+  SACV_STAMP_HERE();
   int cur = 0;
   for (int sidx = 0; sidx < nseg; ++sidx) {
 #pragma unroll
@@ -369,6 +385,8 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
           for (int j = 0; j < TN; ++j)
             fb[nbuf][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * LS + (jj + 1) * 8);
         }
+        // one A gather and one B gather per quarter of the MFMA block.  (Issuing all eight in the first two
+        // quarters, to give them more time before the LDS store, was measured: 122 -> 106-115 TF.)
         if (jj < RA) load_a(jj);
         if (jj < RB) load_b(jj);
         // raise the wave's issue priority for the MFMA block (dropped again before the LDS stores and the
@@ -399,6 +417,7 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
       if (!(a.flags & 4096)) __syncthreads();
       cur ^= 1;
     }
+    SACV_STAMP_HERE();  // end of K loop
     // ---- epilogue: accumulators -> LDS [BM][BN+4] -> 16-byte row-major stores
     {
       constexpr int CS = BN + 4;
@@ -433,6 +452,7 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
         __syncthreads();
         cur = 0;
       }
+      SACV_STAMP_HERE();  // end of epilogue (+ next slab in LDS)
     }
   }
 }
@@ -810,7 +830,9 @@ static int num_cus() {
   return g_num_cus;
 }
 
+#ifndef SACV_NT_BLOCKS_PER_CU
 #define SACV_NT_BLOCKS_PER_CU 2
+#endif
 #ifndef SACV_NT_WN
 #define SACV_NT_WN 2  // waves along N of the 128x128 kernel: 2 -> 4 waves of 64x64, 4 -> 8 waves of 64x32
 #endif

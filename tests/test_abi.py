@@ -56,3 +56,18 @@ def test_no_cpu_fallback():
         dec([[torch.zeros(1, 2, 2, 9, 80)], [torch.zeros(1, 2, 2, 9, 4)]])
     with pytest.raises(NotImplementedError):
         decode.__dict__['RetinaDecoder'](nms_type='torch_nms')
+
+
+def test_bench_generator_matches_fixture_generator():
+    """bench.py draws its synthetic batches from the product package (it must not import oracle/ outside its
+    cpu_baseline leg); the recipe is the one the fixtures were generated with."""
+    import numpy as np
+    from oracle import synth as osynth
+    from sacv_amd import synthetic
+    assert np.array_equal(osynth.images(3, 1, 17, 23), synthetic.images(3, 1, 17, 23))
+    assert np.array_equal(osynth.annotations(5, 2, 800, 1333), synthetic.annotations(5, 2, 800, 1333))
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    head, _, tail = src.partition('def cpu_baseline')
+    body_after = tail.split('\ndef main', 1)[1]
+    assert 'oracle' not in head.replace('oracle/', '').split('import argparse')[1].split('def ')[0]
+    assert 'from oracle' not in body_after and 'import oracle' not in body_after

@@ -631,22 +631,39 @@ __global__ __launch_bounds__(256, 2) void conv_tn_kernel(const WgradArgs a) {
     const bool have_next = kt + 1 < KT;
     const int pnext = pix0 + ((kt + 1) << 5);
     advance();
-    const float* cA = sA + cur * 32 * BM + wm0 + l31;
-    const float* cB = sB + cur * 32 * BN + wn0 + l31;
-    // next slab's gathers are issued in the MFMA shadows, two per group of four k-steps
+    // Fragment reads: the wave's two 32-row MFMA blocks are INTERLEAVED in the LDS row (row 2i+b of the wave's
+    // 64-row range belongs to block b), so one 8-byte ds_read_b64 per lane fetches the operands of both blocks
+    // (64 contiguous dwords per half-wave: conflict-free) -- half the LDS instructions of two ds_read_b32.
+    const float* cA = sA + cur * 32 * BM + wm0 + (TM == 2 ? 2 * l31 : l31);
+    const float* cB = sB + cur * 32 * BN + wn0 + (TN == 2 ? 2 * l31 : l31);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto read_a = [&](float (&dst)[TM], int krow) {
+      if (TM == 2) {
+        f32x2 v = *reinterpret_cast<const f32x2*>(cA + krow * BM);
+        dst[0] = v[0];
+        dst[TM - 1] = v[1];
+      } else {
+        dst[0] = cA[krow * BM];
+      }
+    };
+    auto read_b = [&](float (&dst)[TN], int krow) {
+      if (TN == 2) {
+        f32x2 v = *reinterpret_cast<const f32x2*>(cB + krow * BN);
+        dst[0] = v[0];
+        dst[TN - 1] = v[1];
+      } else {
+        dst[0] = cB[krow * BN];
+      }
+    };
     float fa[2][TM], fb[2][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fa[0][i] = cA[lh * BM + i * 32];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = cB[lh * BN + j * 32];
+    read_a(fa[0], lh);
+    read_b(fb[0], lh);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int cbuf = s & 1, nbuf = cbuf ^ 1;
       if (s < 15) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[nbuf][i] = cA[(2 * (s + 1) + lh) * BM + i * 32];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[nbuf][j] = cB[(2 * (s + 1) + lh) * BN + j * 32];
+        read_a(fa[nbuf], 2 * (s + 1) + lh);
+        read_b(fb[nbuf], 2 * (s + 1) + lh);
       }
       if ((s & 3) == 0 && (s >> 2) < RA) load_a(s >> 2, pnext, have_next);
       if ((s & 3) == 2 && (s >> 2) < RB) load_b(s >> 2, pnext, have_next);
@@ -659,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void conv_tn_kernel(const WgradArgs a) {
 #pragma unroll
       for (int m = 0; m < TM * TN; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (m < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (m < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
         if (m == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
@@ -677,8 +694,12 @@ __global__ __launch_bounds__(256, 2) void conv_tn_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        stage[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CS + wn0 + j * 32 + l31] = acc[i][j][r];
+      for (int r = 0; r < 16; ++r) {
+        const int ri = (r & 3) + 8 * (r >> 2) + 4 * lh;  // row of the 32x32 MFMA block held in register r
+        const int row = wm0 + (TM == 2 ? 2 * ri + i : ri);
+        const int col = wn0 + (TN == 2 ? 2 * l31 + j : l31);
+        stage[row * CS + col] = acc[i][j][r];
+      }
   __syncthreads();
   float* __restrict__ part = a.part + (size_t)ck * a.Cout * a.N2;
   constexpr int CG = BN / 4, RS = 256 / CG;

@@ -178,6 +178,15 @@ int sacv_decode_topk_nms(int kind, int nlev, const float* const* cls, const floa
                          float min_score, int topn, int nms_type, float nms_thr, int max_obj, void* workspace,
                          float* out_scores, float* out_classes, float* out_boxes, void* stream);
 
+/* ---- data boundary either side of the step ------------------------------------- */
+/* DetectionCollater + Normalize (detection/common.py:223-286): B (<=16) uint8 [h][w][3] device images ->
+ * zero-padded fp32 batch [B][R][R][3] = channels_last storage of the model input, value / 255 */
+int sacv_collate_u8(int B, const unsigned char* const* imgs /*host array*/, const int* h, const int* w, int R,
+                    float* out, void* stream);
+/* evaluate_coco_detection post-steps (tools/scripts.py:742-758), in place on boxes [B][M][4]:
+ * / scale, clip to the original image size, xyxy -> xywh */
+int sacv_eval_postprocess(float* boxes, const float* scales, const float* sizes, int B, int M, void* stream);
+
 /* ---- optimizer (tools/utils.py:480-582 build_optimizer -> torch.optim.AdamW) ------------------------- */
 int sacv_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
                     long long split, float lr, float beta1, float beta2, float eps, float wd_lo, float wd_hi,

@@ -108,3 +108,30 @@ def fcos_decode(cls_preds, reg_preds, ctr_preds, strides=_anchors.DEFAULT_STRIDE
     e = np.exp(reg)
     boxes = np.concatenate([pos - e[..., 0:2], pos + e[..., 2:4]], axis=2).astype(np.int32)
     return select_detections(scores, classes, boxes, **kw)
+
+
+def collate(samples, resize=800, resize_type='retina_style', max_annots_num=100):
+    """Normalize + DetectionCollater (simpleAICV/detection/common.py:223-286) in NumPy: samples hold uint8 HWC
+    images; returns (images [B,R,R,3] fp32 = value/255 zero padded, annots [B,max,5] padded with -1)."""
+    r = int(round(resize * 1333. / 800)) if resize_type == 'retina_style' else resize
+    out = np.zeros((len(samples), r, r, 3), dtype=F32)
+    ann = np.full((len(samples), max_annots_num, 5), -1, dtype=F32)
+    for i, s in enumerate(samples):
+        im = s['image'].astype(F32) / 255.
+        out[i, :im.shape[0], :im.shape[1], :] = im
+        if s['annots'].shape[0] > 0:
+            ann[i, :s['annots'].shape[0]] = s['annots']
+    return out, ann
+
+
+def eval_postprocess(boxes, scales, sizes):
+    """tools/scripts.py:742-758 on a copy of boxes [B,M,4] fp32."""
+    b = boxes.astype(F32).copy()
+    b /= np.asarray(scales, dtype=F32)[:, None, None]
+    for i in range(b.shape[0]):
+        b[i, :, 0] = np.maximum(b[i, :, 0], 0)
+        b[i, :, 1] = np.maximum(b[i, :, 1], 0)
+        b[i, :, 2] = np.minimum(b[i, :, 2], sizes[i][1])
+        b[i, :, 3] = np.minimum(b[i, :, 3], sizes[i][0])
+        b[i, :, 2:] -= b[i, :, :2]
+    return b

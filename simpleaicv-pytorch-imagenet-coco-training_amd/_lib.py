@@ -51,6 +51,8 @@ SIGNATURES = {
     'sacv_retina_box_loss_fwd_bwd': (I, [I, P, P, P, P, P, I, I, I, F, F, P, P, P, I, P]),
     'sacv_decode_workspace_bytes': (LL, [I, I, I]),
     'sacv_decode_topk_nms': (I, [I, I, P, P, P, P, P, I, I, I, F, I, I, F, I, P, P, P, P, P]),
+    'sacv_collate_u8': (I, [I, P, P, P, I, P, P]),
+    'sacv_eval_postprocess': (I, [P, P, P, I, I, P]),
     'sacv_adamw_step': (I, [P, P, P, P, LL, LL, F, F, F, F, F, F, I, F, P]),
     'sacv_fill': (I, [P, LL, F, P]),
 }

@@ -59,8 +59,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_partial_kernel(const floa
 
 // Second stage: 16 channels per 256-thread block, 16 threads per channel each summing a fixed strided
 // subset of the per-block partials (coalesced 64-byte rows), then a fixed-order fp64 combine in LDS.
-#define FIN_CH 16
-#define FIN_PARTS 16
+#define FIN_CH 4
+#define FIN_PARTS 64
 __device__ __forceinline__ void finalize_sums(const float* __restrict__ partial, int nblocks, int C, int c, int part,
                                               bool valid, double* red, double& s, double& q) {
   double ls = 0.0, lq = 0.0;

@@ -340,3 +340,86 @@ int sacv_colsum_finalize(const float* partial, int nblocks, int stride, int C, f
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- device-side data boundary
+// DetectionCollater + Normalize (simpleAICV/detection/common.py:223-286): uint8 HWC images of different sizes ->
+// one zero-padded fp32 batch [B][R][R][3] (channels_last storage of the logical [B,3,R,R] the model takes),
+// value / 255 in fp32.  Moves 4x fewer bytes over PCIe than the reference's host-side float batch.
+struct CollateArgs {
+  const unsigned char* img[16];
+  int h[16], w[16];
+  int B, R;
+};
+__global__ __launch_bounds__(256) void collate_u8_kernel(const CollateArgs a, float* __restrict__ out) {
+  const size_t per = (size_t)a.R * a.R;
+  const size_t total = per * a.B;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    int b = (int)(i / per);
+    size_t r = i - (size_t)b * per;
+    int y = (int)(r / a.R), x = (int)(r - (size_t)y * a.R);
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    if (y < a.h[b] && x < a.w[b]) {
+      const unsigned char* p = a.img[b] + ((size_t)y * a.w[b] + x) * 3;
+      v0 = (float)p[0] / 255.f;
+      v1 = (float)p[1] / 255.f;
+      v2 = (float)p[2] / 255.f;
+    }
+    float* o = out + i * 3;
+    o[0] = v0;
+    o[1] = v1;
+    o[2] = v2;
+  }
+}
+
+// evaluate_coco_detection post-steps (tools/scripts.py:742-758) in place on boxes [B][M][4]:
+// boxes /= scale[b]; clip x1,y1 >= 0, x2 <= size[b][1], y2 <= size[b][0]; (x2,y2) -= (x1,y1)
+__global__ void eval_postprocess_kernel(float* __restrict__ boxes, const float* __restrict__ scales,
+                                        const float* __restrict__ sizes, int B, int M) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * M) return;
+  int b = i / M;
+  f32x4 v = *reinterpret_cast<f32x4*>(boxes + (size_t)i * 4);
+  float s = scales[b];
+  v[0] = v[0] / s;
+  v[1] = v[1] / s;
+  v[2] = v[2] / s;
+  v[3] = v[3] / s;
+  v[0] = fmaxf(v[0], 0.f);
+  v[1] = fmaxf(v[1], 0.f);
+  v[2] = fminf(v[2], sizes[b * 2 + 1]);
+  v[3] = fminf(v[3], sizes[b * 2 + 0]);
+  v[2] = v[2] - v[0];
+  v[3] = v[3] - v[1];
+  *reinterpret_cast<f32x4*>(boxes + (size_t)i * 4) = v;
+}
+
+extern "C" {
+
+// imgs: host array of B (<= 16) device pointers to uint8 [h][w][3]; out: fp32 [B][R][R][3]
+int sacv_collate_u8(int B, const unsigned char* const* imgs, const int* h, const int* w, int R, float* out,
+                    void* stream) {
+  SACV_CHECK_ARG(B >= 1 && B <= 16 && imgs && h && w && out && R > 0, "collate_u8: bad args (B <= 16)");
+  CollateArgs a;
+  a.B = B;
+  a.R = R;
+  for (int i = 0; i < B; ++i) {
+    SACV_CHECK_ARG(imgs[i] && h[i] > 0 && w[i] > 0 && h[i] <= R && w[i] <= R, "collate_u8: image %d does not fit", i);
+    a.img[i] = imgs[i];
+    a.h[i] = h[i];
+    a.w[i] = w[i];
+  }
+  size_t total = (size_t)B * R * R;
+  hipLaunchKernelGGL(collate_u8_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, out);
+  SACV_CHECK_LAUNCH("collate_u8");
+  return SACV_OK;
+}
+
+int sacv_eval_postprocess(float* boxes, const float* scales, const float* sizes, int B, int M, void* stream) {
+  SACV_CHECK_ARG(boxes && scales && sizes && B > 0 && M > 0, "eval_postprocess: bad args");
+  hipLaunchKernelGGL(eval_postprocess_kernel, dim3((B * M + 127) / 128), dim3(128), 0, (hipStream_t)stream, boxes,
+                     scales, sizes, B, M);
+  SACV_CHECK_LAUNCH("eval_postprocess");
+  return SACV_OK;
+}
+
+}  // extern "C"

@@ -466,3 +466,26 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, split, lr, beta1, beta2, eps,
                grad_scale=1.0):
     check(lib.sacv_adamw_step(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), split,
                               lr, beta1, beta2, eps, wd_lo, wd_hi, step, grad_scale, _stream()), 'adamw_step')
+
+
+# ------------------------------------------------------------------------------------------ data boundary
+def collate_u8(images_u8, resize):
+    """images_u8: list of uint8 CUDA tensors [h,w,3] -> logical [B,3,R,R] fp32 tensor in channels_last storage."""
+    b = len(images_u8)
+    dev = images_u8[0].device
+    for t in images_u8:
+        if t.dtype != torch.uint8 or t.device.type != 'cuda' or not t.is_contiguous() or t.shape[-1] != 3:
+            raise ValueError('collate_u8: expected contiguous uint8 CUDA tensors [h,w,3]')
+    out = torch.empty((b, resize, resize, 3), device=dev, dtype=torch.float32)
+    check(lib.sacv_collate_u8(b, parr([t.data_ptr() for t in images_u8]), iarr([t.shape[0] for t in images_u8]),
+                              iarr([t.shape[1] for t in images_u8]), resize, _ptr(out), _stream()), 'collate_u8')
+    return out.permute(0, 3, 1, 2)
+
+
+def eval_postprocess(boxes, scales, sizes):
+    """In place on boxes [B,M,4] (fp32 CUDA): / scale, clip to sizes [B,2] = (h,w), xyxy -> xywh."""
+    _chk(boxes, 'boxes')
+    b, m, _ = boxes.shape
+    check(lib.sacv_eval_postprocess(_ptr(boxes), _ptr(_chk(scales, 'scales')), _ptr(_chk(sizes, 'sizes')), b, m,
+                                    _stream()), 'eval_postprocess')
+    return boxes

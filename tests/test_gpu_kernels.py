@@ -374,3 +374,27 @@ def test_retina_decoder(ops, tag, nms_type, golden_dir):
     if key + '_scores' in G:  # outputs of the reference's own RetinaDecoder
         assert np.array_equal(s, G[key + '_scores']) and np.array_equal(b, G[key + '_boxes'])
         assert np.array_equal(c, G[key + '_classes'])
+
+
+# ----------------------------------------------------------------------------------------- data boundary
+def test_device_collater_and_eval_postprocess(ops):
+    """device-side Normalize + DetectionCollater and the evaluation box post-steps, bit-exact
+    against the NumPy restatement of the reference's host code."""
+    from sacv_amd.detection import common
+    rng = np.random.RandomState(0)
+    samples = []
+    for h, w, n in ((37, 51, 3), (64, 40, 0), (5, 66, 7)):
+        samples.append({'image': rng.randint(0, 256, size=(h, w, 3)).astype(np.uint8),
+                        'annots': rng.rand(n, 5).astype(np.float32) * 30, 'scale': 0.5 + rng.rand(), 'size': (h * 2, w * 2)})
+    col = common.DetectionCollater(resize=40, resize_type='retina_style', max_annots_num=10)  # R = 67
+    out = col(samples)
+    ref_img, ref_ann = odecode.collate(samples, resize=40, max_annots_num=10)
+    img = out['image']
+    assert tuple(img.shape) == (3, 3, 67, 67) and img.is_contiguous(memory_format=torch.channels_last)
+    assert np.array_equal(img.permute(0, 2, 3, 1).cpu().numpy(), ref_img)
+    assert np.array_equal(out['annots'].numpy(), ref_ann)
+    assert out['scale'].dtype == np.float32 and out['size'].shape == (3, 2)
+    boxes = (rng.rand(3, 100, 4).astype(np.float32) * 200 - 20)
+    boxes[:, 60:] = 0
+    got = common.eval_postprocess(torch.tensor(boxes).cuda(), out['scale'], out['size']).cpu().numpy()
+    assert np.array_equal(got, odecode.eval_postprocess(boxes, out['scale'], out['size']))

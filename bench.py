@@ -54,14 +54,87 @@ def cpu_baseline(max_steps=2):
                        f'RetinaNet-R50 fwd+RetinaLoss+bwd+AdamW, torch-CPU fp32 oracle, {t:.2f} s/step')
 
 
+def bench_classification(args, rank, world, group, ops, synth):
+    """Secondary workload: 0.classification_training/imagenet/resnet50/train_config.py --
+    batch 256, 224x224, CELoss, SGD(0.1, 0.9, wd 1e-4) -- in fp32 (the reference recipe runs fp16 autocast)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sacv_amd.classification import backbones, losses
+    from sacv_amd.train import ClassificationTrainer
+    CB, R = 256, 224
+    net = backbones.__dict__['resnet50'](num_classes=1000).cuda().train()
+    trainer = ClassificationTrainer(net, losses.__dict__['CELoss'](), lr=0.1, momentum=0.9, weight_decay=1e-4,
+                                    process_group=group)
+    images = torch.cat([torch.tensor(synth.images(rank * 64 + i, CB // 8, R, R)) for i in range(8)]).cuda()
+    labels = torch.tensor((synth.uniform(rank + 99, (CB,)) * 1000).astype(np.int64) % 1000).cuda()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = trainer.step(images, labels)
+    timer = None
+    if not args.no_kernel_timer:
+        timer = ops.TIMER = ops.KernelTimer()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(images, labels)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    loss = trainer.finish_step(out)
+    if world > 1:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    roofline = None
+    if timer is not None:
+        k = dict(launches=0, flops=0.0, ms=0.0)
+        for name, v in timer.summary().items():
+            if name.startswith('conv_nt_'):
+                for f_ in k:
+                    k[f_] += v[f_]
+        if k['launches']:
+            ach = k['flops'] / (k['ms'] * 1e-3) / 1e12
+            roofline = dict(kernel='conv_nt_kernel (implicit-GEMM conv forward + data gradient, fp32 MFMA 32x32x2)',
+                            bound='mfma', achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
+                            frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                            launches_per_step=k['launches'] // args.steps,
+                            share_of_step_ms=round(k['ms'] / args.steps, 2))
+        if os.environ.get('SACV_BENCH_DUMP') and rank == 0:
+            recs = timer.records[-(len(timer.records) // args.steps):]
+            with open(os.environ['SACV_BENCH_DUMP'], 'w') as f:
+                for key, flops, e0, e1 in recs:
+                    ms = e0.elapsed_time(e1)
+                    f.write(f'{key} {flops/1e9:.3f} GFLOP {ms*1e3:.1f} us {flops/(ms*1e-3)/1e12:.1f} TF\n')
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'images/sec/node ResNet50 ImageNet 224x224 bs=256/GPU (secondary, SURVEY 8f-1)',
+            'value': round(world * CB * args.steps / elapsed, 2), 'unit': 'images/sec', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'ResNet50 ImageNet training step (fwd + CELoss + bwd + grad all-reduce + SGD '
+                                   'momentum), images [256,3,224,224]/GPU, random init',
+                       'global_batch': world * CB, 'parallelism': f'dp{world}'},
+            'loss': loss, 'roofline': roofline}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--model', default='retinanet', choices=['retinanet', 'fcos'],
-                    help='retinanet = the headline metric; fcos = secondary workload (BASELINE config 4)')
+    ap.add_argument('--model', default='retinanet', choices=['retinanet', 'fcos', 'resnet50_cls'],
+                    help='retinanet = the headline metric; fcos = secondary workload (BASELINE config 4); '
+                         'resnet50_cls = ResNet50 ImageNet classification, bs 256/GPU, 224x224 (SURVEY.md 8f-1)')
     ap.add_argument('--no-kernel-timer', action='store_true')
     args = ap.parse_args()
 
@@ -90,6 +163,8 @@ def main():
     from sacv_amd.train import DetectionTrainer
 
     torch.manual_seed(0)
+    if args.model == 'resnet50_cls':
+        return bench_classification(args, rank, world, group, ops, synth)
     if args.model == 'fcos':
         net = models.__dict__['resnet50_fcos'](backbone_pretrained_path='', num_classes=80).cuda().train()
         crit = losses.__dict__['FCOSLoss']()

@@ -187,6 +187,17 @@ int sacv_collate_u8(int B, const unsigned char* const* imgs /*host array*/, cons
  * / scale, clip to the original image size, xyxy -> xywh */
 int sacv_eval_postprocess(float* boxes, const float* scales, const float* sizes, int B, int M, void* stream);
 
+/* ---- ResNet50 classification tail (classification/backbones/resnet.py:203,241;
+ *      classification/losses.py:14-26).  The FC layer runs as a 1x1 problem of sacv_conv2d_gemm. ------------- */
+int sacv_avgpool_fwd(const float* x, float* out, int N, int HW, int C, void* stream);
+int sacv_avgpool_bwd(const float* dy, float* dx, int N, int HW, int C, void* stream);
+/* nn.CrossEntropyLoss(reduction='mean') forward + gradient; labels int64; workspace >= ceil(N/4) floats */
+int sacv_softmax_ce_fwd_bwd(const float* logits, const long long* labels, float* dlogits, float* loss_out, int N,
+                            int C, float grad_scale, float* workspace, void* stream);
+/* torch.optim.SGD with momentum over the flat arena ([0,split) uses wd_lo, the rest wd_hi) */
+int sacv_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, long long split, float lr,
+                  float momentum, float wd_lo, float wd_hi, int first_step, float grad_scale, void* stream);
+
 /* ---- optimizer (tools/utils.py:480-582 build_optimizer -> torch.optim.AdamW) ------------------------- */
 int sacv_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
                     long long split, float lr, float beta1, float beta2, float eps, float wd_lo, float wd_hi,

@@ -48,3 +48,13 @@ def load_reference():
         sys.path.insert(0, REFERENCE_ROOT)
     from simpleAICV.detection import models, losses, decode
     return models, losses, decode
+
+
+def load_reference_classification():
+    """Return (backbones.resnet, losses) modules of simpleAICV.classification, CPU only.  The resnet module is
+    imported by file name: the package __init__ pulls every backbone family (and their third-party imports)."""
+    load_reference()
+    import importlib
+    resnet = importlib.import_module('simpleAICV.classification.backbones.resnet')
+    closses = importlib.import_module('simpleAICV.classification.losses')
+    return resnet, closses

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import synth, model as omodel  # noqa: E402
-from oracle.import_reference import load_reference  # noqa: E402
+from oracle.import_reference import load_reference, load_reference_classification  # noqa: E402
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 S1 = (800, 1333)
@@ -358,7 +358,71 @@ def sec_e2e_s1(ref):
     json.dump(meta, open(os.path.join(GOLD, 'e2e_s1.json'), 'w'), indent=0)
 
 
-SECTIONS = dict(contract=sec_contract, anchors=sec_anchors, assign=sec_assign, losses=sec_losses,
+def labels_for(seed, n, num_classes):
+    return (synth.uniform(seed, (n,)) * num_classes).astype(np.int64) % num_classes
+
+
+def sec_cls(ref):
+    """ResNet50 ImageNet classification row: contract, loss / logits / gradient norms of the
+    reference model on seeded inputs, and two reference SGD steps."""
+    resnet, closses = load_reference_classification()
+    meta, arrs = {}, {}
+    net = resnet.resnet50(num_classes=1000)
+    sd = net.state_dict()
+    meta['contract'] = dict(keys=[[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in sd.items()],
+                            params=[[k, list(v.shape)] for k, v in net.named_parameters()],
+                            n_params=int(sum(p.numel() for p in net.parameters())))
+    for name, B, R, nc in (('cls_64', 4, 64, 1000), ('cls_224', 8, 224, 1000), ('cls_96_nc40', 6, 96, 40)):
+        net = resnet.resnet50(num_classes=nc)
+        net.load_state_dict(omodel.init_resnet50_cls_state(0, nc), strict=True)
+        net.train()
+        crit = closses.CELoss()
+        x = torch.tensor(synth.images(11, B, R, R))
+        lab = torch.tensor(labels_for(23, B, nc))
+        logits = net(x)
+        loss = crit(logits, lab)
+        loss.backward()
+        m = dict(B=B, R=R, num_classes=nc, loss=float(loss.detach()), labels=lab.tolist(),
+                 grad_norm={k: float(p.grad.double().norm()) for k, p in net.named_parameters()})
+        arrs[f'{name}_logits'] = logits.detach().numpy()
+        for k in ('fc.bias', 'conv1.layer.1.weight', 'layer4.2.conv3.layer.1.bias'):
+            arrs[f'{name}_grad_{k}'] = dict(net.named_parameters())[k].grad.numpy().copy()
+        arrs[f'{name}_buf_conv1.layer.1.running_var'] = net.state_dict()['conv1.layer.1.running_var'].numpy().copy()
+        # two optimizer steps of the recipe's SGD (second one exercises the momentum buffer)
+        one_d = [p for p in net.parameters() if p.ndim == 1]
+        multi = [p for p in net.parameters() if p.ndim > 1]
+        opt = torch.optim.SGD([{'params': one_d, 'weight_decay': 0.0}, {'params': multi, 'weight_decay': 1e-4}],
+                              lr=0.1, momentum=0.9)
+        opt.step()
+        opt.zero_grad()
+        loss2 = crit(net(x), lab)
+        loss2.backward()
+        opt.step()
+        m['loss_step1'] = float(loss2)
+        # yardstick for the step-1 loss: the same step by the oracle in fp64 (lr 0.1 on random-init weights
+        # amplifies the fp32 rounding noise of the first backward pass into percents of the next loss)
+        sd64 = {k: (v.double() if v.dtype.is_floating_point else v.clone())
+                for k, v in omodel.init_resnet50_cls_state(0, nc).items()}
+        P = {k: v.clone().requires_grad_(True) for k, v in sd64.items() if v.dtype.is_floating_point
+             and 'running_' not in k}
+        sd64.update(P)
+        omodel.ce_loss(omodel.resnet50_cls_forward(sd64, x.double(), True), lab).backward()
+        Pn = {k: v.detach().clone() for k, v in P.items()}
+        omodel.sgd_momentum_step(Pn, {k: v.grad for k, v in P.items()}, {}, 0.1, 0.9, 1e-4, first=True)
+        sd64.update(Pn)
+        with torch.no_grad():
+            m['loss_step1_fp64'] = float(omodel.ce_loss(omodel.resnet50_cls_forward(sd64, x.double(), True), lab))
+        m['param_norm_after2'] = {k: float(p.detach().double().norm()) for k, p in net.named_parameters()}
+        net.eval()
+        with torch.no_grad():
+            arrs[f'{name}_eval_logits'] = net(x).numpy()
+        meta[name] = m
+        print(name, m['loss'], m['loss_step1'])
+    np.savez_compressed(os.path.join(GOLD, 'cls.npz'), **arrs)
+    json.dump(meta, open(os.path.join(GOLD, 'cls.json'), 'w'), indent=0)
+
+
+SECTIONS = dict(cls=sec_cls, contract=sec_contract, anchors=sec_anchors, assign=sec_assign, losses=sec_losses,
                 decode=sec_decode, e2e=sec_e2e, e2e_s1=sec_e2e_s1)
 
 if __name__ == '__main__':

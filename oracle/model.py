@@ -112,14 +112,14 @@ def _cba(sd, prefix, x, stride, pad, act, training, momentum=0.1, eps=1e-5):
     return F.relu(y) if act else y
 
 
-def backbone_forward(sd, x, training=True):
-    x = _cba(sd, 'backbone.conv1', x, 2, 3, True, training)
+def backbone_forward(sd, x, training=True, prefix='backbone.'):
+    x = _cba(sd, prefix + 'conv1', x, 2, 3, True, training)
     x = F.max_pool2d(x, 3, 2, 1)
     feats = []
     inpl = 64
     for li, (n, pl) in enumerate(zip(RESNET50_LAYERS, [64, 128, 256, 512]), start=1):
         for bi in range(n):
-            p = f'backbone.layer{li}.{bi}'
+            p = f'{prefix}layer{li}.{bi}'
             stride = 2 if (bi == 0 and li > 1) else 1
             idt = x
             y = _cba(sd, p + '.conv1', x, 1, 0, True, training)
@@ -193,3 +193,36 @@ def fcos_forward(sd, images, training=True):
         reg_heads.append((r.permute(0, 2, 3, 1).contiguous()) * torch.exp(sd['scales'][lvl]))
         ctr_heads.append(t.permute(0, 2, 3, 1).contiguous())
     return [cls_heads, reg_heads, ctr_heads]
+
+
+# ----------------------------------------------------------------------------- ResNet50 classifier (8f-1)
+def init_resnet50_cls_state(seed=0, num_classes=1000):
+    """State dict of classification/backbones/resnet.py::ResNet (Bottleneck [3,4,6,3]): the trunk of
+    init_retinanet_state without the 'backbone.' prefix + fc (nn.Linear default law, bound 1/sqrt(2048))."""
+    det = init_retinanet_state(seed)
+    sd = {k[len('backbone.'):]: v for k, v in det.items() if k.startswith('backbone.')}
+    bound = 1.0 / math.sqrt(2048)
+    u = lambda key, *shape: torch.from_numpy(synth.uniform(seed * 1000003 + zlib.crc32(key.encode()) + 17, shape))
+    sd['fc.weight'] = (u('fc.w', num_classes, 2048) * 2 - 1) * bound
+    sd['fc.bias'] = (u('fc.b', num_classes) * 2 - 1) * bound
+    return sd
+
+
+def resnet50_cls_forward(sd, images, training=True):
+    """ResNet.forward (classification/backbones/resnet.py:224-245): trunk -> global avg pool -> fc."""
+    c5 = backbone_forward(sd, images, training, prefix='')[3]
+    x = F.adaptive_avg_pool2d(c5, (1, 1)).flatten(1)
+    return F.linear(x, sd['fc.weight'], sd['fc.bias'])
+
+
+def ce_loss(logits, labels):
+    """CELoss (classification/losses.py:14-26): nn.CrossEntropyLoss(reduction='mean')."""
+    return F.cross_entropy(logits, labels, reduction='mean')
+
+
+def sgd_momentum_step(params, grads, bufs, lr, momentum, weight_decay, first):
+    """torch.optim.SGD as built by tools/utils.py:558-565 (weight decay on ndim>1 tensors only)."""
+    for k in params:
+        g = grads[k] + (weight_decay * params[k] if params[k].ndim > 1 else 0.0)
+        bufs[k] = g.clone() if first else momentum * bufs[k] + g
+        params[k] = params[k] - lr * bufs[k]

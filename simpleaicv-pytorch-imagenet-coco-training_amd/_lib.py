@@ -53,6 +53,10 @@ SIGNATURES = {
     'sacv_decode_topk_nms': (I, [I, I, P, P, P, P, P, I, I, I, F, I, I, F, I, P, P, P, P, P]),
     'sacv_collate_u8': (I, [I, P, P, P, I, P, P]),
     'sacv_eval_postprocess': (I, [P, P, P, I, I, P]),
+    'sacv_avgpool_fwd': (I, [P, P, I, I, I, P]),
+    'sacv_avgpool_bwd': (I, [P, P, I, I, I, P]),
+    'sacv_softmax_ce_fwd_bwd': (I, [P, P, P, P, I, I, F, P, P]),
+    'sacv_sgd_step': (I, [P, P, P, LL, LL, F, F, F, F, I, F, P]),
     'sacv_adamw_step': (I, [P, P, P, P, LL, LL, F, F, F, F, F, F, I, F, P]),
     'sacv_fill': (I, [P, LL, F, P]),
 }

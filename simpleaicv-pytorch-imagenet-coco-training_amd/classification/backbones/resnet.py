@@ -1,0 +1,87 @@
+"""ResNet50 classifier with the reference's constructor, module tree and state_dict keys
+(simpleAICV/classification/backbones/resnet.py:158-268), executed by the HIP engine.
+
+As for the detectors, the torch.nn modules are parameter containers only; forward runs the hand-written
+kernels (implicit-GEMM convolutions with fused BatchNorm statistics, global average pool, FC as a 1x1 GEMM
+problem) and there is no CPU / eager execution path.
+"""
+import torch
+import torch.nn as nn
+
+from ...engine import ClassifierEngine
+from ...detection.models._arena import ParamArena
+from ...detection.models._base import _resnet50_backbone
+
+__all__ = ['resnet50', 'ResNet']
+
+
+class _ClassifierFunction(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, model, images, *params):
+        ctx.model = model
+        return model._engine.forward(images, training=model.training, keep=True)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model = ctx.model
+        model._engine.backward(dlogits.contiguous())
+        return (None, None) + tuple(model._arena.grad_views[name] for name, _ in model._param_list)
+
+
+class ResNet(nn.Module):
+
+    def __init__(self, block='Bottleneck', layer_nums=(3, 4, 6, 3), inplanes=64, num_classes=1000,
+                 use_gradient_checkpoint=False):
+        super().__init__()
+        if block != 'Bottleneck' or tuple(layer_nums) != (3, 4, 6, 3) or inplanes != 64:
+            raise NotImplementedError('only ResNet50 (Bottleneck, [3,4,6,3], 64) is on the MI355X hot path')
+        if use_gradient_checkpoint:
+            raise NotImplementedError('use_gradient_checkpoint: activations are kept in HBM (288 GB) instead')
+        self.layer_nums, self.num_classes, self.inplanes = list(layer_nums), num_classes, 2048
+        self.planes, self.expansion = [64, 128, 256, 512], 4
+        self.use_gradient_checkpoint = use_gradient_checkpoint
+        _resnet50_backbone(self)  # conv1, layer1..layer4 (kaiming fan_out / BN 1,0 init, resnet.py:205-212)
+        self.maxpool1 = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(2048, num_classes)
+        self._arena = self._engine = self._param_list = None
+
+    def prepare(self):
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('sacv_amd ResNet runs on MI355X only: move the model to the GPU (.cuda()); there is '
+                               'no CPU/PyTorch fallback path')
+        self._arena = ParamArena(self)
+        self._param_list = list(self._arena.order)
+        tensors = {n: p.data for n, p in self.named_parameters()}
+        tensors.update({n: b for n, b in self.named_buffers()})
+        self._engine = ClassifierEngine(tensors, self._arena.grad_views, self.num_classes)
+        return self
+
+    def _ready(self):
+        if self._arena is None or not self._arena.is_current():
+            self.prepare()
+
+    @property
+    def arena(self):
+        self._ready()
+        return self._arena
+
+    @property
+    def engine(self):
+        self._ready()
+        return self._engine
+
+    def forward(self, x):
+        if x.device.type != 'cuda':
+            raise RuntimeError('sacv_amd ResNet runs on MI355X only: inputs must be on the GPU (no CPU fallback)')
+        self._ready()
+        x = x.float()
+        if torch.is_grad_enabled() and self.training:
+            return _ClassifierFunction.apply(self, x, *[p for _, p in self._param_list])
+        return self._engine.forward(x, training=self.training, keep=False)
+
+
+def resnet50(**kwargs):
+    return ResNet('Bottleneck', [3, 4, 6, 3], 64, **kwargs)

@@ -864,8 +864,9 @@ struct NtPlan {
 };
 
 // Schedule of `tiles` equal tiles of KT K-iterations on `grid` persistent workgroups.  w = relative cost of
-// one K-iteration of this tile shape (1.0 for 128x128, ~0.6 for 128x64).
-static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w) {
+// one K-iteration of this tile shape (1.0 for 128x128, ~0.6 for 128x64).  max_slots = partial-tile slabs the
+// split-K workspace holds for this tile shape (sacv_conv2d_gemm_workspace_bytes / tile bytes).
+static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w, int max_slots) {
   const double epi = 3.0, epi_split = 7.0;  // epilogue / slab write + fix-up, in K-iterations
   NtPlan p;
   p.base = tiles / grid;
@@ -883,7 +884,7 @@ static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w) {
     for (int b = 2; b <= max_bpt; ++b) {
       long long blocks = (long long)p.rem * b;
       if (p.base > 0 && blocks > grid) break;          // phase 2 of a multi-round launch: one slice per workgroup
-      if (blocks > 4LL * grid) break;
+      if (blocks > 4LL * grid || blocks > max_slots) break;  // every split block owns one workspace slab
       int rounds = (int)((blocks + grid - 1) / grid);  // base == 0 may oversubscribe (plain extra rounds)
       double c = rounds * ((KT + b - 1) / b + epi_split);
       if (c < best_c) {
@@ -910,11 +911,13 @@ static int launch_nt(ConvArgs& a, const NtPlan& plan, float* workspace, hipStrea
   if (lds_epi > lds) lds = lds_epi;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN, MODE, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN, MODE, WN>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   int launch_blocks = a.base > 0 ? grid : a.rem_tiles * a.bpt;
+  SACV_CHECK_ARG(a.bpt == 1 || (long long)a.rem_tiles * a.bpt * BM * BN <= (long long)grid * 128 * 128,
+                 "conv2d_gemm: split-K plan exceeds the workspace (%d slabs)", a.rem_tiles * a.bpt);
   hipLaunchKernelGGL((conv_nt_kernel<BM, BN, MODE, WN>), dim3(launch_blocks), dim3(128 * WN), lds, st, a);
   SACV_CHECK_LAUNCH("conv_nt_kernel");
   if (a.rem_tiles > 0 && a.bpt > 1) {
@@ -932,7 +935,7 @@ static int launch_tn(const WgradArgs& a, int chunks, hipStream_t st) {
   if (lds_epi > lds) lds = lds_epi;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tn_kernel<BM, BN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tn_kernel<BM, BN>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
@@ -1027,8 +1030,8 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
   const int grid = num_cus() * SACV_NT_BLOCKS_PER_CU;
   const int KT = KH * KW * ((Cs + 31) / 32);
   const bool ws = workspace != nullptr;
-  NtPlan p128 = plan_nt(tiles * ((N + 127) / 128), KT, grid, ws, 1.0);
-  NtPlan p64 = plan_nt(tiles * ((N + 63) / 64), KT, grid, ws, 0.6);
+  NtPlan p128 = plan_nt(tiles * ((N + 127) / 128), KT, grid, ws, 1.0, grid);
+  NtPlan p64 = plan_nt(tiles * ((N + 63) / 64), KT, grid, ws, 0.6, 2 * grid);
   const bool use64 = (N <= 64) || (p64.cost < p128.cost);
   if (use64)
     return mode == 0 ? launch_nt<128, 64, 0, 2>(a, p64, workspace, st) : launch_nt<128, 64, 1, 2>(a, p64, workspace, st);

@@ -26,8 +26,9 @@ def _bottleneck(cin, planes, stride):
     return blk
 
 
-def _resnet50_backbone():
-    bb = nn.Module()
+def _resnet50_backbone(bb=None):
+    """ResNet50 trunk containers; populates `bb` (the bare classifier registers them on itself)."""
+    bb = nn.Module() if bb is None else bb
     bb.conv1 = _conv_bn_act(3, 64, 7, 2, 3)
     cin = 64
     for li, (n, planes) in enumerate(zip(RESNET50_LAYERS, (64, 128, 256, 512)), start=1):

@@ -41,6 +41,7 @@ class DetectorEngine:
         self.p, self.g = p, g
         self.num_classes, self.num_anchors, self.planes, self.fcos = num_classes, num_anchors, planes, fcos
         self.ctx = None
+        self.bp = 'backbone.'  # key prefix of the trunk in the state_dict ('' for the bare classifier)
         # Weight gradients are leaves of the backward dependency graph (nothing downstream reads them until
         # the optimizer / all-reduce), so they CAN run on a side HIP stream next to the BatchNorm / data-
         # gradient chain.  Measured on MI355X: no gain (45.9 vs 44.8 ms/step) -- the persistent conv kernels
@@ -166,18 +167,28 @@ class DetectorEngine:
     # ------------------------------------------------------------------ forward
     def forward(self, images, training=True, keep=True):
         """images: logical [B,3,H,W] fp32 (any strides).  Returns (cls_levels, reg_levels)."""
-        p = self.p
         ctx = {} if keep else None
+        feats = self._backbone_fwd(images, training, keep, ctx)
+        c3f, c4f, c5f = feats[1], feats[2], feats[3]
+        fpn = self._fpn_fwd(c3f, c4f, c5f, ctx)
+        outs = self._fcos_heads_fwd(fpn, ctx) if self.fcos else self._heads_fwd(fpn, ctx)
+        if keep:
+            self.ctx = ctx
+        return outs
+
+    def _backbone_fwd(self, images, training, keep, ctx):
+        """ResNet50 trunk (classification/backbones/resnet.py:158-245): returns [C2, C3, C4, C5]."""
+        p, bp = self.p, self.bp
         b, _, h, w = images.shape
         # stem: explicit im2col (Cin=3) + GEMM, BN, ReLU, 3x3/s2 max pool
         ho, wo = _out_hw(h, w, 7, 2, 3)
         col = ops.im2col_stem(images, ho, wo)
-        wst = ops.pack_weight(p['backbone.conv1.layer.0.weight'], PACK_STEM)
+        wst = ops.pack_weight(p[bp + 'conv1.layer.0.weight'], PACK_STEM)
         if training:
             (y,), st = ops.conv_gemm([col], wst, 64, 1, 1, 1, 0, 0, [(ho, wo)], stats=True)
         else:
             y, st = ops.conv_gemm([col], wst, 64, 1, 1, 1, 0, 0, [(ho, wo)])[0], None
-        z, c = self._bn_fwd(col, y, 'backbone.conv1', 7, 2, 3, True, training, None, keep, st)
+        z, c = self._bn_fwd(col, y, bp + 'conv1', 7, 2, 3, True, training, None, keep, st)
         x, pool_idx = ops.maxpool_fwd(z, 3, 2, 1, want_idx=keep)
         if keep:
             ctx['stem'] = c
@@ -187,19 +198,15 @@ class DetectorEngine:
         blocks = []
         for li, n in enumerate(RESNET50_LAYERS, start=1):
             for bi in range(n):
-                pre = f'backbone.layer{li}.{bi}'
+                pre = f'{bp}layer{li}.{bi}'
                 stride = 2 if (bi == 0 and li > 1) else 1
                 out, (c1, c2, c3, cd) = self._bottleneck_fwd(x, pre, stride, training, keep)
                 blocks.append((c1, c2, c3, cd, li, bi))
                 x = out
             feats.append(x)
-        c3f, c4f, c5f = feats[1], feats[2], feats[3]
-        fpn = self._fpn_fwd(c3f, c4f, c5f, ctx)
-        outs = self._fcos_heads_fwd(fpn, ctx) if self.fcos else self._heads_fwd(fpn, ctx)
         if keep:
             ctx['blocks'] = blocks
-            self.ctx = ctx
-        return outs
+        return feats
 
     def _bottleneck_fwd(self, x, pre, stride, training, keep=True):
         """Bottleneck.forward (classification/backbones/resnet.py:141-155): 1x1 -> 3x3(stride) -> 1x1,
@@ -442,10 +449,17 @@ class DetectorEngine:
             self._join_side()
             on_stage('heads')  # head gradients are final: their all-reduce can start now
         dc3, dc4, dc5 = self._fpn_bwd(dfeat)
-        # backbone, last block first
-        blocks = ctx['blocks']
-        dout = dc5
-        for c1, c2, c3, cd, li, bi in reversed(blocks):
+        self._backbone_bwd(dc5, dc4, dc3, on_stage)
+        self._join_side()
+        if on_stage:
+            on_stage('rest')
+        self.ctx = None
+
+    def _backbone_bwd(self, dout, dc4=None, dc3=None, on_stage=None):
+        """Backward of the trunk, last block first; dc4 / dc3 are the FPN lateral gradients that join the
+        data gradient at the inputs of layer4 / layer3 (None for the classifier)."""
+        ctx, bp = self.ctx, self.bp
+        for c1, c2, c3, cd, li, bi in reversed(ctx['blocks']):
             accum_target = None
             if bi == 0 and li == 4:
                 accum_target = dc4
@@ -458,15 +472,11 @@ class DetectorEngine:
         # max pool + stem
         dpool = ops.maxpool_bwd(dout, ctx['pool_idx'], ctx['pool_in_shape'], 3, 2, 1)
         st = ctx['stem']
-        bn = 'backbone.conv1.layer.1.'
+        bn = bp + 'conv1.layer.1.'
         dy, _ = ops.bn_train_bwd(dpool, st.z, st.y, st.mean, st.invstd, self.p[bn + 'weight'], self.g[bn + 'weight'],
                                  self.g[bn + 'bias'])
-        self._wgrad([dy], [st.x], self.g['backbone.conv1.layer.0.weight'], 3, 1, 1, 1, 0,
+        self._wgrad([dy], [st.x], self.g[bp + 'conv1.layer.0.weight'], 3, 1, 1, 1, 0,
                     cin_pad=ops.STEM_KPAD, dw_taps=49)
-        self._join_side()
-        if on_stage:
-            on_stage('rest')
-        self.ctx = None
 
     def _bottleneck_bwd(self, c1, c2, c3, cd, dout, accum_target):
         # out = relu(bn3(conv3(z2)) + idt): g is the masked gradient shared by both branches
@@ -508,3 +518,46 @@ class DetectorEngine:
         else:
             self._conv_bias_bwd(dp5, f['c5'], 'fpn.P5_1', 1, 1, 0, out=dc5, accumulate=True)
         return dc3, dc4, dc5
+
+
+class ClassifierEngine(DetectorEngine):
+    """ResNet50 ImageNet classifier (classification/backbones/resnet.py:158-245): the trunk of
+    the detector engine + global average pool + FC (a 1x1 problem of the conv GEMM kernels)."""
+
+    def __init__(self, p, g, num_classes=1000):
+        super().__init__(p, g, num_classes=num_classes)
+        self.bp = ''
+
+    def forward(self, images, training=True, keep=True):
+        """images logical [B,3,H,W] -> logits [B, num_classes]"""
+        ctx = {} if keep else None
+        c5 = self._backbone_fwd(images, training, keep, ctx)[3]
+        pooled = ops.avgpool_fwd(c5)
+        w = self.p['fc.weight']
+        wp = ops.pack_weight(w.view(w.shape[0], w.shape[1], 1, 1), PACK_FWD)
+        logits = ops.conv_gemm([pooled], wp, w.shape[0], 1, 1, 1, 0, 0, [(1, 1)], bias=self.p['fc.bias'])[0]
+        if keep:
+            ctx['pooled'] = pooled
+            ctx['c5_shape'] = tuple(c5.shape)
+            self.ctx = ctx
+        return logits.view(logits.shape[0], w.shape[0])
+
+    def backward(self, dlogits, on_stage=None):
+        ctx = self.ctx
+        if ctx is None:
+            raise RuntimeError('backward() without a preceding forward(keep=True)')
+        w = self.p['fc.weight']
+        nout, nin = w.shape
+        dy = dlogits.contiguous().view(dlogits.shape[0], 1, 1, nout)
+        self._wgrad([dy], [ctx['pooled']], self.g['fc.weight'].view(nout, nin, 1, 1), nin, 1, 1, 1, 0)
+        ops.colsum(dy.view(-1, nout), nout, self.g['fc.bias'])
+        dpooled = self._dgrad(dy, w.view(nout, nin, 1, 1), ctx['pooled'].shape, 1, 1, 0)
+        dc5 = ops.avgpool_bwd(dpooled, ctx['c5_shape'])
+        if on_stage:
+            self._join_side()
+            on_stage('heads')
+        self._backbone_bwd(dc5, None, None, on_stage)
+        self._join_side()
+        if on_stage:
+            on_stage('rest')
+        self.ctx = None

@@ -489,3 +489,37 @@ def eval_postprocess(boxes, scales, sizes):
     check(lib.sacv_eval_postprocess(_ptr(boxes), _ptr(_chk(scales, 'scales')), _ptr(_chk(sizes, 'sizes')), b, m,
                                     _stream()), 'eval_postprocess')
     return boxes
+
+
+# ------------------------------------------------------------------------------------------ classification
+def avgpool_fwd(x):
+    n, h, w, c = x.shape
+    out = torch.empty((n, 1, 1, c), device=x.device, dtype=torch.float32)
+    check(lib.sacv_avgpool_fwd(_ptr(x), _ptr(out), n, h * w, c, _stream()), 'avgpool_fwd')
+    return out
+
+
+def avgpool_bwd(dy, x_shape):
+    n, h, w, c = x_shape
+    dx = torch.empty(tuple(x_shape), device=dy.device, dtype=torch.float32)
+    check(lib.sacv_avgpool_bwd(_ptr(dy), _ptr(dx), n, h * w, c, _stream()), 'avgpool_bwd')
+    return dx
+
+
+def softmax_ce(logits, labels, want_grad=True, grad_scale=1.0):
+    """logits [N,C] fp32, labels [N] int64 -> (loss f32[1], dlogits or None)."""
+    _chk(logits, 'logits')
+    n, c = logits.shape
+    if labels.dtype != torch.int64 or labels.device != logits.device:
+        raise ValueError('softmax_ce: labels must be int64 on the same device')
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    dl = torch.empty_like(logits) if want_grad else None
+    ws = workspace(((n + 3) // 4 + 64) * 4, logits.device, 'ce')
+    check(lib.sacv_softmax_ce_fwd_bwd(_ptr(logits), _ptr(labels.contiguous()), _ptr(dl), _ptr(loss), n, c,
+                                      grad_scale, ws.data_ptr(), _stream()), 'softmax_ce')
+    return loss, dl
+
+
+def sgd_step(params, grads, momentum_buf, split, lr, momentum, wd_lo, wd_hi, first_step, grad_scale=1.0):
+    check(lib.sacv_sgd_step(_ptr(params), _ptr(grads), _ptr(momentum_buf), params.numel(), split, lr, momentum,
+                            wd_lo, wd_hi, int(first_step), grad_scale, _stream()), 'sgd_step')

@@ -21,8 +21,8 @@ def stage_ranges(arena_order, offsets, numel, split):
     """Contiguous [begin, end) element ranges of the gradient arena per backward stage.
 
     arena_order: [(name, tensor)] in arena order (1-D tensors first, then >=2-D in module order).
-    Returns dict stage -> (begin, end):  'heads' (cls_head/reg_head weights), 'neck' (fpn + backbone
-    layer4 weights), 'rest' (everything else including the whole 1-D section)."""
+    Returns dict stage -> (begin, end):  'heads' (cls_head/reg_head weights; the classifier's fc),
+    'neck' (fpn + backbone layer4 weights), 'rest' (everything else including the whole 1-D section)."""
     multi = [(n, offsets[n]) for n, t in arena_order if t.ndim != 1]
 
     def first(prefixes):
@@ -31,8 +31,8 @@ def stage_ranges(arena_order, offsets, numel, split):
                 return o
         return numel
 
-    heads_begin = first(('cls_head.', 'reg_head.', 'clsregcnt_head.'))
-    neck_begin = min(first(('backbone.layer4.',)), first(('fpn.',)))
+    heads_begin = first(('cls_head.', 'reg_head.', 'clsregcnt_head.', 'fc.'))
+    neck_begin = min(first(('backbone.layer4.', 'layer4.')), first(('fpn.',)))
     neck_begin = min(neck_begin, heads_begin)
     return {'heads': (heads_begin, numel), 'neck': (neck_begin, heads_begin), 'rest': (0, neck_begin)}
 

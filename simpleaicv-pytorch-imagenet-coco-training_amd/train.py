@@ -63,3 +63,44 @@ class DetectionTrainer:
         out = dict(zip(keys, v))
         out['loss'] = sum(v)
         return out
+
+
+class ClassificationTrainer:
+    """One ImageNet training step of tools/scripts.py::train_classification with the ResNet50 recipe's
+    optimizer (0.classification_training/imagenet/resnet50/train_config.py:68-79: SGD lr 0.1, momentum 0.9,
+    weight decay 1e-4 on ndim>1 tensors only) as one fused kernel over the flat arena."""
+
+    def __init__(self, model, criterion, lr=0.1, momentum=0.9, weight_decay=1e-4, accumulation_steps=1,
+                 process_group=None):
+        self.model, self.criterion = model, criterion
+        self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        self.accumulation_steps = accumulation_steps
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.step_count = 0
+        arena = model.arena
+        self.momentum_buf = torch.zeros_like(arena.params)
+        self.exchanger = GradExchanger(arena.grads, stage_ranges(arena.order, arena.offsets, arena.numel, arena.split),
+                                       process_group)
+        if self.world > 1:
+            dist.broadcast(arena.params, src=0, group=process_group)
+            broadcast_buffers(arena.buffers, process_group)
+
+    def step(self, images, labels):
+        model = self.model
+        engine, arena = model.engine, model.arena
+        if self.world > 1:
+            broadcast_buffers(arena.buffers, self.group)
+        logits = engine.forward(images, training=True, keep=True)
+        loss, dlogits = self.criterion.fused(logits, labels, grad_scale=1.0 / self.accumulation_steps)
+        engine.backward(dlogits, on_stage=self.exchanger.stage_done)
+        self.exchanger.wait()
+        ops.sgd_step(arena.params, arena.grads, self.momentum_buf, arena.split, self.lr, self.momentum, 0.0,
+                     self.weight_decay, self.step_count == 0, grad_scale=1.0 / self.world)
+        self.step_count += 1
+        return {'loss': loss[0]}
+
+    def finish_step(self, loss_dict):
+        v = loss_dict['loss'].reshape(1).float().clone()
+        v = (vote_and_reduce_scalars(v, self.group) / self.world).tolist()
+        return {'loss': v[0]}

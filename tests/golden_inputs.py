@@ -101,3 +101,8 @@ def digest(a, nsamp=512):
     step = max(1, a.size // nsamp)
     return dict(sum=float(a.sum()), abssum=float(np.abs(a).sum()), n=int(a.size), step=int(step),
                 samples=a[::step][:nsamp].astype(np.float32))
+
+
+def labels_for(seed, n, num_classes):
+    """Seeded class labels of the classification fixtures (same recipe as oracle/make_golden.py::labels_for)."""
+    return (synth.uniform(seed, (n,)) * num_classes).astype(np.int64) % num_classes

@@ -4,6 +4,8 @@ autograd of the oracle's functional graph, on WELL-CONDITIONED random data: stru
 (a missing gradient fan-in, a wrong mask, a wrong accumulation) show up as O(1) errors, fp32
 rounding as ~1e-5.  Metric: relative L2 per tensor <= 1e-4 (the max-abs metric is not used because a
 single ReLU whose pre-activation rounds across zero flips one element)."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -52,7 +54,7 @@ def test_bottleneck_fwd_bwd(cin, planes, stride, h, w):
     pre = 'backbone.layer2.0'
     sd = {}
     for name, ci, co, k in (('conv1', cin, planes, 1), ('conv2', planes, planes, 3), ('conv3', planes, planes * 4, 1)):
-        sd[f'{pre}.{name}.layer.0.weight'] = rnd(hash(name) % 1000, co, ci, k, k, std=(2.0 / (ci * k * k))**0.5)
+        sd[f'{pre}.{name}.layer.0.weight'] = rnd(zlib.crc32(name.encode()) % 1000, co, ci, k, k, std=(2.0 / (ci * k * k))**0.5)
         bn_entries(sd, f'{pre}.{name}', co, 7 + len(name))
     if stride != 1 or cin != planes * 4:
         sd[f'{pre}.downsample_conv.layer.0.weight'] = rnd(5, planes * 4, cin, 1, 1, std=(2.0 / cin)**0.5)

@@ -168,6 +168,18 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     assert float((dw.cpu() - wr.grad).abs().max()) <= 5e-5 * float(wr.grad.abs().max())
 
 
+def test_conv_split_plan_stays_inside_workspace(ops):
+    """Regression: 392 output tiles on 512 persistent workgroups (layer4.0.conv2 of the bs-256 classifier).  The
+    split-K planner once preferred 5 K-slices per tile = 1960 partial slabs for a 512-slab workspace."""
+    x = rnd(1, 256, 512, 14, 14)
+    wt = rnd(2, 512, 512, 3, 3, std=(1.0 / (512 * 9))**0.5)
+    yr = F.conv2d(x, wt, None, 2, 1)
+    guard = torch.zeros(1 << 20, device='cuda')  # likely neighbour of a freshly grown workspace
+    y = ops.conv_gemm([nhwc(x)], ops.pack_weight(wt.cuda(), ops.PACK_FWD), 512, 3, 3, 2, 1, 0, [(7, 7)])[0]
+    assert float((nchw(y) - yr).abs().max()) <= 2e-5 * float(yr.abs().max())
+    assert float(guard.abs().max()) == 0.0
+
+
 def test_conv_epilogues_and_grouping(ops):
     """relu / sigmoid / mask / accumulate epilogues and a 5-problem grouped launch (shared weights)."""
     cin, cout, k = 64, 96, 3

@@ -31,10 +31,15 @@ CASES = [
     ('l1_1x1_256_64', [(2, 200, 334)], 256, 64, 1, 1, 0),
     ('l2_3x3_128', [(2, 100, 167)], 128, 128, 3, 1, 1),
     ('l2_1x1_512_128', [(2, 100, 167)], 512, 128, 1, 1, 0),
+    ('l2_1x1_128_512', [(2, 100, 167)], 128, 512, 1, 1, 0),
     ('l3_3x3_256', [(2, 50, 84)], 256, 256, 3, 1, 1),
+    ('l3_1x1_1024_256', [(2, 50, 84)], 1024, 256, 1, 1, 0),
     ('l3_1x1_256_1024', [(2, 50, 84)], 256, 1024, 1, 1, 0),
     ('l4_3x3_512', [(2, 25, 42)], 512, 512, 3, 1, 1),
     ('l4_1x1_2048_512', [(2, 25, 42)], 2048, 512, 1, 1, 0),
+    ('l4_1x1_512_2048', [(2, 25, 42)], 512, 2048, 1, 1, 0),
+    ('fpn_p5_3x3', [(2, 25, 42)], 256, 256, 3, 1, 1),
+    ('fpn_p4_3x3', [(2, 50, 84)], 256, 256, 3, 1, 1),
     ('balanced_3x3_256', [(4, 128, 128)], 256, 256, 3, 1, 1),
 ]
 which = sys.argv[1:] or None

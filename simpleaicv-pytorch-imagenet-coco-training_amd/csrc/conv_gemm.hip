@@ -21,6 +21,7 @@
 // LDS image [row][36] floats: ds_write_b128 per 8-lane row group and ds_read_b128 per lane are
 // both bank-conflict free (row stride 36 dwords = 9 x 16 B, 9 odd).
 #include "sacv_common.h"
+#include <stdlib.h>
 
 #define SACV_MAXP 8
 #ifndef SACV_SGB_VALU
@@ -60,11 +61,15 @@ struct ConvArgs {
   int kh0, khs, kw0, kws, KWr;
   int mode;
   int flags;
-  // persistent schedule (hybrid data-parallel + split-K):
+  // persistent schedule (hybrid data-parallel + stream-K):
   //   phase 1: block b owns whole tiles b, b+grid, ... (base rounds)
-  //   phase 2: the remaining rem_tiles (< grid) tiles are each split along K over bpt blocks
-  //            whose partial accumulators go to `partial` and are summed by conv_fixup_kernel
-  int grid, base, rem_tiles, bpt;
+  //   phase 2: the remaining rem_tiles (< grid) tiles are laid end to end as rem_tiles*KT K-iterations and cut
+  //            into sk_blocks equal contiguous ranges, one per block (stream-K): a range is the tail of one tile
+  //            and/or the head of the next (never more: sk_blocks >= rem_tiles).  A range that is a whole tile is
+  //            finished in place; partial accumulators go to slab 2*b + s of `partial` (segment s of block b) and
+  //            conv_fixup_kernel sums the slabs of each tile in block order (= K order, deterministic).
+  //            Every workgroup gets the same number of K-iterations, so all CUs finish together.
+  int grid, base, rem_tiles, sk_blocks;
   float* partial;  // [slots][BM][BN] row-major K-slice tiles
   float* stats;    // [total_mtiles][2][N] column sum / sum of squares (CF_STATS)
 };
@@ -158,6 +163,11 @@ __device__ __forceinline__ void vec_epilogue(const ConvArgs& a, const TileCoord&
   }
 }
 
+// first K-iteration (in the end-to-end numbering of the remainder tiles) of stream-K block b
+__device__ __forceinline__ int sk_range_begin(const ConvArgs& a, int KT, int b) {
+  return (int)(((long long)b * a.rem_tiles * KT) / a.sk_blocks);
+}
+
 template <int BM, int BN, int MODE, int WN>
 __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a) {
   constexpr int LS = 36;
@@ -180,9 +190,14 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
   const int KT = a.KH * a.KW * cpt;
   const int smask = (1 << a.stride_log2) - 1;
 
-  // segments of this block: `base` whole tiles, then at most one K-slice of a remainder tile
-  const int nrem = a.rem_tiles * a.bpt;
-  const int nseg = a.base + (bid < nrem ? 1 : 0);
+  // segments of this block: `base` whole tiles, then its stream-K range (parts of at most two remainder tiles)
+  int sk_u0 = 0, sk_u1 = 0, nsk = 0;
+  if (bid < a.sk_blocks) {
+    sk_u0 = sk_range_begin(a, KT, bid);
+    sk_u1 = sk_range_begin(a, KT, bid + 1);
+    if (sk_u1 > sk_u0) nsk = (sk_u1 > (sk_u0 / KT + 1) * KT) ? 2 : 1;
+  }
+  const int nseg = a.base + nsk;
   if (nseg == 0) return;
 
   // per-thread gather state of the CURRENT segment.  All offsets are 32-bit element indices (tensors are
@@ -209,11 +224,14 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
       k_end = KT;
       slot = -1;
     } else {
-      int rt = bid / a.bpt, part = bid - rt * a.bpt;
+      const int s = sidx - a.base;  // 0: first tile of the stream-K range, 1: the next tile
+      const int t0 = sk_u0 / KT;
+      const int rt = t0 + s;
       tile = a.base * a.grid + rt;
-      k_begin = (int)(((long long)part * KT) / a.bpt);
-      k_end = (int)(((long long)(part + 1) * KT) / a.bpt);
-      slot = (a.bpt > 1) ? bid : -1;
+      k_begin = s ? 0 : sk_u0 - t0 * KT;
+      k_end = sk_u1 - rt * KT;
+      if (k_end > KT) k_end = KT;
+      slot = (k_begin == 0 && k_end == KT) ? -1 : 2 * bid + s;
     }
     cur_tile = tile;
     tc = tile_coord<BM, BN>(a, tile);
@@ -457,22 +475,44 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
   }
 }
 
-// Sums the K-slices of each split tile in a fixed order (deterministic) and applies the epilogue.
+// Sums the stream-K slabs of each remainder tile in block order (deterministic) and applies the epilogue.
 template <int BM, int BN>
 __global__ __launch_bounds__(1024) void conv_fixup_kernel(const ConvArgs a) {
   __shared__ __attribute__((aligned(16))) float red[2 * (1024 / (BN / 4)) * BN];
+  __shared__ int slab_of[256];
+  __shared__ int nparts_s;
   const int rt = blockIdx.x;
   const int ntn = (a.N + BN - 1) / BN;
+  const int KT = a.KH * a.KW * ((a.Cs + 31) >> 5);
   const int tile = a.base * a.grid + rt;
+  // blocks whose ranges hold the first and the last K-iteration of this tile
+  const int u_first = rt * KT, u_last = u_first + KT - 1;
+  const long long U = (long long)a.rem_tiles * KT;
+  int b_first = (int)(((long long)u_first * a.sk_blocks) / U);
+  while (sk_range_begin(a, KT, b_first + 1) <= u_first) ++b_first;
+  while (sk_range_begin(a, KT, b_first) > u_first) --b_first;
+  int b_last = (int)(((long long)u_last * a.sk_blocks) / U);
+  while (sk_range_begin(a, KT, b_last + 1) <= u_last) ++b_last;
+  while (sk_range_begin(a, KT, b_last) > u_last) --b_last;
+  if (b_first == b_last) return;  // one block held the whole tile and finished it in place
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int b = b_first; b <= b_last && n < 256; ++b) {
+      const int ub = sk_range_begin(a, KT, b);
+      if (sk_range_begin(a, KT, b + 1) == ub) continue;
+      slab_of[n++] = 2 * b + ((ub / KT == rt) ? 0 : 1);
+    }
+    nparts_s = n;
+  }
+  __syncthreads();
+  const int nparts = nparts_s;
   const TileCoord tc = tile_coord<BM, BN>(a, tile);
-  const float* base = a.partial + (size_t)rt * a.bpt * (BM * BN);
-  const int bpt = a.bpt;
   vec_epilogue<BM, BN, 1024>(
       a, tc, tile / ntn,
       [&](int row, int c4) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int part = 0; part < bpt; ++part)
-          v += *reinterpret_cast<const f32x4*>(base + (size_t)part * (BM * BN) + row * BN + c4 * 4);
+        for (int part = 0; part < nparts; ++part)
+          v += *reinterpret_cast<const f32x4*>(a.partial + (size_t)slab_of[part] * (BM * BN) + row * BN + c4 * 4);
         return v;
       },
       red);
@@ -859,42 +899,69 @@ static int num_cus() {
 #endif
 
 struct NtPlan {
-  int base, rem, bpt;
+  int base, rem, sk_blocks;
   double cost;  // in units of one 128x128 K-iteration
 };
 
+#ifndef SACV_SK_MIN_ITERS
+#define SACV_SK_MIN_ITERS 4  // a stream-K range shorter than this is not worth its slab + fix-up
+#endif
+
 // Schedule of `tiles` equal tiles of KT K-iterations on `grid` persistent workgroups.  w = relative cost of
-// one K-iteration of this tile shape (1.0 for 128x128, ~0.6 for 128x64).  max_slots = partial-tile slabs the
-// split-K workspace holds for this tile shape (sacv_conv2d_gemm_workspace_bytes / tile bytes).
-static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w, int max_slots) {
+// one K-iteration of this tile shape (1.0 for 128x128, ~0.6 for 128x64).  The split-K workspace holds two
+// slabs per workgroup (sacv_conv2d_gemm_workspace_bytes).
+static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w) {
   const double epi = 3.0, epi_split = 7.0;  // epilogue / slab write + fix-up, in K-iterations
   NtPlan p;
   p.base = tiles / grid;
   p.rem = tiles - p.base * grid;
-  p.bpt = 1;
+  p.sk_blocks = 0;
   if (p.rem == 0) {
     p.cost = p.base * (KT + epi) * w;
     return p;
   }
-  int best = 1;
-  double best_c = (KT + epi);
-  if (has_ws) {
-    int max_bpt = KT / 4 > 0 ? KT / 4 : 1;
-    if (max_bpt > 64) max_bpt = 64;
-    for (int b = 2; b <= max_bpt; ++b) {
-      long long blocks = (long long)p.rem * b;
-      if (p.base > 0 && blocks > grid) break;          // phase 2 of a multi-round launch: one slice per workgroup
-      if (blocks > 4LL * grid || blocks > max_slots) break;  // every split block owns one workspace slab
-      int rounds = (int)((blocks + grid - 1) / grid);  // base == 0 may oversubscribe (plain extra rounds)
-      double c = rounds * ((KT + b - 1) / b + epi_split);
-      if (c < best_c) {
-        best_c = c;
-        best = b;
+  // candidates for the remainder tiles (cost in K-iterations per workgroup):
+  //   one workgroup per tile                      KT + epi
+  //   uniform split, j slices per tile (rem*j<=grid)  ceil(KT/j) + epi_split
+  //   stream-K over all workgroups                ceil(rem*KT/grid) + epi_split + sk_extra
+  // Stream-K equalises the work of every CU but costs a second (partial) epilogue in the workgroups whose
+  // range crosses a tile boundary and more slabs per tile in the fix-up: measured ~+12 us per launch
+  // (~6 K-iterations) over a uniform split, so it wins on the long-K problems (3x3 convs, head towers).
+  static int policy = -1;
+  static double sk_extra = 6.0;
+  if (policy < 0) {
+    const char* e = getenv("SACV_SK_POLICY");  // tuning: 0 none, 1 uniform only, 2 stream-K only, 3 auto
+    policy = e ? atoi(e) : 3;
+    const char* x = getenv("SACV_SK_EXTRA");
+    if (x) sk_extra = atof(x);
+  }
+  p.sk_blocks = p.rem;
+  double tail = KT + epi;
+  if (has_ws && policy > 0) {
+    if (policy != 2) {
+      int max_j = KT / 4 > 0 ? KT / 4 : 1;
+      if (max_j > 64) max_j = 64;
+      for (int j = 2; j <= max_j && (long long)p.rem * j <= grid; ++j) {
+        const double c = (KT + j - 1) / j + epi_split;
+        if (c < tail) {
+          tail = c;
+          p.sk_blocks = p.rem * j;
+        }
+      }
+    }
+    if (policy != 1) {
+      const long long U = (long long)p.rem * KT;
+      long long gs = grid;
+      if (U / gs < SACV_SK_MIN_ITERS) gs = U / SACV_SK_MIN_ITERS;
+      if (gs < p.rem) gs = p.rem;
+      const double c = (double)((U + gs - 1) / gs) + epi_split + sk_extra;
+      if (gs > p.rem && (c < tail || policy == 2)) {
+        tail = c;
+        p.sk_blocks = (int)gs;
       }
     }
   }
-  p.bpt = best;
-  p.cost = (p.base * (KT + epi) + best_c) * w;
+  p.cost = (p.base * (KT + epi) + tail) * w;
   return p;
 }
 
@@ -904,7 +971,7 @@ static int launch_nt(ConvArgs& a, const NtPlan& plan, float* workspace, hipStrea
   a.grid = grid;
   a.base = plan.base;
   a.rem_tiles = plan.rem;
-  a.bpt = plan.bpt;
+  a.sk_blocks = plan.sk_blocks;
   a.partial = workspace;
   size_t lds = (size_t)2 * (BM + BN) * 36 * sizeof(float);
   size_t lds_epi = ((size_t)BM * (BN + 4) + 2 * (128 * WN / (BN / 4)) * BN) * sizeof(float);
@@ -915,12 +982,12 @@ static int launch_nt(ConvArgs& a, const NtPlan& plan, float* workspace, hipStrea
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  int launch_blocks = a.base > 0 ? grid : a.rem_tiles * a.bpt;
-  SACV_CHECK_ARG(a.bpt == 1 || (long long)a.rem_tiles * a.bpt * BM * BN <= (long long)grid * 128 * 128,
-                 "conv2d_gemm: split-K plan exceeds the workspace (%d slabs)", a.rem_tiles * a.bpt);
+  int launch_blocks = a.base > 0 ? grid : a.sk_blocks;
+  SACV_CHECK_ARG(a.sk_blocks <= grid && (a.sk_blocks == 0 || a.sk_blocks >= a.rem_tiles),
+                 "conv2d_gemm: stream-K plan outside the workspace (%d ranges)", a.sk_blocks);
   hipLaunchKernelGGL((conv_nt_kernel<BM, BN, MODE, WN>), dim3(launch_blocks), dim3(128 * WN), lds, st, a);
   SACV_CHECK_LAUNCH("conv_nt_kernel");
-  if (a.rem_tiles > 0 && a.bpt > 1) {
+  if (a.sk_blocks > a.rem_tiles) {
     hipLaunchKernelGGL((conv_fixup_kernel<BM, BN>), dim3(a.rem_tiles), dim3(1024), 0, st, a);
     SACV_CHECK_LAUNCH("conv_fixup_kernel");
   }
@@ -1030,8 +1097,8 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
   const int grid = num_cus() * SACV_NT_BLOCKS_PER_CU;
   const int KT = KH * KW * ((Cs + 31) / 32);
   const bool ws = workspace != nullptr;
-  NtPlan p128 = plan_nt(tiles * ((N + 127) / 128), KT, grid, ws, 1.0, grid);
-  NtPlan p64 = plan_nt(tiles * ((N + 63) / 64), KT, grid, ws, 0.6, 2 * grid);
+  NtPlan p128 = plan_nt(tiles * ((N + 127) / 128), KT, grid, ws, 1.0);
+  NtPlan p64 = plan_nt(tiles * ((N + 63) / 64), KT, grid, ws, 0.6);
   const bool use64 = (N <= 64) || (p64.cost < p128.cost);
   if (use64)
     return mode == 0 ? launch_nt<128, 64, 0, 2>(a, p64, workspace, st) : launch_nt<128, 64, 1, 2>(a, p64, workspace, st);
@@ -1048,7 +1115,7 @@ int sacv_conv2d_gemm_stats_rows(int nprob, const int* Nb, const int* Hd, const i
 
 // Bytes of split-K workspace sacv_conv2d_gemm wants (it runs unsplit when given NULL).
 long long sacv_conv2d_gemm_workspace_bytes(void) {
-  return (long long)num_cus() * SACV_NT_BLOCKS_PER_CU * 128 * 128 * (long long)sizeof(float);
+  return 2LL * num_cus() * SACV_NT_BLOCKS_PER_CU * 128 * 128 * (long long)sizeof(float);  // 2 slabs per workgroup
 }
 
 // Workspace (bytes) needed by sacv_conv2d_wgrad for the given problem list.

@@ -68,3 +68,16 @@ def test_grad_exchange_world2():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {0: 'ok', 1: 'ok'}
+
+
+def test_stage_ranges_of_the_classifier_arena():
+    """ResNet50 classifier: fc is the 'heads' stage, layer4 the 'neck', everything else 'rest'."""
+    from sacv_amd.classification import backbones
+    from sacv_amd.detection.models._arena import ParamArena
+    from sacv_amd.parallel import stage_ranges
+    arena = ParamArena(backbones.__dict__['resnet50'](num_classes=1000))
+    r = stage_ranges(arena.order, arena.offsets, arena.numel, arena.split)
+    assert r['rest'][0] == 0 and r['rest'][1] == r['neck'][0] and r['neck'][1] == r['heads'][0]
+    assert r['heads'] == (arena.offsets['fc.weight'], arena.numel)
+    assert r['neck'][0] == arena.offsets['layer4.0.conv1.layer.0.weight']
+    assert arena.split % 4 == 0 and arena.numel % 4 == 0

@@ -94,11 +94,12 @@ int sacv_bn_finalize_stats(const float* partial, int nblocks, int R, int C, floa
 int sacv_bn_apply(const float* y, const float* mean, const float* invstd_or_var, const float* gamma,
                   const float* beta, const float* residual, float* z, long long numel, int C, int relu,
                   int stat_is_var, float eps, void* stream);
-/* zmask != NULL fuses the ReLU backward (resnet.py:42, :153); g_out receives the masked upstream
- * gradient (the residual branch's gradient). */
+/* zmask != NULL fuses the ReLU backward (resnet.py:42, :153); with zmask == NULL and beta != NULL the ReLU mask
+ * is recomputed from y (output = relu(bn(y)), no residual), which saves reading z; g_out receives the masked
+ * upstream gradient (the residual branch's gradient). */
 int sacv_bn_train_bwd(const float* dz, const float* zmask, const float* y, const float* mean, const float* invstd,
-                      const float* gamma, float* dy, float* g_out, float* dgamma, float* dbeta, int R, int C,
-                      int accumulate, float* workspace, void* stream);
+                      const float* gamma, const float* beta, float* dy, float* g_out, float* dgamma, float* dbeta,
+                      int R, int C, int accumulate, float* workspace, void* stream);
 
 /* ---- GroupNorm(32, C) + ReLU of the FCOS head towers (detection/models/head.py:110,125) --------------- */
 long long sacv_gn_workspace_floats(int N, int HW, int C);

@@ -28,7 +28,7 @@ SIGNATURES = {
     'sacv_bn_workspace_floats': (LL, [I, I]),
     'sacv_bn_train_stats': (I, [P, I, I, F, F, P, P, P, P, P, P, P]),
     'sacv_bn_apply': (I, [P, P, P, P, P, P, P, LL, I, I, I, F, P]),
-    'sacv_bn_train_bwd': (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
+    'sacv_bn_train_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
     'sacv_gn_workspace_floats': (LL, [I, I, I]),
     'sacv_groupnorm_fwd': (I, [P, P, P, P, P, I, I, I, I, F, I, P, P]),
     'sacv_groupnorm_bwd': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),

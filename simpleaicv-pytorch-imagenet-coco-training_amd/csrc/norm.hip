@@ -137,12 +137,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
 }
 
-// backward partials: partial[b][0][c] = sum g, partial[b][1][c] = sum g*xhat,  g = dz * (zmask > 0)
+// backward partials: partial[b][0][c] = sum g, partial[b][1][c] = sum g*xhat,  g = dz * (z > 0).
+// The ReLU mask comes from `zmask` (the stored block output) or, when rc_beta is given, is recomputed from y
+// with the forward's own expression ((y - mean) * invstd) * gamma + beta (bit-identical: -ffp-contract=off),
+// which saves reading z (layers without a residual input).
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float* __restrict__ dz,
                                                                      const float* __restrict__ zmask,
                                                                      const float* __restrict__ y,
                                                                      const float* __restrict__ mean,
                                                                      const float* __restrict__ invstd,
+                                                                     const float* __restrict__ rc_gamma,
+                                                                     const float* __restrict__ rc_beta,
                                                                      float* __restrict__ partial, int R, int C,
                                                                      int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -154,14 +159,21 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float*
   auto accum = [&](int r, int c4, const f32x4& mu, const f32x4& is, f32x4& s, f32x4& q) {
     size_t o = (size_t)r * C + c4 * 4;
     f32x4 g = *reinterpret_cast<const f32x4*>(dz + o);
+    f32x4 v = *reinterpret_cast<const f32x4*>(y + o);
+    const f32x4 xhat = (v - mu) * is;
     if (zmask) {
       f32x4 zz = *reinterpret_cast<const f32x4*>(zmask + o);
 #pragma unroll
       for (int k = 0; k < 4; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
+    } else if (rc_beta) {
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(rc_gamma + c4 * 4);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(rc_beta + c4 * 4);
+      const f32x4 zz = xhat * ga + be;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
     }
-    f32x4 v = *reinterpret_cast<const f32x4*>(y + o);
     s += g;
-    q += g * ((v - mu) * is);
+    q += g * xhat;
   };
   if (cg >= BN_THREADS) {
     for (int c4 = tid; c4 < cg; c4 += BN_THREADS) {
@@ -224,17 +236,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
+                                                            const float* __restrict__ rc_beta,
                                                             const float* __restrict__ coef, float* __restrict__ dy,
                                                             float* __restrict__ g_out, size_t n4, int C) {
   const int cg = C >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     int c4 = (int)(i % cg) * 4;
     f32x4 g = *reinterpret_cast<const f32x4*>(dz + i * 4);
-    if (zmask) {
-      f32x4 zz = *reinterpret_cast<const f32x4*>(zmask + i * 4);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
-    }
     f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
     f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4);
     f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4);
@@ -242,6 +250,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     f32x4 mg = *reinterpret_cast<const f32x4*>(coef + c4);
     f32x4 mgx = *reinterpret_cast<const f32x4*>(coef + C + c4);
     f32x4 xhat = (v - mu) * is;
+    if (zmask) {
+      f32x4 zz = *reinterpret_cast<const f32x4*>(zmask + i * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
+    } else if (rc_beta) {
+      const f32x4 zz = xhat * ga + *reinterpret_cast<const f32x4*>(rc_beta + c4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
+    }
     f32x4 o = (g - mg - xhat * mgx) * (ga * is);
     *reinterpret_cast<f32x4*>(dy + i * 4) = o;
     if (g_out) *reinterpret_cast<f32x4*>(g_out + i * 4) = g;
@@ -318,10 +335,11 @@ int sacv_bn_apply(const float* y, const float* mean, const float* invstd_or_var,
   return SACV_OK;
 }
 
-// dz: upstream grad; zmask: block output for the ReLU mask (or null); y: conv output (pre-BN).
+// dz: upstream grad; y: conv output (pre-BN).  ReLU mask: zmask = the block output (or null); with zmask null and
+// beta non-null the mask is recomputed from y (layers whose output is relu(bn(y)), no residual).
 int sacv_bn_train_bwd(const float* dz, const float* zmask, const float* y, const float* mean, const float* invstd,
-                      const float* gamma, float* dy, float* g_out, float* dgamma, float* dbeta, int R, int C,
-                      int accumulate, float* workspace, void* stream) {
+                      const float* gamma, const float* beta, float* dy, float* g_out, float* dgamma, float* dbeta,
+                      int R, int C, int accumulate, float* workspace, void* stream) {
   SACV_CHECK_ARG(dz && y && mean && invstd && gamma && dy && dgamma && dbeta && workspace, "bn_train_bwd: null");
   SACV_CHECK_ARG(C % 4 == 0 && C > 0 && R > 0, "bn_train_bwd: bad shape");
   int rpb;
@@ -329,7 +347,7 @@ int sacv_bn_train_bwd(const float* dz, const float* zmask, const float* y, const
   hipStream_t st = (hipStream_t)stream;
   float* coef = workspace + (size_t)nb * 2 * C;
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(BN_THREADS), lds_for(C), st, dz, zmask, y, mean, invstd,
-                     workspace, R, C, rpb);
+                     gamma, zmask ? nullptr : beta, workspace, R, C, rpb);
   SACV_CHECK_LAUNCH("bn_bwd_partial");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, st,
                      workspace, nb, R, C, dgamma,
@@ -338,8 +356,8 @@ int sacv_bn_train_bwd(const float* dz, const float* zmask, const float* y, const
   size_t n4 = (size_t)R * C / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dz, zmask, y, mean, invstd, gamma, coef,
-                     dy, g_out, n4, C);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dz, zmask, y, mean, invstd, gamma,
+                     zmask ? nullptr : beta, coef, dy, g_out, n4, C);
   SACV_CHECK_LAUNCH("bn_bwd_apply");
   return SACV_OK;
 }

@@ -110,8 +110,11 @@ class DetectorEngine:
         p, g = self.p, self.g
         bn = c.prefix + '.layer.1.'
         wname = c.prefix + '.layer.0.weight'
-        dy, gm = ops.bn_train_bwd(dz, c.z if c.relu else None, c.y, c.mean, c.invstd, p[bn + 'weight'],
-                                  g[bn + 'weight'], g[bn + 'bias'], want_g=want_g)
+        # ReLU mask: layers without a residual input recompute it from y (one read of z less in both passes)
+        recompute = c.relu and not c.residual
+        dy, gm = ops.bn_train_bwd(dz, c.z if (c.relu and not recompute) else None, c.y, c.mean, c.invstd,
+                                  p[bn + 'weight'], g[bn + 'weight'], g[bn + 'bias'], want_g=want_g,
+                                  relu_beta=p[bn + 'bias'] if recompute else None)
         w = p[wname]
         cin = w.shape[1]
         self._wgrad([dy], [c.x], g[wname], cin, c.k, c.k, c.stride, c.pad)
@@ -473,8 +476,8 @@ class DetectorEngine:
         dpool = ops.maxpool_bwd(dout, ctx['pool_idx'], ctx['pool_in_shape'], 3, 2, 1)
         st = ctx['stem']
         bn = bp + 'conv1.layer.1.'
-        dy, _ = ops.bn_train_bwd(dpool, st.z, st.y, st.mean, st.invstd, self.p[bn + 'weight'], self.g[bn + 'weight'],
-                                 self.g[bn + 'bias'])
+        dy, _ = ops.bn_train_bwd(dpool, None, st.y, st.mean, st.invstd, self.p[bn + 'weight'], self.g[bn + 'weight'],
+                                 self.g[bn + 'bias'], relu_beta=self.p[bn + 'bias'])
         self._wgrad([dy], [st.x], self.g[bp + 'conv1.layer.0.weight'], 3, 1, 1, 1, 0,
                     cin_pad=ops.STEM_KPAD, dw_taps=49)
 

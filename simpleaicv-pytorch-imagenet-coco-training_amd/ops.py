@@ -231,13 +231,15 @@ def bn_apply(y, mean, invstd_or_var, gamma, beta, residual=None, relu=False, sta
     return z
 
 
-def bn_train_bwd(dz, zmask, y, mean, invstd, gamma, dgamma, dbeta, want_g=False, accumulate=False, dy_out=None):
+def bn_train_bwd(dz, zmask, y, mean, invstd, gamma, dgamma, dbeta, want_g=False, accumulate=False, dy_out=None,
+                 relu_beta=None):
+    """relu_beta (the BN bias) with zmask=None: the ReLU mask is recomputed from y instead of read from z."""
     c = y.shape[-1]
     r = y.numel() // c
     dy = dy_out if dy_out is not None else torch.empty_like(y)
     g = torch.empty_like(y) if want_g else None
-    check(lib.sacv_bn_train_bwd(_ptr(dz), _ptr(zmask), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(dy),
-                                _ptr(g), _ptr(dgamma), _ptr(dbeta), r, c, int(accumulate),
+    check(lib.sacv_bn_train_bwd(_ptr(dz), _ptr(zmask), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                _ptr(relu_beta), _ptr(dy), _ptr(g), _ptr(dgamma), _ptr(dbeta), r, c, int(accumulate),
                                 _bn_ws(r, c, y.device).data_ptr(), _stream()), 'bn_train_bwd')
     return dy, g
 

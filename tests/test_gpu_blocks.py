@@ -175,8 +175,9 @@ def test_stem_and_pool_bwd():
     pooled, idx = ops.maxpool_fwd(zz)
     assert rel_l2(nchw(pooled), out_r.detach()) <= 1e-5
     dpool = ops.maxpool_bwd(nhwc(dout), idx, tuple(zz.shape))
-    dy, _ = ops.bn_train_bwd(dpool, c.z, c.y, c.mean, c.invstd, p['backbone.conv1.layer.1.weight'],
-                             g['backbone.conv1.layer.1.weight'], g['backbone.conv1.layer.1.bias'])
+    dy, _ = ops.bn_train_bwd(dpool, None, c.y, c.mean, c.invstd, p['backbone.conv1.layer.1.weight'],
+                             g['backbone.conv1.layer.1.weight'], g['backbone.conv1.layer.1.bias'],
+                             relu_beta=p['backbone.conv1.layer.1.bias'])  # as engine._backbone_bwd does
     ops.conv_wgrad([dy], [c.x], g['backbone.conv1.layer.0.weight'], 3, 1, 1, 1, 0, cin_pad=ops.STEM_KPAD, dw_taps=49)
     for k, pr in params.items():
         assert rel_l2(g[k].cpu(), pr.grad) <= 1e-4, k

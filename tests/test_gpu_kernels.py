@@ -301,6 +301,12 @@ def test_batchnorm_train_fwd_bwd(ops, shape, relu, res):
     np.testing.assert_allclose(db.cpu().numpy(), br.grad.numpy(), rtol=2e-4, atol=2e-4)
     if res:
         assert float((nchw(g) - rr.grad).abs().max()) <= 1e-6
+    if relu and not res:
+        # the ReLU mask recomputed from y (no read of z) must reproduce the stored-z result bit for bit
+        dg2, db2 = torch.empty(c).cuda(), torch.empty(c).cuda()
+        dy2, g2 = ops.bn_train_bwd(nhwc(dz), None, yd, mean, invstd, gamma.cuda(), dg2, db2, want_g=True,
+                                   relu_beta=beta.cuda())
+        assert torch.equal(dy2, dyd) and torch.equal(g2, g) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
 def test_batchnorm_eval(ops):

@@ -64,16 +64,22 @@ long long sacv_conv2d_wgrad_workspace_bytes(int nseg, const int* Nb, const int* 
 
 /* Weight gradient dw[OIHW] (+)= sum over segments of x (*) dy, split over pixels in `chunk`-sized
  * slabs and reduced in a fixed order (deterministic).  dw_taps > 0: x is the stem im2col matrix
- * (KH = KW = 1, Cin_pad = padded K) and dw is [Cout][Cin][dw_taps]. */
+ * (KH = KW = 1, Cin_pad = padded K) and dw is [Cout][Cin][dw_taps].  dw_layout 1: dw is stored
+ * [Cout][KH][KW][Cin] (channels_last weight gradient = the forward GEMM panel order) instead of OIHW. */
 int sacv_conv2d_wgrad(int nseg, const float* const* dy, const float* const* x, const int* Nb, const int* Hx,
                       const int* Wx, const int* Ho, const int* Wo /*host arrays*/, float* dw, float* workspace,
                       int Cin, int Cin_pad, int Cout, int KH, int KW, int stride, int pad, int chunk, int accumulate,
-                      int dw_taps, void* stream);
+                      int dw_taps, int dw_layout, void* stream);
 
 /* kind 0: [Cout][KH*KW*Cin] forward panel; 1: [Cin][KH*KW*Cout] data-gradient panel;
- * 2: stem panel [Cout][Kpad] (k = tap*Cin + ci, zero padded). */
+ * 2: stem panel [Cout][Kpad] (k = tap*Cin + ci, zero padded); 3: as 1 from a channels_last ([Cout][KH][KW][Cin])
+ * source.  A channels_last weight IS its forward panel: no pack is needed for kind 0 then. */
 int sacv_pack_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW, int kind, int Kpad,
                      void* stream);
+/* every data-gradient panel of a model in one launch.  descs: device array of 32-byte records
+ * {const float* src; float* dst; int Cout, Cin, T, src_ohwi}; chunk_map: device int[nchunks][2] =
+ * (record index, index of a 1024-element chunk of that weight). */
+int sacv_pack_dgrad_batched(const void* descs, const int* chunk_map, int nchunks, void* stream);
 
 /* im2col of the 7x7/s2 stem (backbones/resnet.py:42-49).  x is addressed by element strides, so both
  * NCHW-contiguous and the collater's channels_last images (detection/common.py:262-268) are accepted. */

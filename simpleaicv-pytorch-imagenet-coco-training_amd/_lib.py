@@ -22,7 +22,8 @@ SIGNATURES = {
     'sacv_colsum_finalize': (I, [P, I, I, I, P, I, P]),
     'sacv_conv2d_gemm_workspace_bytes': (LL, []),
     'sacv_conv2d_wgrad_workspace_bytes': (LL, [I, P, P, P, I, I, I, I, I]),
-    'sacv_conv2d_wgrad': (I, [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P]),
+    'sacv_conv2d_wgrad': (I, [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    'sacv_pack_dgrad_batched': (I, [P, P, I, P]),
     'sacv_pack_weight': (I, [P, P, I, I, I, I, I, I, P]),
     'sacv_im2col_stem': (I, [P, P, I, I, I, I, LL, LL, LL, LL, I, I, I, I, I, I, I, P]),
     'sacv_bn_workspace_floats': (LL, [I, I]),

@@ -756,10 +756,15 @@ __global__ __launch_bounds__(256, 2) void conv_tn_kernel(const WgradArgs a) {
   }
 }
 
-// dw_oihw[co][ci][kh][kw] (+)= sum_s part[s][co][(kh*KW+kw)*Cin_pad + ci]   (ci < Cin)
+// source element (co, ci, tap) of a weight stored OIHW (src_ohwi = 0) or OHWI = channels_last (src_ohwi = 1)
+__device__ __forceinline__ size_t w_src_index(int co, int ci, int tap, int Cin, int T, int src_ohwi) {
+  return src_ohwi ? ((size_t)co * T + tap) * Cin + ci : ((size_t)co * Cin + ci) * T + tap;
+}
+
+// dw[co][ci][kh][kw] (OIHW; or [co][kh][kw][ci] when dw_ohwi) (+)= sum_s part[s][co][(kh*KW+kw)*Cin_pad + ci]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                             int nchunks, int Cout, int Cin, int Cin_pad, int T,
-                                                            int accumulate) {
+                                                            int accumulate, int dw_ohwi) {
   // 64 consecutive slab elements per block, 4 threads per element each summing every 4th chunk (coalesced
   // 256-byte rows), fixed-order combine through LDS: short serial chains even for hundreds of chunks.
   __shared__ float red[256];
@@ -780,7 +785,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       int tap = n2 / Cin_pad;
       int ci = n2 - tap * Cin_pad;
       if (ci < Cin) {
-        size_t o = ((size_t)co * Cin + ci) * T + tap;
+        size_t o = w_src_index(co, ci, tap, Cin, T, dw_ohwi);
         dw[o] = accumulate ? dw[o] + t : t;
       }
     }
@@ -803,7 +808,8 @@ __global__ void pack_w_fwd_kernel(const float* __restrict__ w, float* __restrict
     wf[idx] = w[((size_t)co * Cin + ci) * T + tap];
   }
 }
-__global__ void pack_w_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wd, int Cout, int Cin, int T) {
+__global__ void pack_w_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wd, int Cout, int Cin, int T,
+                                    int src_ohwi) {
   size_t total = (size_t)Cout * Cin * T;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (size_t)gridDim.x * blockDim.x) {
@@ -811,7 +817,30 @@ __global__ void pack_w_dgrad_kernel(const float* __restrict__ w, float* __restri
     size_t q = idx / Cout;
     int tap = (int)(q % T);
     int ci = (int)(q / T);
-    wd[idx] = w[((size_t)co * Cin + ci) * T + tap];
+    wd[idx] = w[w_src_index(co, ci, tap, Cin, T, src_ohwi)];
+  }
+}
+// all data-gradient panels of a model in ONE launch: chunk_map[b] = (descriptor, first 1024-element chunk)
+struct PackDesc {
+  const float* src;
+  float* dst;
+  int Cout, Cin, T, src_ohwi;
+};
+__global__ __launch_bounds__(256) void pack_dgrad_batched_kernel(const PackDesc* __restrict__ descs,
+                                                                  const int* __restrict__ chunk_map) {
+  const int di = chunk_map[2 * blockIdx.x], chunk = chunk_map[2 * blockIdx.x + 1];
+  const PackDesc d = descs[di];
+  const size_t total = (size_t)d.Cout * d.Cin * d.T;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    size_t idx = (size_t)chunk * 1024 + e * 256 + threadIdx.x;
+    if (idx < total) {
+      int co = (int)(idx % d.Cout);
+      size_t q = idx / d.Cout;
+      int tap = (int)(q % d.T);
+      int ci = (int)(q / d.T);
+      d.dst[idx] = d.src[w_src_index(co, ci, tap, d.Cin, d.T, d.src_ohwi)];
+    }
   }
 }
 // stem panel: wf[co][k], k = (kh*KW+kw)*Cin + ci for k < T*Cin, zero up to Kpad
@@ -1131,7 +1160,8 @@ long long sacv_conv2d_wgrad_workspace_bytes(int nseg, const int* Nb, const int* 
 int sacv_conv2d_wgrad(int nseg, const float* const* dy, const float* const* x, const int* Nb, const int* Hx,
                       const int* Wx, const int* Ho, const int* Wo, float* dw, float* workspace, int Cin, int Cin_pad,
                       int Cout, int KH, int KW, int stride, int pad, int chunk, int accumulate, int dw_taps,
-                      void* stream) {
+                      int dw_layout, void* stream) {
+  SACV_CHECK_ARG(dw_layout == 0 || (dw_layout == 1 && dw_taps == 0), "conv2d_wgrad: dw_layout");
   SACV_CHECK_ARG(nseg >= 1 && nseg <= SACV_MAXP, "conv2d_wgrad: nseg");
   SACV_CHECK_ARG(Cin_pad % 4 == 0 && Cout % 4 == 0, "conv2d_wgrad: channels must be multiples of 4");
   SACV_CHECK_ARG(chunk % 32 == 0 && chunk > 0, "conv2d_wgrad: chunk must be a multiple of 32");
@@ -1185,7 +1215,7 @@ int sacv_conv2d_wgrad(int nseg, const float* const* dy, const float* const* x, c
                        dw_taps, Cin_pad, accumulate);
   } else {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw, chunks, Cout, Cin, Cin_pad,
-                       T, accumulate);
+                       T, accumulate, dw_layout);
   }
   SACV_CHECK_LAUNCH("wgrad_reduce_kernel");
   return SACV_OK;
@@ -1201,7 +1231,9 @@ int sacv_pack_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH,
   if (kind == 0)
     hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(blocks), dim3(256), 0, st, w_oihw, out, Cout, Cin, KH * KW);
   else if (kind == 1)
-    hipLaunchKernelGGL(pack_w_dgrad_kernel, dim3(blocks), dim3(256), 0, st, w_oihw, out, Cout, Cin, KH * KW);
+    hipLaunchKernelGGL(pack_w_dgrad_kernel, dim3(blocks), dim3(256), 0, st, w_oihw, out, Cout, Cin, KH * KW, 0);
+  else if (kind == 3)  // data-gradient panel from a channels_last (OHWI) weight
+    hipLaunchKernelGGL(pack_w_dgrad_kernel, dim3(blocks), dim3(256), 0, st, w_oihw, out, Cout, Cin, KH * KW, 1);
   else if (kind == 2) {
     SACV_CHECK_ARG(Kpad >= Cin * KH * KW, "pack_weight: Kpad too small");
     hipLaunchKernelGGL(pack_w_stem_kernel, dim3(sacv_cdiv((long long)Cout * Kpad, 256)), dim3(256), 0, st, w_oihw,
@@ -1211,6 +1243,17 @@ int sacv_pack_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH,
     return SACV_ERR_ARG;
   }
   SACV_CHECK_LAUNCH("pack_weight");
+  return SACV_OK;
+}
+
+// descs: device array of {const float* src; float* dst; int Cout, Cin, T, src_ohwi} (32 bytes each);
+// chunk_map: device int[nchunks][2] = (descriptor index, 1024-element chunk index within that weight)
+int sacv_pack_dgrad_batched(const void* descs, const int* chunk_map, int nchunks, void* stream) {
+  SACV_CHECK_ARG(descs && chunk_map && nchunks > 0, "pack_dgrad_batched: bad args");
+  static_assert(sizeof(PackDesc) == 32, "PackDesc layout is part of the ABI");
+  hipLaunchKernelGGL(pack_dgrad_batched_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
+                     (const PackDesc*)descs, chunk_map);
+  SACV_CHECK_LAUNCH("pack_dgrad_batched");
   return SACV_OK;
 }
 

@@ -42,10 +42,10 @@ class ParamArena:
         with torch.no_grad():
             for n, p in self.order:
                 o = self.offsets[n]
-                view = self.params[o:o + p.numel()].view(p.shape)
+                view = self._view(self.params[o:o + p.numel()], p.shape)
                 view.copy_(p.data)
                 p.data = view
-                self.grad_views[n] = self.grads[o:o + p.numel()].view(p.shape)
+                self.grad_views[n] = self._view(self.grads[o:o + p.numel()], p.shape)
                 self._ptrs[n] = view.data_ptr()
         self.module_params = dict(self.order)
         # floating-point buffers (BatchNorm running statistics) in one flat block as well
@@ -62,6 +62,18 @@ class ParamArena:
                 owner, _, leaf = n.rpartition('.')
                 modules[owner]._buffers[leaf] = view
                 off += _pad4(b.numel())
+
+    @staticmethod
+    def _view(flat, shape):
+        """Logical-shape view of one tensor's arena slice.  k x k (k > 1) conv weights with Cin % 4 == 0 are
+        STORED channels_last ([Cout][KH][KW][Cin]): that is the forward implicit-GEMM panel, so the conv kernels
+        read the master weights in place (no per-step repack) and the weight-gradient reduction writes the same
+        order.  The parameter keeps its OIHW shape (a strided view), so state_dict()/load_state_dict()/p.grad
+        are unchanged for the caller; the optimizer and the all-reduce are elementwise and layout-agnostic."""
+        if len(shape) == 4 and shape[2] * shape[3] > 1 and shape[1] % 4 == 0:
+            co, ci, kh, kw = shape
+            return flat.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return flat.view(shape)
 
     def is_current(self):
         """False when something (.to(), .cuda(), load via assignment) re-allocated a parameter."""

@@ -50,6 +50,7 @@ class DetectorEngine:
         self.use_side_stream = False
         self.side = None
         self._keep = []
+        self._panels = None  # data-gradient weight panels, refreshed by one launch per training step
 
     def _wgrad(self, dys, xs, dw, cin, kh, kw, stride, pad, **kw_args):
         if not self.use_side_stream:
@@ -64,6 +65,24 @@ class DetectorEngine:
             ops.conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, **kw_args)
         self._keep.append((dys, xs))  # keep the operands alive until the side stream is joined
 
+    def _dgrad_panel(self, w):
+        """[Cin][KH*KW*Cout] panel of a weight: from the batched per-step refresh when the weight is one of the
+        model's parameters, packed on the spot otherwise (composite weights, unit tests)."""
+        if self._panels is not None:
+            pnl = self._panels.get(w)
+            if pnl is not None:
+                return pnl
+        return ops.pack_weight(w, PACK_DGRAD)
+
+    def _refresh_dgrad_panels(self):
+        if self._panels is None or not self._panels.is_current():
+            stem = self.bp + 'conv1.layer.0.weight'
+            ws = [t for k, t in self.p.items() if k.endswith('.weight') and t.ndim == 4 and k != stem
+                  and t.dtype == torch.float32]
+            self._panels = ops.DgradPanels(ws) if ws else None
+        if self._panels is not None:
+            self._panels.refresh()
+
     def _join_side(self):
         if self.use_side_stream and self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
@@ -74,7 +93,7 @@ class DetectorEngine:
         p = self.p
         w = p[prefix + '.layer.0.weight']
         cout = w.shape[0]
-        wp = ops.pack_weight(w, PACK_FWD)
+        wp = ops.fwd_panel(w)
         hw = _out_hw(x.shape[1], x.shape[2], k, stride, pad)
         if training:  # batch statistics come out of the conv epilogue (no extra pass over y)
             (y,), st = ops.conv_gemm([x], wp, cout, k, k, stride, pad, 0, [hw], stats=True)
@@ -125,7 +144,7 @@ class DetectorEngine:
 
     def _dgrad(self, dy, w, x_shape, k, stride, pad, out=None, accumulate=False, mask=None):
         cin = w.shape[1]
-        wd = ops.pack_weight(w, PACK_DGRAD)
+        wd = self._dgrad_panel(w)
         n, h, wdt, _ = x_shape
         flags = (CF_ACCUM if accumulate else 0) | (CF_MASK if mask is not None else 0)
         if k == 1 and stride > 1:
@@ -171,6 +190,8 @@ class DetectorEngine:
     def forward(self, images, training=True, keep=True):
         """images: logical [B,3,H,W] fp32 (any strides).  Returns (cls_levels, reg_levels)."""
         ctx = {} if keep else None
+        if keep:
+            self._refresh_dgrad_panels()
         feats = self._backbone_fwd(images, training, keep, ctx)
         c3f, c4f, c5f = feats[1], feats[2], feats[3]
         fpn = self._fpn_fwd(c3f, c4f, c5f, ctx)
@@ -226,7 +247,7 @@ class DetectorEngine:
 
     def _conv_bias(self, x, name, k, stride, pad, flags=0):
         w = self.p[name + '.weight']
-        wp = ops.pack_weight(w, PACK_FWD)
+        wp = ops.fwd_panel(w)
         hw = _out_hw(x.shape[1], x.shape[2], k, stride, pad)
         return ops.conv_gemm([x], wp, w.shape[0], k, k, stride, pad, 0, [hw], bias=self.p[name + '.bias'],
                              flags=flags)[0]
@@ -254,11 +275,11 @@ class DetectorEngine:
         saved = []
         for i in (0, 2, 4, 6):
             name = f'{tower}.{i}'
-            wp = ops.pack_weight(p[name + '.weight'], PACK_FWD)
+            wp = ops.fwd_panel(p[name + '.weight'])
             saved.append(xs)
             xs = ops.conv_gemm(xs, wp, self.planes, 3, 3, 1, 1, 0, hw, bias=p[name + '.bias'], flags=CF_RELU)
         saved.append(xs)
-        wp = ops.pack_weight(p[out_name + '.weight'], PACK_FWD)
+        wp = ops.fwd_panel(p[out_name + '.weight'])
         outs = ops.conv_gemm(xs, wp, n_out, 3, 3, 1, 1, 0, hw, bias=p[out_name + '.bias'], flags=out_flags)
         if ctx is not None:
             ctx[tower] = saved
@@ -286,7 +307,7 @@ class DetectorEngine:
         saved = []
         for i in (0, 3, 6, 9):
             w = p[f'{tower}.{i}.weight']
-            ys = ops.conv_gemm(xs, ops.pack_weight(w, PACK_FWD), self.planes, 3, 3, 1, 1, 0, hw)
+            ys = ops.conv_gemm(xs, ops.fwd_panel(w), self.planes, 3, 3, 1, 1, 0, hw)
             zs, sts = [], []
             for y in ys:
                 z, st = ops.groupnorm_fwd(y, p[f'{tower}.{i + 1}.weight'], p[f'{tower}.{i + 1}.bias'], 32, 1e-5, True)
@@ -314,10 +335,10 @@ class DetectorEngine:
         cls_x = self._gn_tower_fwd(feats, 'clsregcnt_head.cls_head', ctx)
         reg_x = self._gn_tower_fwd(feats, 'clsregcnt_head.reg_head', ctx)
         w = p['clsregcnt_head.cls_out.weight']
-        cls = ops.conv_gemm(cls_x, ops.pack_weight(w, PACK_FWD), w.shape[0], 3, 3, 1, 1, 0, hw,
+        cls = ops.conv_gemm(cls_x, ops.fwd_panel(w), w.shape[0], 3, 3, 1, 1, 0, hw,
                             bias=p['clsregcnt_head.cls_out.bias'], flags=CF_SIGMOID)
         w8, b8 = self._fcos_w8()
-        y8 = ops.conv_gemm(reg_x, ops.pack_weight(w8, PACK_FWD), 8, 3, 3, 1, 1, 0, hw, bias=b8)
+        y8 = ops.conv_gemm(reg_x, ops.fwd_panel(w8), 8, 3, 3, 1, 1, 0, hw, bias=b8)
         regs, ctrs = [], []
         for l, y in enumerate(y8):
             r, c = ops.fcos_split_fwd(y, p['scales'][l:l + 1])
@@ -340,7 +361,7 @@ class DetectorEngine:
             w = p[f'{tower}.{i}.weight']
             self._wgrad(dys, xs, g[f'{tower}.{i}.weight'], w.shape[1], 3, 3, 1, 1)
             hw = [(x.shape[1], x.shape[2]) for x in xs]
-            wd = ops.pack_weight(w, PACK_DGRAD)
+            wd = self._dgrad_panel(w)
             if li == 0 and accum_into is not None:
                 cur = ops.conv_gemm(dys, wd, w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_ACCUM, outs=accum_into)
             else:
@@ -357,7 +378,7 @@ class DetectorEngine:
         w = p['clsregcnt_head.cls_out.weight']
         self._wgrad(dz_cls, o['cls_x'], g['clsregcnt_head.cls_out.weight'], w.shape[1], 3, 3, 1, 1)
         self._bias_grad(dz_cls, 'clsregcnt_head.cls_out')
-        d_cls_x = ops.conv_gemm(dz_cls, ops.pack_weight(w, PACK_DGRAD), w.shape[1], 3, 3, 1, 1, 1, hw)
+        d_cls_x = ops.conv_gemm(dz_cls, self._dgrad_panel(w), w.shape[1], 3, 3, 1, 1, 1, hw)
         dfeat = self._gn_tower_bwd(d_cls_x, 'clsregcnt_head.cls_head')
         # regression + centerness branch (8-channel combined output conv)
         dy8 = [ops.fcos_split_bwd(dr.contiguous(), dc.contiguous(), r, c, p['scales'][l:l + 1], g['scales'], l,
@@ -372,7 +393,7 @@ class DetectorEngine:
             ops.colsum(d, 8, db8, accumulate=l > 0)
         g['clsregcnt_head.reg_out.bias'].copy_(db8[0:4])
         g['clsregcnt_head.center_out.bias'].copy_(db8[4:5])
-        d_reg_x = ops.conv_gemm(dy8, ops.pack_weight(o['w8'], PACK_DGRAD), self.planes, 3, 3, 1, 1, 1, hw)
+        d_reg_x = ops.conv_gemm(dy8, self._dgrad_panel(o['w8']), self.planes, 3, 3, 1, 1, 1, hw)
         return self._gn_tower_bwd(d_reg_x, 'clsregcnt_head.reg_head', accum_into=dfeat)
 
     # ------------------------------------------------------------------ backward
@@ -395,7 +416,7 @@ class DetectorEngine:
         self._wgrad(dys, xs, g[out_name + '.weight'], w.shape[1], 3, 3, 1, 1)
         self._bias_grad(dys, out_name)
         hw = [(x.shape[1], x.shape[2]) for x in xs]
-        cur, st = ops.conv_gemm(dys, ops.pack_weight(w, PACK_DGRAD), w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_MASK,
+        cur, st = ops.conv_gemm(dys, self._dgrad_panel(w), w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_MASK,
                                 masks=xs, stats=True)
         for li, i in reversed(list(enumerate((0, 2, 4, 6)))):
             name = f'{tower}.{i}'
@@ -403,7 +424,7 @@ class DetectorEngine:
             xs = saved[li]
             self._wgrad(cur, xs, g[name + '.weight'], w.shape[1], 3, 3, 1, 1)
             ops.colsum_finalize(st, g[name + '.bias'])
-            wd = ops.pack_weight(w, PACK_DGRAD)
+            wd = self._dgrad_panel(w)
             if li > 0:
                 cur, st = ops.conv_gemm(cur, wd, w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_MASK, masks=xs, stats=True)
             elif accum_into is not None:
@@ -534,10 +555,12 @@ class ClassifierEngine(DetectorEngine):
     def forward(self, images, training=True, keep=True):
         """images logical [B,3,H,W] -> logits [B, num_classes]"""
         ctx = {} if keep else None
+        if keep:
+            self._refresh_dgrad_panels()
         c5 = self._backbone_fwd(images, training, keep, ctx)[3]
         pooled = ops.avgpool_fwd(c5)
         w = self.p['fc.weight']
-        wp = ops.pack_weight(w.view(w.shape[0], w.shape[1], 1, 1), PACK_FWD)
+        wp = ops.fwd_panel(w.view(w.shape[0], w.shape[1], 1, 1))
         logits = ops.conv_gemm([pooled], wp, w.shape[0], 1, 1, 1, 0, 0, [(1, 1)], bias=self.p['fc.bias'])[0]
         if keep:
             ctx['pooled'] = pooled

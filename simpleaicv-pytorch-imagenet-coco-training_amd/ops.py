@@ -61,9 +61,41 @@ def _ptr(t):
 
 
 # ------------------------------------------------------------------------------------------ conv
+def weight_layout(w):
+    """0: OIHW-contiguous, 1: channels_last storage [Cout][KH][KW][Cin] (what ParamArena gives k>1 conv weights).
+    1x1 weights are both; they report 0."""
+    if w.device.type != 'cuda' or w.dtype != torch.float32 or w.ndim != 4:
+        raise ValueError('weight: expected a 4-D fp32 CUDA(HIP) tensor')
+    if w.is_contiguous():
+        return 0
+    if w.permute(0, 2, 3, 1).is_contiguous():
+        return 1
+    raise ValueError(f'weight: strides {w.stride()} are neither OIHW-contiguous nor channels_last')
+
+
+def fwd_panel(w):
+    """Forward GEMM panel [Cout][KH*KW*Cin] of a conv weight: zero-copy when the weight is stored channels_last
+    (or is 1x1), otherwise packed."""
+    co, ci, kh, kw = w.shape
+    if weight_layout(w) == 1:
+        return w.permute(0, 2, 3, 1)
+    if kh * kw == 1:
+        return w
+    return pack_weight(w, PACK_FWD)
+
+
 def pack_weight(w_oihw, kind, out=None):
-    _chk(w_oihw, 'weight')
+    layout = weight_layout(w_oihw)
+    if layout == 1:
+        if kind == PACK_FWD:
+            return fwd_panel(w_oihw)
+        if kind != PACK_DGRAD:
+            raise ValueError('pack_weight: the stem panel is packed from an OIHW weight')
     co, ci, kh, kw = w_oihw.shape
+    if layout == 1:
+        out = out if out is not None else torch.empty((ci, kh * kw * co), device=w_oihw.device, dtype=torch.float32)
+        check(lib.sacv_pack_weight(_ptr(w_oihw), _ptr(out), co, ci, kh, kw, 3, 0, _stream()), 'pack_weight')
+        return out
     if kind == PACK_STEM:
         shape, kpad = (co, STEM_KPAD), STEM_KPAD
     elif kind == PACK_FWD:
@@ -156,8 +188,10 @@ def workspace(nbytes, device, tag='ws'):
 
 
 def conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, accumulate=False, cin_pad=None, dw_taps=0):
-    """dw (OIHW, contiguous view into the gradient arena) (+)= sum over problems of x (*) dy."""
+    """dw (logical OIHW view into the gradient arena, stored OIHW or channels_last) (+)= sum over problems of
+    x (*) dy."""
     n = len(dys)
+    dw_layout = weight_layout(dw) if dw.ndim == 4 else 0
     cin_pad = cin_pad or cin
     cout = dys[0].shape[3]
     nb = [d.shape[0] for d in dys]
@@ -171,7 +205,7 @@ def conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, accumulate=False, cin_pad=
         n, parr([d.data_ptr() for d in dys]), parr([x.data_ptr() for x in xs]), iarr(nb),
         iarr([x.shape[1] for x in xs]), iarr([x.shape[2] for x in xs]), iarr(ho), iarr(wo),
         _ptr(dw), ws.data_ptr(), cin, cin_pad, cout, kh, kw, stride, pad, chunk, int(accumulate), dw_taps,
-        _stream()), 'conv2d_wgrad')
+        dw_layout, _stream()), 'conv2d_wgrad')
     return dw
 
 
@@ -525,3 +559,41 @@ def softmax_ce(logits, labels, want_grad=True, grad_scale=1.0):
 def sgd_step(params, grads, momentum_buf, split, lr, momentum, wd_lo, wd_hi, first_step, grad_scale=1.0):
     check(lib.sacv_sgd_step(_ptr(params), _ptr(grads), _ptr(momentum_buf), params.numel(), split, lr, momentum,
                             wd_lo, wd_hi, int(first_step), grad_scale, _stream()), 'sgd_step')
+
+
+class DgradPanels:
+    """Data-gradient panels ([Cin][KH*KW*Cout]) of a set of conv weights, refreshed by ONE kernel launch per step
+    (the per-layer pack launches were 0.4 ms of a 42 ms step).  Buffers and the descriptor table are built once;
+    `get(w)` returns the panel of a weight by its storage address."""
+
+    def __init__(self, weights):
+        import numpy as np
+        self.dev = weights[0].device
+        self.panels = {}
+        recs = np.zeros(len(weights), dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('co', '<i4'), ('ci', '<i4'),
+                                                      ('t', '<i4'), ('ohwi', '<i4')]))
+        assert recs.dtype.itemsize == 32
+        cmap = []
+        self._keep = list(weights)
+        for i, w in enumerate(weights):
+            co, ci, kh, kw = w.shape
+            out = torch.empty((ci, kh * kw * co), device=self.dev, dtype=torch.float32)
+            self.panels[w.data_ptr()] = out
+            recs[i] = (w.data_ptr(), out.data_ptr(), co, ci, kh * kw, weight_layout(w))
+            nchunk = (w.numel() + 1023) // 1024
+            cmap.append(np.stack([np.full(nchunk, i, dtype=np.int32), np.arange(nchunk, dtype=np.int32)], axis=1))
+        cmap = np.concatenate(cmap)
+        self.nchunks = int(cmap.shape[0])
+        self.descs = torch.from_numpy(recs.view(np.uint8).copy()).to(self.dev)
+        self.cmap = torch.from_numpy(cmap.copy()).to(self.dev)
+        self.ptrs = [w.data_ptr() for w in weights]
+
+    def is_current(self):
+        return all(w.data_ptr() == p for w, p in zip(self._keep, self.ptrs))
+
+    def refresh(self):
+        check(lib.sacv_pack_dgrad_batched(self.descs.data_ptr(), self.cmap.data_ptr(), self.nchunks, _stream()),
+              'pack_dgrad_batched')
+
+    def get(self, w):
+        return self.panels.get(w.data_ptr())

@@ -71,3 +71,31 @@ def test_bench_generator_matches_fixture_generator():
     body_after = tail.split('\ndef main', 1)[1]
     assert 'oracle' not in head.replace('oracle/', '').split('import argparse')[1].split('def ')[0]
     assert 'from oracle' not in body_after and 'import oracle' not in body_after
+
+
+def test_arena_channels_last_weights_keep_the_state_dict_contract():
+    """k x k conv weights live channels_last in the flat arena (= the forward GEMM panel) but stay OIHW-shaped
+    parameters: state_dict values, load_state_dict and p.grad are unchanged for the caller."""
+    import torch
+    from sacv_amd.classification import backbones
+    from sacv_amd.detection.models._arena import ParamArena
+    from oracle import model as omodel
+    m = backbones.__dict__['resnet50'](num_classes=16)
+    sd0 = omodel.init_resnet50_cls_state(0, 16)
+    m.load_state_dict(sd0, strict=True)
+    arena = ParamArena(m)
+    w = m.layer1[0].conv2.layer[0].weight
+    assert tuple(w.shape) == (64, 64, 3, 3) and not w.is_contiguous() and w.permute(0, 2, 3, 1).is_contiguous()
+    assert m.conv1.layer[0].weight.is_contiguous()          # Cin = 3: stays OIHW (packed into the stem panel)
+    assert m.layer1[0].conv1.layer[0].weight.is_contiguous()  # 1x1: both layouts coincide
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd0[k]), k
+    # the arena slice of a 3x3 weight is the [Cout][KH][KW][Cin] panel
+    o = arena.offsets['layer1.0.conv2.layer.0.weight']
+    assert torch.equal(arena.params[o:o + w.numel()].view(64, 3, 3, 64), sd0['layer1.0.conv2.layer.0.weight'].permute(0, 2, 3, 1))
+    sd1 = {k: (v + 1 if v.dtype.is_floating_point else v) for k, v in sd0.items()}
+    m.load_state_dict(sd1, strict=True)
+    assert arena.is_current()
+    assert torch.equal(w, sd1['layer1.0.conv2.layer.0.weight'])
+    arena.attach_grads()
+    assert w.grad.shape == w.shape and w.grad.stride() == w.stride()

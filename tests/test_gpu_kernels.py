@@ -180,6 +180,32 @@ def test_conv_split_plan_stays_inside_workspace(ops):
     assert float(guard.abs().max()) == 0.0
 
 
+def test_channels_last_weight_paths(ops):
+    """A channels_last-stored weight is its own forward panel (zero copy); its data-gradient panel comes from the
+    batched one-launch pack; the weight gradient is written in the same channels_last order."""
+    wt = rnd(2, 96, 32, 3, 3)
+    w_cl = wt.cuda().permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)  # logical OIHW, stored OHWI
+    w_pl = wt.cuda()
+    assert ops.weight_layout(w_cl) == 1 and ops.weight_layout(w_pl) == 0
+    pf = ops.fwd_panel(w_cl)
+    assert pf.data_ptr() == w_cl.data_ptr()
+    assert torch.equal(pf.reshape(96, -1), ops.pack_weight(w_pl, ops.PACK_FWD))
+    ref_d = ops.pack_weight(w_pl, ops.PACK_DGRAD)
+    assert torch.equal(ops.pack_weight(w_cl, ops.PACK_DGRAD), ref_d)
+    w2 = rnd(3, 40, 64, 1, 1).cuda()
+    panels = ops.DgradPanels([w_cl, w2, w_pl])
+    panels.refresh()
+    assert torch.equal(panels.get(w_cl), ref_d) and torch.equal(panels.get(w_pl), ref_d)
+    assert torch.equal(panels.get(w2), ops.pack_weight(w2, ops.PACK_DGRAD))
+    x, dy = nhwc(rnd(4, 2, 32, 9, 11)), nhwc(rnd(5, 2, 96, 9, 11))
+    dw_pl = torch.empty_like(w_pl)
+    dw_cl = torch.empty_like(w_cl)
+    assert dw_cl.stride() == w_cl.stride()
+    ops.conv_wgrad([dy], [x], dw_pl, 32, 3, 3, 1, 1)
+    ops.conv_wgrad([dy], [x], dw_cl, 32, 3, 3, 1, 1)
+    assert torch.equal(dw_cl, dw_pl)
+
+
 def test_conv_epilogues_and_grouping(ops):
     """relu / sigmoid / mask / accumulate epilogues and a 5-problem grouped launch (shared weights)."""
     cin, cout, k = 64, 96, 3

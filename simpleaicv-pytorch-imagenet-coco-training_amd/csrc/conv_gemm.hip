@@ -864,23 +864,36 @@ __global__ void pack_w_stem_kernel(const float* __restrict__ w, float* __restric
 __global__ void im2col_stem_kernel(const float* __restrict__ x, float* __restrict__ col, int Nb, int Cin, int H,
                                    int W, long long sN, long long sC, long long sH, long long sW, int Ho, int Wo,
                                    int KH, int KW, int stride, int pad, int Kpad) {
-  size_t total = (size_t)Nb * Ho * Wo * Kpad;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (size_t)gridDim.x * blockDim.x) {
-    int k = (int)(idx % Kpad);
-    size_t m = idx / Kpad;
-    float v = 0.f;
-    if (k < KH * KW * Cin) {
-      int tap = k / Cin, ci = k - tap * Cin;
-      int kh = tap / KW, kw = tap - kh * KW;
-      int wo = (int)(m % Wo);
-      size_t q = m / Wo;
-      int ho = (int)(q % Ho);
-      int n = (int)(q / Ho);
-      int hi = ho * stride - pad + kh, wi = wo * stride - pad + kw;
-      if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = x[n * sN + ci * sC + hi * sH + wi * sW];
+  // one thread per 4 consecutive k of one output pixel: the pixel decode (two integer divisions) is shared by
+  // the four elements, the small k -> (kh, kw, ci) decodes use exact float reciprocals (k < 2^10), and the
+  // result leaves as one coalesced 16-byte store.
+  const int G = Kpad >> 2;
+  const size_t total = (size_t)Nb * Ho * Wo * G;
+  const int K = KH * KW * Cin;
+  const float rcin = 1.0f / (float)Cin, rkw = 1.0f / (float)KW;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(t % G);
+    const size_t m = t / G;
+    const int wo = (int)(m % Wo);
+    const size_t q = m / Wo;
+    const int ho = (int)(q % Ho);
+    const int n = (int)(q / Ho);
+    const float* __restrict__ src = x + n * sN;
+    const int hb = ho * stride - pad, wb = wo * stride - pad;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 4 * g + e;
+      if (k < K) {
+        const int tap = (int)(((float)k + 0.5f) * rcin);
+        const int ci = k - tap * Cin;
+        const int kh = (int)(((float)tap + 0.5f) * rkw);
+        const int kw = tap - kh * KW;
+        const int hi = hb + kh, wi = wb + kw;
+        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v[e] = src[ci * sC + hi * sH + wi * sW];
+      }
     }
-    col[idx] = v;
+    *reinterpret_cast<f32x4*>(col + t * 4) = v;
   }
 }
 
@@ -1262,7 +1275,7 @@ int sacv_im2col_stem(const float* x, float* col, int Nb, int Cin, int H, int W, 
                      void* stream) {
   SACV_CHECK_ARG(x && col, "im2col_stem: null pointer");
   SACV_CHECK_ARG(Kpad % 32 == 0 && Kpad >= Cin * KH * KW, "im2col_stem: Kpad must be a multiple of 32 >= K");
-  size_t total = (size_t)Nb * Ho * Wo * Kpad;
+  size_t total = (size_t)Nb * Ho * Wo * (Kpad / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(im2col_stem_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, col, Nb, Cin, H, W, sN,

@@ -1,0 +1,145 @@
+"""Builds profiles/rNN_* from the raw outputs of one profiling session on the GPU box (see profiles/README in the
+summary it writes for the exact commands):
+
+    python scripts/make_profile_summary.py r01 <kernel_stats.csv> <bench.json> <pmc_fetch.csv> <pmc_write.csv> \
+           [<cls_kernel_stats.csv> <cls_bench.json>]
+
+kernel_stats.csv: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2
+--no-cpu-baseline` (7 steps recorded); pmc_*.csv: the counter_collection.csv of `rocprofv3 --pmc FETCH_SIZE` and
+`--pmc WRITE_SIZE` (separate passes) over `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer`.
+"""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def read_stats(path):
+    rows = []
+    for r in csv.DictReader(open(path)):
+        rows.append((r['Name'], int(r['Calls']), float(r['TotalDurationNs']), float(r['AverageNs']), float(r['Percentage'])))
+    return rows
+
+
+def pmc_per_launch(path, counter, match):
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] == counter and match in r['Kernel_Name']:
+            tot += float(r['Counter_Value'])
+            n += 1
+    return tot, n
+
+
+def resnet50_bn_layers(B, H, W):
+    """(elements, relu, residual) of every BatchNorm output of the ResNet50 trunk."""
+    o = lambda s, k, st, p: (s + 2 * p - k) // st + 1
+    h, w = o(H, 7, 2, 3), o(W, 7, 2, 3)
+    layers = [(B * h * w * 64, True, False)]
+    h, w = o(h, 3, 2, 1), o(w, 3, 2, 1)
+    cin = 64
+    for li, (n, pl) in enumerate(zip([3, 4, 6, 3], [64, 128, 256, 512])):
+        for bi in range(n):
+            st = 2 if (bi == 0 and li > 0) else 1
+            ho, wo = o(h, 3, st, 1), o(w, 3, st, 1)
+            layers.append((B * h * w * pl, True, False))        # conv1 at the input resolution
+            layers.append((B * ho * wo * pl, True, False))      # conv2
+            layers.append((B * ho * wo * pl * 4, True, True))   # conv3 + residual
+            if st != 1 or cin != pl * 4:
+                layers.append((B * ho * wo * pl * 4, False, False))  # projection shortcut
+            cin, h, w = pl * 4, ho, wo
+    return layers
+
+
+def hbm_table(stats_by_name, steps, B, H, W, extra):
+    L = resnet50_bn_layers(B, H, W)
+    gb = lambda f: sum(f(e, relu, res) for e, relu, res in L) * 4 / 1e9
+    rows = [
+        ('bn_apply_kernel', gb(lambda e, r, s: e * (3 if s else 2)), 'read y, write z (+ the residual input of the 16 block outputs)'),
+        ('bn_bwd_partial_kernel', gb(lambda e, r, s: e * (3 if s else 2)), 'read dz, y (+ z where the ReLU follows a residual add; elsewhere the mask is recomputed from y)'),
+        ('bn_bwd_apply_kernel', gb(lambda e, r, s: e * (5 if s else 3)), 'read dz, y (+ z), write dy (+ the masked gradient copy for the residual branch)'),
+    ] + extra
+    out = []
+    for name, g, what in rows:
+        hit = [v for k, v in stats_by_name.items() if k.startswith(name)]
+        if not hit:
+            continue
+        ms = sum(h[1] for h in hit) / steps / 1e6
+        out.append(f'| `{name}` | {g:.2f} | {ms:.3f} | {g / ms:.2f} | {g / ms / 8.0:.2f} | {what} |')
+    return out
+
+
+def main():
+    tag, stats_p, bench_p, pf, pw = sys.argv[1:6]
+    steps = 7
+    prof = os.path.join(ROOT, 'profiles')
+    rows = read_stats(stats_p)
+    by = {r[0]: (r[1], r[2]) for r in rows}
+    with open(os.path.join(prof, f'{tag}_bench_kernel_stats.csv'), 'w') as f:
+        f.write(open(stats_p).read())
+    bench = json.loads([l for l in open(bench_p) if l.startswith('{')][-1])
+    # PMC traffic of the conv_nt family
+    fs, n1 = pmc_per_launch(pf, 'FETCH_SIZE', 'conv_nt_kernel')
+    ws, n2 = pmc_per_launch(pw, 'WRITE_SIZE', 'conv_nt_kernel')
+    traffic = dict(kernel='conv_nt_kernel<128,*,*>', launches=n1, fetch_size_kb_per_launch=fs / n1,
+                   write_size_kb_per_launch=ws / n2, hbm_bytes_per_launch=(2 * fs / n1 + ws / n2) * 1024,
+                   note='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 2 '
+                        '--warmup 1; gfx950 correction: FETCH_SIZE counts 64 B per 128-B request, so reads are doubled '
+                        '(MI355X_MICROARCH.md, HBM section); KB -> bytes x1024')
+    json.dump(traffic, open(os.path.join(prof, f'{tag}_pmc_traffic.json'), 'w'), indent=1)
+    bench['roofline']['traffic'] = round(traffic['hbm_bytes_per_launch'])
+    json.dump(bench, open(os.path.join(prof, f'{tag}_bench.json'), 'w'))
+    total_ms = sum(r[2] for r in rows) / steps / 1e6
+    md = [f'# Round {tag[1:]} profile summary (MI355X, 1 GPU)', '',
+          'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`',
+          f'({steps} steps recorded; raw table: `{tag}_bench_kernel_stats.csv`; un-profiled bench line with CPU baseline: `{tag}_bench.json`;',
+          f'PMC HBM-traffic passes for the conv kernel family: `{tag}_pmc_traffic.json`; generated by `scripts/make_profile_summary.py`).', '',
+          f'Sum of kernel time per step: {total_ms:.2f} ms; bench ms_per_step {bench["ms_per_step"]} (un-profiled): the step is GPU-bound.', '',
+          '| kernel | calls/step | ms/step | avg us | % |', '|---|---|---|---|---|']
+    for name, calls, tot, avg, pct in rows[:30]:
+        md.append(f'| `{name[:60]}` | {calls / steps:.1f} | {tot / steps / 1e6:.3f} | {avg / 1e3:.1f} | {pct:.2f} |')
+    r = bench['roofline']
+    nt_ms = sum(v[1] for k, v in by.items() if 'conv_nt_kernel' in k) / steps / 1e6
+    nt_calls = sum(v[0] for k, v in by.items() if 'conv_nt_kernel' in k) / steps
+    tn_ms = sum(v[1] for k, v in by.items() if 'conv_tn_kernel' in k) / steps / 1e6
+    md += ['', '## Roofline per kernel class', '',
+           f'* MFMA-bound: `conv_nt_kernel` (forward + data gradient) -- bench.py HIP events: {r["achieved"]} TFLOP/s of {r["peak"]} '
+           f'(fp32 matrix) = {r["frac"]}; avg launch {r["avg_launch_ms"]} ms, {r["algorithmic_gflop_per_launch"]} algorithmic GFLOP/launch '
+           f'({r["launches_per_step"]} launches/step). rocprofv3 over the same kernels: {nt_calls:.0f} launches/step, {nt_ms:.2f} ms/step '
+           f'(avg {nt_ms / nt_calls:.4f} ms; the HIP-event figure also covers the fix-up kernel of split tiles). '
+           f'HBM traffic {traffic["hbm_bytes_per_launch"] / 1e6:.0f} MB/launch (PMC).',
+           f'* MFMA-bound: `conv_tn_kernel` (weight gradient) -- the same algorithmic flops as the forward convolutions '
+           f'({r["algorithmic_gflop_per_launch"] * r["launches_per_step"] / 2 / 1e3:.3f} TFLOP/step) in {tn_ms:.2f} ms = '
+           f'{r["algorithmic_gflop_per_launch"] * r["launches_per_step"] / 2 / tn_ms:.1f} TFLOP/s, plus `wgrad_reduce`.',
+           '* HBM-bound classes (algorithmic bytes / rocprof time, peak 8 TB/s spec):', '',
+           '| kernel | algorithmic GB/step | ms/step | achieved TB/s | frac of 8 TB/s | bytes counted |', '|---|---|---|---|---|---|']
+    extra = [('adamw_kernel', 37968692 * 4 * 7 / 1e9, 'read p,g,m,v write p,m,v'),
+             ('im2col_stem_kernel', (2 * 3 * 800 * 1333 + 2 * 400 * 667 * 160) * 4 / 1e9, 'read image, write im2col matrix')]
+    md += hbm_table(by, steps, 2, 800, 1333, extra)
+    if 'cpu_baseline' in bench:
+        md += ['', f'CPU baseline (same run, {bench["cpu_baseline"]["cores"]} host threads): {bench["cpu_baseline"]}']
+    if len(sys.argv) > 7:
+        crow = read_stats(sys.argv[6])
+        cb = json.loads([l for l in open(sys.argv[7]) if l.startswith('{')][-1])
+        cby = {r[0]: (r[1], r[2]) for r in crow}
+        with open(os.path.join(prof, f'{tag}_cls_kernel_stats.csv'), 'w') as f:
+            f.write(open(sys.argv[6]).read())
+        json.dump(cb, open(os.path.join(prof, f'{tag}_cls_bench.json'), 'w'))
+        ctot = sum(r[2] for r in crow) / steps / 1e6
+        md += ['', '## Secondary workload: ResNet50 ImageNet classification, bs 256, 224x224, fp32 (SURVEY 8f-1)', '',
+               f'`bench.py --model resnet50_cls`: {cb["value"]} images/s, {cb["ms_per_step"]} ms/step (un-profiled; `{tag}_cls_bench.json`); '
+               f'kernel time {ctot:.2f} ms/step (`{tag}_cls_kernel_stats.csv`). conv_nt family {cb["roofline"]["achieved"]} TFLOP/s '
+               f'({cb["roofline"]["frac"]} of the fp32 MFMA peak).', '',
+               '| kernel | calls/step | ms/step | avg us | % |', '|---|---|---|---|---|']
+        for name, calls, tot, avg, pct in crow[:14]:
+            md.append(f'| `{name[:60]}` | {calls / steps:.1f} | {tot / steps / 1e6:.3f} | {avg / 1e3:.1f} | {pct:.2f} |')
+        md += ['', '| kernel | algorithmic GB/step | ms/step | achieved TB/s | frac of 8 TB/s | bytes counted |', '|---|---|---|---|---|---|']
+        md += hbm_table(cby, steps, 256, 224, 224, [
+            ('im2col_stem_kernel', (256 * 3 * 224 * 224 + 256 * 112 * 112 * 160) * 4 / 1e9, 'read image, write im2col matrix')])
+    open(os.path.join(prof, f'{tag}_summary.md'), 'w').write('\n'.join(md) + '\n')
+    print('\n'.join(md[:20]))
+
+
+if __name__ == '__main__':
+    main()

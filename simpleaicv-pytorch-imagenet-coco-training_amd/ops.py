@@ -4,6 +4,8 @@ torch is used for device memory and the current HIP stream only; every computati
 a hand-written gfx950 kernel reached through ctypes on raw device pointers.  All activations
 are NHWC-contiguous fp32 tensors of logical shape [N, H, W, C].
 """
+import os
+
 import torch
 
 from . import _lib
@@ -165,7 +167,11 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
     return outs
 
 
-def _wgrad_chunk(npix_total, cout, n2, target_blocks=1024):
+_WGRAD_TARGET = int(os.environ.get('SACV_WGRAD_TARGET_BLOCKS', '512'))  # = resident workgroups (2/CU): one wave of blocks; 544 or 1024 measured slower
+
+
+def _wgrad_chunk(npix_total, cout, n2, target_blocks=None):
+    target_blocks = target_blocks or _WGRAD_TARGET
     bm = 64 if cout <= 64 else 128
     bn = 64 if n2 <= 64 else 128
     tiles = -(-cout // bm) * -(-n2 // bn)

@@ -167,16 +167,23 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
     return outs
 
 
+_WGRAD_TARGET_MULTI = int(os.environ.get('SACV_WGRAD_TARGET_MULTI', '1024'))
 _WGRAD_TARGET = int(os.environ.get('SACV_WGRAD_TARGET_BLOCKS', '512'))  # = resident workgroups (2/CU): one wave of blocks; 544 or 1024 measured slower
 
 
-def _wgrad_chunk(npix_total, cout, n2, target_blocks=None):
-    target_blocks = target_blocks or _WGRAD_TARGET
+def _wgrad_chunk(npix, cout, n2, target_blocks=None):
+    """Pixels per split of the weight-gradient GEMM.  npix: pixel count per segment (each segment is split on its
+    own).  One segment: equal splits, as many as keep tiles x splits within ONE co-resident wave of workgroups
+    (measured: 512 beats 544 and 1024).  Several segments (pyramid levels sharing a weight): the splits are unequal
+    (short levels), so twice as many, smaller splits balance better (1024 beats 512 by 20 %)."""
+    npix = [npix] if isinstance(npix, int) else list(npix)
+    target_blocks = target_blocks or (_WGRAD_TARGET if len(npix) == 1 else _WGRAD_TARGET_MULTI)
     bm = 64 if cout <= 64 else 128
     bn = 64 if n2 <= 64 else 128
     tiles = -(-cout // bm) * -(-n2 // bn)
-    chunks = max(1, min(target_blocks // tiles, -(-npix_total // 128)))
-    chunk = -(-npix_total // chunks)
+    total = sum(npix)
+    chunks = max(1, min(target_blocks // tiles, -(-total // 128)))
+    chunk = -(-total // chunks)
     return max(32, -(-chunk // 32) * 32)
 
 
@@ -203,8 +210,7 @@ def conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, accumulate=False, cin_pad=
     nb = [d.shape[0] for d in dys]
     ho = [d.shape[1] for d in dys]
     wo = [d.shape[2] for d in dys]
-    npix = sum(b * h * w for b, h, w in zip(nb, ho, wo))
-    chunk = _wgrad_chunk(npix, cout, kh * kw * cin_pad)
+    chunk = _wgrad_chunk([b * h * w for b, h, w in zip(nb, ho, wo)], cout, kh * kw * cin_pad)
     nbytes = lib.sacv_conv2d_wgrad_workspace_bytes(n, iarr(nb), iarr(ho), iarr(wo), cin_pad, cout, kh, kw, chunk)
     ws = workspace(nbytes, dys[0].device, 'wgrad')
     check(lib.sacv_conv2d_wgrad(

@@ -490,9 +490,9 @@ class DetectorEngine:
             elif bi == 0 and li == 3:
                 accum_target = dc3
             dout = self._bottleneck_bwd(c1, c2, c3, cd, dout, accum_target)
-            if on_stage and li == 4 and bi == 0:
+            if on_stage and bi == 0 and li in (3, 4):
                 self._join_side()
-                on_stage('neck')  # fpn + layer4 gradients are final
+                on_stage('neck' if li == 4 else 'mid')  # fpn + layer4 / layer3 gradients are final
         # max pool + stem
         dpool = ops.maxpool_bwd(dout, ctx['pool_idx'], ctx['pool_in_shape'], 3, 2, 1)
         st = ctx['stem']

@@ -3,7 +3,7 @@
 One process per GPU.  The gradient arena is a single flat fp32 buffer whose >=2-D section is
 laid out in module order (backbone ... fpn, cls_head, reg_head), i.e. in REVERSE of the order
 the backward pass finishes them.  The exchanger cuts it into a few large contiguous stages
-(heads | fpn + layer4 | rest) and launches one asynchronous all-reduce per stage as soon as
+(heads | fpn + layer4 | layer3 | rest) and launches one asynchronous all-reduce per stage as soon as
 the backward pass has produced that stage, so the transfer over xGMI runs under the remaining
 backward convolutions; the optimizer waits for all of them.  Stages are zero-copy slices, so
 there is no bucket packing.  Replaces the DDP wrapper of tools/utils.py:178-180 (mean of the
@@ -22,7 +22,8 @@ def stage_ranges(arena_order, offsets, numel, split):
 
     arena_order: [(name, tensor)] in arena order (1-D tensors first, then >=2-D in module order).
     Returns dict stage -> (begin, end):  'heads' (cls_head/reg_head weights; the classifier's fc),
-    'neck' (fpn + backbone layer4 weights), 'rest' (everything else including the whole 1-D section)."""
+    'neck' (fpn + backbone layer4 weights), 'mid' (backbone layer3 weights, 28 MB), 'rest' (everything else
+    including the whole 1-D section: ~6 MB, the only transfer left exposed at the end of the backward pass)."""
     multi = [(n, offsets[n]) for n, t in arena_order if t.ndim != 1]
 
     def first(prefixes):
@@ -34,7 +35,9 @@ def stage_ranges(arena_order, offsets, numel, split):
     heads_begin = first(('cls_head.', 'reg_head.', 'clsregcnt_head.', 'fc.'))
     neck_begin = min(first(('backbone.layer4.', 'layer4.')), first(('fpn.',)))
     neck_begin = min(neck_begin, heads_begin)
-    return {'heads': (heads_begin, numel), 'neck': (neck_begin, heads_begin), 'rest': (0, neck_begin)}
+    mid_begin = min(first(('backbone.layer3.', 'layer3.')), neck_begin)
+    return {'heads': (heads_begin, numel), 'neck': (neck_begin, heads_begin), 'mid': (mid_begin, neck_begin),
+            'rest': (0, mid_begin)}
 
 
 class GradExchanger:

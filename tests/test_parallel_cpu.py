@@ -30,7 +30,8 @@ def _worker(rank, world, port, ret):
         arena = ParamArena(m)
         ranges = stage_ranges(arena.order, arena.offsets, arena.numel, arena.split)
         # stages tile the arena exactly, in backward order heads -> neck -> rest
-        assert ranges['rest'][0] == 0 and ranges['rest'][1] == ranges['neck'][0]
+        assert ranges['rest'][0] == 0 and ranges['rest'][1] == ranges['mid'][0]
+        assert ranges['mid'] == (arena.offsets['backbone.layer3.0.conv1.layer.0.weight'], ranges['neck'][0])
         assert ranges['neck'][1] == ranges['heads'][0] and ranges['heads'][1] == arena.numel
         for n, _ in arena.order:
             o = arena.offsets[n]
@@ -40,7 +41,7 @@ def _worker(rank, world, port, ret):
         g = arena.grads
         g.copy_(torch.arange(g.numel(), dtype=torch.float32) % 97 + rank)
         ex = GradExchanger(g, ranges)
-        for stage in ('heads', 'neck', 'rest'):
+        for stage in ('heads', 'neck', 'mid', 'rest'):
             ex.stage_done(stage)
         ex.wait()
         expect = (torch.arange(g.numel(), dtype=torch.float32) % 97) * world + sum(range(world))
@@ -77,7 +78,8 @@ def test_stage_ranges_of_the_classifier_arena():
     from sacv_amd.parallel import stage_ranges
     arena = ParamArena(backbones.__dict__['resnet50'](num_classes=1000))
     r = stage_ranges(arena.order, arena.offsets, arena.numel, arena.split)
-    assert r['rest'][0] == 0 and r['rest'][1] == r['neck'][0] and r['neck'][1] == r['heads'][0]
+    assert r['rest'][0] == 0 and r['rest'][1] == r['mid'][0] and r['mid'][1] == r['neck'][0]
+    assert r['neck'][1] == r['heads'][0] and r['mid'][0] == arena.offsets['layer3.0.conv1.layer.0.weight']
     assert r['heads'] == (arena.offsets['fc.weight'], arena.numel)
     assert r['neck'][0] == arena.offsets['layer4.0.conv1.layer.0.weight']
     assert arena.split % 4 == 0 and arena.numel % 4 == 0

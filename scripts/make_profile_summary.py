@@ -70,7 +70,42 @@ def hbm_table(stats_by_name, steps, B, H, W, extra):
     return out
 
 
+def mfma_utilisation(path, tag):
+    """SQ_VALU_MFMA_BUSY_CYCLES per kernel family / (duration x 2.4 GHz x 1024 SIMDs); wave-cycle breakdown."""
+    import collections
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    dur, n, seen = collections.defaultdict(float), collections.Counter(), set()
+    for r in csv.DictReader(open(path)):
+        k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+        agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+        if r['Dispatch_Id'] not in seen:
+            seen.add(r['Dispatch_Id'])
+            n[k] += 1
+            dur[k] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+    out, md = {}, ['', '## Matrix-pipe utilisation (PMC pass, `SQ_VALU_MFMA_BUSY_CYCLES`; kernels run slower under the profiler)', '',
+                   '`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY` '
+                   'over `bench.py --steps 2 --warmup 1`; utilisation = busy cycles / (kernel duration x 2.4 GHz x 1024 SIMDs); it counts '
+                   'the zero-padded part of edge tiles too, which the algorithmic TFLOP/s above do not.', '',
+                   '| kernel | launches | MFMA busy | waves parked (s_waitcnt/barrier) | issue stalls | issuing |', '|---|---|---|---|---|---|']
+    for k in sorted(agg, key=lambda k: -dur[k]):
+        a = agg[k]
+        if a.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) <= 0:
+            continue
+        u = a['SQ_VALU_MFMA_BUSY_CYCLES'] / (dur[k] * 2.4 * 1024)
+        w = a['SQ_WAVE_CYCLES']
+        out[k] = dict(launches=n[k], mfma_busy_frac=round(u, 4), wait_any=round(a['SQ_WAIT_ANY'] / w, 3),
+                      wait_inst_any=round(a['SQ_WAIT_INST_ANY'] / w, 3), active_inst=round(a['SQ_ACTIVE_INST_ANY'] / w, 3))
+        md.append(f'| `{k}` | {n[k]} | {u:.2f} | {a["SQ_WAIT_ANY"] / w:.2f} | {a["SQ_WAIT_INST_ANY"] / w:.2f} | {a["SQ_ACTIVE_INST_ANY"] / w:.2f} |')
+    json.dump(out, open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_mfma.json'), 'w'), indent=1)
+    return md
+
+
 def main():
+    mfma_md = []
+    if '--mfma' in sys.argv:
+        i = sys.argv.index('--mfma')
+        mfma_md = mfma_utilisation(sys.argv[i + 1], sys.argv[1])
+        del sys.argv[i:i + 2]
     tag, stats_p, bench_p, pf, pw = sys.argv[1:6]
     steps = 7
     prof = os.path.join(ROOT, 'profiles')
@@ -117,6 +152,7 @@ def main():
     extra = [('adamw_kernel', 37968692 * 4 * 7 / 1e9, 'read p,g,m,v write p,m,v'),
              ('im2col_stem_kernel', (2 * 3 * 800 * 1333 + 2 * 400 * 667 * 160) * 4 / 1e9, 'read image, write im2col matrix')]
     md += hbm_table(by, steps, 2, 800, 1333, extra)
+    md += mfma_md
     if 'cpu_baseline' in bench:
         md += ['', f'CPU baseline (same run, {bench["cpu_baseline"]["cores"]} host threads): {bench["cpu_baseline"]}']
     if len(sys.argv) > 7:

@@ -358,6 +358,8 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
   SACV_STAMP_HERE();
   // (delaying half of the workgroups by half a K iteration at start-up -- by parity or by grid half -- to
   // break the lockstep of the two workgroups of a CU was measured: no effect, they re-synchronise)
+  // (the same stagger restricted to short-K, store-heavy 1x1 problems -- odd workgroups sleeping 3-14 us first --
+  // only adds the delay: 78 -> 81..91 us)
   setup(0);
   load_tile(k_begin);
   store_tile(0);

@@ -35,6 +35,12 @@
 #define CF_MASK 16
 #define CF_STATS 32
 
+// 16 bytes of zeros in device memory: masked-out gathers (padding taps, rows beyond M, channels beyond Cs) READ
+// THIS instead of being loaded and then replaced by zeros.  A select on the loaded VALUE makes the compiler
+// wait for the load right where the select is scheduled -- in the middle of the MFMA block -- whereas a select
+// on the ADDRESS keeps every gathered register untouched until the LDS store at the end of the K iteration.
+__device__ __attribute__((aligned(16))) float sacv_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 struct ConvProb {
   const float* src;
   float* dst;
@@ -308,17 +314,13 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
       off = rowoff[i] + (hs * Ws + ws) * Cs + lt_c0;
     }
     ok = ok && lt_kok;
-    unsigned uoff = ok ? (unsigned)off : 0u;
-    f32x4 v = *reinterpret_cast<const f32x4*>(src + uoff);
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    ra[i] = ok ? v : z;
+    const float* ptr = ok ? src + (unsigned)off : sacv_zero16;
+    ra[i] = *reinterpret_cast<const f32x4*>(ptr);
   };
   auto load_b = [&](int i) {
     bool ok = wok[i] && lt_kok;
-    unsigned uoff = ok ? (unsigned)(wrow[i] + lt_boff) : 0u;
-    f32x4 v = *reinterpret_cast<const f32x4*>(wgt + uoff);
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    rb[i] = ok ? v : z;
+    const float* ptr = ok ? wgt + (unsigned)(wrow[i] + lt_boff) : sacv_zero16;
+    rb[i] = *reinterpret_cast<const f32x4*>(ptr);
   };
   auto load_tile = [&](int kt) {
     load_begin(kt, true);
@@ -407,8 +409,17 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
         }
         // one A gather and one B gather per quarter of the MFMA block.  (Issuing all eight in the first two
         // quarters, to give them more time before the LDS store, was measured: 122 -> 106-115 TF.)
-        if (jj < RA) load_a(jj);
-        if (jj < RB) load_b(jj);
+#ifndef SACV_GATHER_QUARTERS
+#define SACV_GATHER_QUARTERS 4  // quarters of the MFMA block over which the next slab's gathers are spread
+#endif
+        constexpr int GPQ_A = (RA + SACV_GATHER_QUARTERS - 1) / SACV_GATHER_QUARTERS;
+        constexpr int GPQ_B = (RB + SACV_GATHER_QUARTERS - 1) / SACV_GATHER_QUARTERS;
+#pragma unroll
+        for (int g = 0; g < GPQ_A; ++g)
+          if (jj * GPQ_A + g < RA) load_a(jj * GPQ_A + g);
+#pragma unroll
+        for (int g = 0; g < GPQ_B; ++g)
+          if (jj * GPQ_B + g < RB) load_b(jj * GPQ_B + g);
         // raise the wave's issue priority for the MFMA block (dropped again before the LDS stores and the
         // barrier): the wave in its math phase then wins arbitration over its SIMD partner's address/LDS
         // work instead of alternating with it.  Measured +7..9 % on the 3x3 convs (112 -> 121 TF).
@@ -426,7 +437,8 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // 1 MFMA
           if (m < TM + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 LDS read
           __builtin_amdgcn_sched_group_barrier(0x002, SACV_SGB_VALU, 0);           // address VALU
-          if (m == 5 || m == 10) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 global load
+          if (SACV_GATHER_QUARTERS == 4 ? (m == 5 || m == 10) : (m == 2 || m == 5 || m == 8 || m == 11))
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 global load
         }
 #endif
       }
@@ -601,21 +613,17 @@ __global__ __launch_bounds__(256, 2) void conv_tn_kernel(const WgradArgs a) {
   f32x4 ra[RA], rb[RB];
   auto load_a = [&](int i, int p0, bool en) {
     int pix = p0 + rra + i * RSA;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     bool ok = en && co_ok && pix < pix1;
-    size_t off = ok ? (size_t)pix * a.Cout + co : (size_t)0;
-    f32x4 v = *reinterpret_cast<const f32x4*>(dy + off);
-    ra[i] = ok ? v : z;
+    const float* ptr = ok ? dy + ((size_t)pix * a.Cout + co) : sacv_zero16;
+    ra[i] = *reinterpret_cast<const f32x4*>(ptr);
   };
   auto load_b = [&](int i, int p0, bool en) {
     int pix = p0 + rrb + i * RSB;
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     int hi = ph[i] * a.stride + dh;
     int wi = pw[i] * a.stride + dw;
     bool ok = en && n2_ok && pix < pix1 && (unsigned)hi < (unsigned)S.Hx && (unsigned)wi < (unsigned)S.Wx;
-    size_t off = ok ? ((size_t)(pn[i] * S.Hx + hi) * S.Wx + wi) * a.Cin + ci : (size_t)0;
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
-    rb[i] = ok ? v : z;
+    const float* ptr = ok ? x + (((size_t)(pn[i] * S.Hx + hi) * S.Wx + wi) * a.Cin + ci) : sacv_zero16;
+    rb[i] = *reinterpret_cast<const f32x4*>(ptr);
   };
   auto advance = [&]() {  // +32 pixels
 #pragma unroll

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void conv_tn_kernel(const WgradArgs a) {
     kw = tap - kh * a.KW;
   }
   const int HoWo = S.Ho * S.Wo;
-  const int Wo = S.Wo, Ho = S.Ho;
+  const int Wo = S.Wo, Ho = S.Ho, Hx = S.Hx, Wx = S.Wx;
   const int dh = kh - a.pad, dw = kw - a.pad;
 
   // pixel coordinates of this thread's RB gather rows, advanced incrementally by 32 pixels per K tile
@@ -608,44 +608,42 @@ __global__ __launch_bounds__(256, 2) void conv_tn_kernel(const WgradArgs a) {
     ph[i] = rem / Wo;
     pw[i] = rem - ph[i] * Wo;
   }
-  const bool fast_adv = Wo >= 32;
 
   f32x4 ra[RA], rb[RB];
   auto load_a = [&](int i, int p0, bool en) {
     int pix = p0 + rra + i * RSA;
     bool ok = en && co_ok && pix < pix1;
-    const float* ptr = ok ? dy + ((size_t)pix * a.Cout + co) : sacv_zero16;
+    // 32-bit element offsets (tensors are checked to be < 2^32 elements) and a pointer select: no 64-bit
+    // multiply, no exec-masked branch in the MFMA loop
+    const float* ptr = dy + (unsigned)(pix * a.Cout + co);
+    ptr = ok ? ptr : sacv_zero16;
     ra[i] = *reinterpret_cast<const f32x4*>(ptr);
   };
   auto load_b = [&](int i, int p0, bool en) {
     int pix = p0 + rrb + i * RSB;
     int hi = ph[i] * a.stride + dh;
     int wi = pw[i] * a.stride + dw;
-    bool ok = en && n2_ok && pix < pix1 && (unsigned)hi < (unsigned)S.Hx && (unsigned)wi < (unsigned)S.Wx;
-    const float* ptr = ok ? x + (((size_t)(pn[i] * S.Hx + hi) * S.Wx + wi) * a.Cin + ci) : sacv_zero16;
+    bool ok = en && n2_ok && pix < pix1 && (unsigned)hi < (unsigned)Hx && (unsigned)wi < (unsigned)Wx;
+    const float* ptr = x + ((unsigned)((pn[i] * Hx + hi) * Wx + wi) * (unsigned)a.Cin + (unsigned)ci);
+    ptr = ok ? ptr : sacv_zero16;
     rb[i] = *reinterpret_cast<const f32x4*>(ptr);
   };
-  auto advance = [&]() {  // +32 pixels
+  // +32 pixels, branch-free: (dn, dhh, dww) = the wave-uniform decomposition of 32 in (image, row, column) units
+  const int adv_n = 32 / HoWo;
+  const int adv_h = (32 - adv_n * HoWo) / Wo;
+  const int adv_w = 32 - adv_n * HoWo - adv_h * Wo;
+  auto advance = [&]() {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      if (fast_adv) {
-        pw[i] += 32;
-        if (pw[i] >= Wo) {
-          pw[i] -= Wo;
-          ph[i] += 1;
-          if (ph[i] >= Ho) {
-            ph[i] = 0;
-            pn[i] += 1;
-          }
-        }
-      } else {
-        int lin = ph[i] * Wo + pw[i] + 32;
-        int q = lin / HoWo;
-        pn[i] += q;
-        lin -= q * HoWo;
-        ph[i] = lin / Wo;
-        pw[i] = lin - ph[i] * Wo;
-      }
+      int w = pw[i] + adv_w;
+      const int cw = w >= Wo ? 1 : 0;
+      w -= cw ? Wo : 0;
+      int h = ph[i] + adv_h + cw;
+      const int chh = h >= Ho ? 1 : 0;
+      h -= chh ? Ho : 0;
+      pw[i] = w;
+      ph[i] = h;
+      pn[i] += adv_n + chh;
     }
   };
   auto store_tile = [&](int buf) {
@@ -1202,7 +1200,7 @@ int sacv_conv2d_wgrad(int nseg, const float* const* dy, const float* const* x, c
     s.Wo = Wo[i];
     long long np = (long long)Nb[i] * Ho[i] * Wo[i];
     SACV_CHECK_ARG(np * (long long)(Cout > Cin_pad ? Cout : Cin_pad) < (1LL << 31) &&
-                       (long long)Nb[i] * Hx[i] * Wx[i] < (1LL << 31),
+                       (long long)Nb[i] * Hx[i] * Wx[i] * Cin_pad < (1LL << 32),
                    "conv2d_wgrad: too large");
     s.npix = (int)np;
     s.chunk_begin = chunks;

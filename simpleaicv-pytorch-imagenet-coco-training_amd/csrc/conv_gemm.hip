@@ -612,7 +612,9 @@ __global__ __launch_bounds__(256, 2) void conv_tn_kernel(const WgradArgs a) {
   f32x4 ra[RA], rb[RB];
   auto load_a = [&](int i, int p0, bool en) {
     int pix = p0 + rra + i * RSA;
-    bool ok = en && co_ok && pix < pix1;
+    // bitwise & on purpose: && short-circuits into exec-masked branches inside the MFMA loop.  (`en` is implied:
+    // the slab after the last one starts at or beyond pix1)
+    bool ok = co_ok & (pix < pix1);
     // 32-bit element offsets (tensors are checked to be < 2^32 elements) and a pointer select: no 64-bit
     // multiply, no exec-masked branch in the MFMA loop
     const float* ptr = dy + (unsigned)(pix * a.Cout + co);
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(256, 2) void conv_tn_kernel(const WgradArgs a) {
     int pix = p0 + rrb + i * RSB;
     int hi = ph[i] * a.stride + dh;
     int wi = pw[i] * a.stride + dw;
-    bool ok = en && n2_ok && pix < pix1 && (unsigned)hi < (unsigned)Hx && (unsigned)wi < (unsigned)Wx;
+    bool ok = n2_ok & (pix < pix1) & ((unsigned)hi < (unsigned)Hx) & ((unsigned)wi < (unsigned)Wx);
     const float* ptr = x + ((unsigned)((pn[i] * Hx + hi) * Wx + wi) * (unsigned)a.Cin + (unsigned)ci);
     ptr = ok ? ptr : sacv_zero16;
     rb[i] = *reinterpret_cast<const f32x4*>(ptr);

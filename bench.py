@@ -149,7 +149,8 @@ def main():
     # SACV_DIST_BACKEND=gloo + SACV_SHARE_GPU=1: rehearsal of the multi-rank path on a one-GPU box (all ranks on
     # cuda:0, collectives through the host).  The real run uses RCCL ("nccl") with one GPU per rank.
     backend = os.environ.get('SACV_DIST_BACKEND', 'nccl')
-    dev_index = 0 if os.environ.get('SACV_SHARE_GPU') else local_rank
+    # one GPU per rank; if the launcher restricted each rank's visibility to a single device, that device is 0
+    dev_index = 0 if os.environ.get('SACV_SHARE_GPU') else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     group = None
     if world > 1:

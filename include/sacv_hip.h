@@ -151,7 +151,8 @@ int sacv_focal_loss_fwd_bwd(int nlev, const float* const* cls_in, float* const* 
                             const float* targets, int tstride, int B, int A, int C, float alpha, float gamma,
                             float weight, const int* counts, float* workspace, float* loss_out, int slot,
                             void* stream);
-/* compute_batch_box_loss (losses.py:263-320): box_type 0 SmoothL1, 1 IoU, 2 GIoU */
+/* compute_batch_box_loss (losses.py:263-320): box_type 0 SmoothL1, 1 IoU, 2 GIoU, 3 DIoU, 4 CIoU, 5 EIoU
+ * (IoUMethod, losses.py:28-123) */
 int sacv_retina_box_loss_fwd_bwd(int nlev, const float* const* reg_in, float* const* grad, const int* level_off,
                                  const float* targets, const float* anchors, int B, int A, int box_type, float beta,
                                  float weight, const int* counts, float* workspace, float* loss_out, int slot,
@@ -162,7 +163,8 @@ int sacv_retina_box_loss_fwd_bwd(int nlev, const float* const* reg_in, float* co
 int sacv_fcos_assign(int nlev, const int* level_off, const float* strides, const float* mi, const float* points,
                      const float* annots, float* targets, int* counts, int B, int P, int G,
                      float center_sample_radius, int use_center_sample, void* stream);
-/* compute_batch_iou_loss (losses.py:550-586, iou_type 0 IoU / 1 GIoU, weighted by the centerness target) and
+/* compute_batch_iou_loss (losses.py:550-586, iou_type 0 IoU / 1 GIoU / 2 DIoU / 3 CIoU / 4 EIoU, weighted by the
+ * centerness target) and
  * compute_batch_centerness_loss (:588-610), forward + gradients */
 int sacv_fcos_reg_ctr_loss_fwd_bwd(int nlev, const float* const* reg_in, const float* const* ctr_in,
                                    float* const* dreg, float* const* dctr, const int* level_off,

@@ -238,8 +238,126 @@ __global__ void loss_finalize_kernel(const float* __restrict__ partial, int n, c
 __device__ __forceinline__ float dmax_a(float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); }
 __device__ __forceinline__ float dmin_a(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
 
-// loss = 1 - IoU/GIoU(pred, gt);  returns loss, writes d loss / d pred[4].  type: 0 IoU, 1 GIoU
+// ---- DIoU / CIoU / EIoU (IoUMethod, losses.py:83-116) by forward-mode differentiation: a value with its four
+// partial derivatives w.r.t. the predicted box, propagated through the reference's operation sequence with
+// torch's subgradient conventions (max/min split ties 0.5/0.5, clamp passes the gradient on the bound, the CIoU
+// alpha is a constant as under torch.no_grad()).
+struct D4 {
+  float v, d[4];
+};
+__device__ __forceinline__ D4 d4_var(float v, int k) {
+  D4 r = {v, {0.f, 0.f, 0.f, 0.f}};
+  r.d[k] = 1.f;
+  return r;
+}
+__device__ __forceinline__ D4 d4_scale(D4 a, float f) {  // derivative chain: value given separately
+  for (int k = 0; k < 4; ++k) a.d[k] *= f;
+  return a;
+}
+__device__ __forceinline__ D4 operator+(D4 a, const D4& b) {
+  a.v += b.v;
+  for (int k = 0; k < 4; ++k) a.d[k] += b.d[k];
+  return a;
+}
+__device__ __forceinline__ D4 operator-(D4 a, const D4& b) {
+  a.v -= b.v;
+  for (int k = 0; k < 4; ++k) a.d[k] -= b.d[k];
+  return a;
+}
+__device__ __forceinline__ D4 operator*(const D4& a, const D4& b) {
+  D4 r;
+  r.v = a.v * b.v;
+  for (int k = 0; k < 4; ++k) r.d[k] = a.d[k] * b.v + a.v * b.d[k];
+  return r;
+}
+__device__ __forceinline__ D4 operator/(const D4& a, const D4& b) {
+  D4 r;
+  r.v = a.v / b.v;
+  const float inv = 1.f / b.v;
+  for (int k = 0; k < 4; ++k) r.d[k] = (a.d[k] - r.v * b.d[k]) * inv;
+  return r;
+}
+__device__ __forceinline__ D4 d4_addc(D4 a, float c) {
+  a.v += c;
+  return a;
+}
+__device__ __forceinline__ D4 d4_rsubc(float c, D4 a) {  // c - a
+  a.v = c - a.v;
+  for (int k = 0; k < 4; ++k) a.d[k] = -a.d[k];
+  return a;
+}
+__device__ __forceinline__ D4 d4_mulc(D4 a, float c) {
+  a.v *= c;
+  for (int k = 0; k < 4; ++k) a.d[k] *= c;
+  return a;
+}
+__device__ __forceinline__ D4 d4_maxc(D4 a, float c) {
+  const float f = a.v > c ? 1.f : (a.v == c ? 0.5f : 0.f);
+  a = d4_scale(a, f);
+  a.v = fmaxf(a.v, c);
+  return a;
+}
+__device__ __forceinline__ D4 d4_minc(D4 a, float c) {
+  const float f = a.v < c ? 1.f : (a.v == c ? 0.5f : 0.f);
+  a = d4_scale(a, f);
+  a.v = fminf(a.v, c);
+  return a;
+}
+__device__ __forceinline__ D4 d4_clamp_min(D4 a, float m) {  // torch.clamp(min=m): gradient where a >= m
+  const float f = a.v >= m ? 1.f : 0.f;
+  a = d4_scale(a, f);
+  a.v = fmaxf(a.v, m);
+  return a;
+}
+__device__ __forceinline__ D4 d4_sq(const D4& a) {
+  D4 r;
+  r.v = a.v * a.v;
+  for (int k = 0; k < 4; ++k) r.d[k] = 2.f * a.v * a.d[k];
+  return r;
+}
+__device__ __forceinline__ D4 d4_atan(const D4& a) {
+  D4 r;
+  r.v = atanf(a.v);
+  const float f = 1.f / (1.f + a.v * a.v);
+  for (int k = 0; k < 4; ++k) r.d[k] = a.d[k] * f;
+  return r;
+}
+
+// type: 2 DIoU, 3 CIoU, 4 EIoU
+__device__ float iou_family_loss_dual(const float p[4], const float g[4], int type, float dp[4]) {
+  const D4 x0 = d4_var(p[0], 0), y0 = d4_var(p[1], 1), x1 = d4_var(p[2], 2), y1 = d4_var(p[3], 3);
+  const D4 w = d4_clamp_min(d4_minc(x1, g[2]) - d4_maxc(x0, g[0]), 0.f);
+  const D4 h = d4_clamp_min(d4_minc(y1, g[3]) - d4_maxc(y0, g[1]), 0.f);
+  const D4 inter = w * h;
+  const D4 pw = d4_clamp_min(x1 - x0, 0.f), ph = d4_clamp_min(y1 - y0, 0.f);
+  const float gw = fmaxf(g[2] - g[0], 0.f), gh = fmaxf(g[3] - g[1], 0.f);
+  const D4 uni = d4_clamp_min(d4_addc(pw * ph, gw * gh) - inter, 1e-4f);
+  const D4 iou = inter / uni;
+  const D4 ew = d4_clamp_min(d4_maxc(x1, g[2]) - d4_minc(x0, g[0]), 0.f);
+  const D4 eh = d4_clamp_min(d4_maxc(y1, g[3]) - d4_minc(y0, g[1]), 0.f);
+  const D4 c2 = d4_clamp_min(d4_sq(ew) + d4_sq(eh), 1e-4f);
+  const D4 pcx = d4_mulc(x1 + x0, 0.5f), pcy = d4_mulc(y1 + y0, 0.5f);
+  const float gcx = (g[2] + g[0]) / 2.f, gcy = (g[3] + g[1]) / 2.f;
+  const D4 p2 = d4_sq(d4_addc(pcx, -gcx)) + d4_sq(d4_addc(pcy, -gcy));
+  D4 pen = p2 / c2;
+  if (type == 3) {
+    const D4 da = d4_rsubc(atanf(gw / gh), d4_atan(pw / ph));  // atan(gw/gh) - atan(pw/ph)
+    const D4 v = d4_mulc(d4_sq(da), 0.40528473456935109f);     // 4 / pi^2
+    const float alpha = v.v / fmaxf(1.f - iou.v + v.v, 1e-4f);
+    pen = pen + d4_mulc(v, alpha);
+  } else if (type == 4) {
+    const D4 cw2 = d4_clamp_min(d4_sq(ew), 1e-4f), ch2 = d4_clamp_min(d4_sq(eh), 1e-4f);
+    pen = pen + d4_sq(d4_rsubc(gw, pw)) / cw2 + d4_sq(d4_rsubc(gh, ph)) / ch2;
+  }
+  const D4 val = iou - pen;
+  for (int k = 0; k < 4; ++k) dp[k] = -val.d[k];
+  return 1.f - val.v;
+}
+
+// loss = 1 - IoU-family(pred, gt);  returns loss, writes d loss / d pred[4].
+// type: 0 IoU, 1 GIoU (hand-derived below), 2 DIoU, 3 CIoU, 4 EIoU (forward-mode, above)
 __device__ float iou_loss_fwd_bwd(const float p[4], const float g[4], int type, float dp[4]) {
+  if (type >= 2) return iou_family_loss_dual(p, g, type, dp);
   float tlx = fmaxf(p[0], g[0]), tly = fmaxf(p[1], g[1]);
   float brx = fminf(p[2], g[2]), bry = fminf(p[3], g[3]);
   float rw = brx - tlx, rh = bry - tly;
@@ -318,7 +436,7 @@ struct RegPtrs {
   int nlev;
 };
 
-// box_type: 0 SmoothL1 (targets are tx,ty,tw,th), 1 IoU, 2 GIoU (targets are GT xyxy)
+// box_type: 0 SmoothL1 (targets are tx,ty,tw,th), 1 IoU, 2 GIoU, 3 DIoU, 4 CIoU, 5 EIoU (targets are GT xyxy)
 __global__ __launch_bounds__(256) void retina_box_loss_kernel(const RegPtrs rp, const float* __restrict__ targets,
                                                                const float* __restrict__ anchors, int B, int A,
                                                                int box_type, float beta, float weight,
@@ -709,8 +827,8 @@ int sacv_retina_box_loss_fwd_bwd(int nlev, const float* const* reg_in, float* co
                                  float weight, const int* counts, float* workspace, float* loss_out, int slot,
                                  void* stream) {
   SACV_CHECK_ARG(nlev >= 1 && nlev <= MAXL, "box_loss: nlev");
-  SACV_CHECK_ARG(box_type >= 0 && box_type <= 2, "box_loss: box_type %d unsupported (0 SmoothL1, 1 IoU, 2 GIoU)",
-                 box_type);
+  SACV_CHECK_ARG(box_type >= 0 && box_type <= 5,
+                 "box_loss: box_type %d unsupported (0 SmoothL1, 1 IoU, 2 GIoU, 3 DIoU, 4 CIoU, 5 EIoU)", box_type);
   SACV_CHECK_ARG(level_off[nlev] == A, "box_loss: level offsets do not sum to A");
   SACV_CHECK_ARG(targets && anchors && counts && workspace && loss_out, "box_loss: null pointer");
   RegPtrs rp;
@@ -771,7 +889,8 @@ int sacv_fcos_reg_ctr_loss_fwd_bwd(int nlev, const float* const* reg_in, const f
                                    const int* counts, float* workspace, float* loss_out, int slot_reg, int slot_ctr,
                                    void* stream) {
   SACV_CHECK_ARG(nlev >= 1 && nlev <= MAXL, "fcos_loss: nlev");
-  SACV_CHECK_ARG(iou_type == 0 || iou_type == 1, "fcos_loss: iou_type %d unsupported (0 IoU, 1 GIoU)", iou_type);
+  SACV_CHECK_ARG(iou_type >= 0 && iou_type <= 4,
+                 "fcos_loss: iou_type %d unsupported (0 IoU, 1 GIoU, 2 DIoU, 3 CIoU, 4 EIoU)", iou_type);
   SACV_CHECK_ARG(level_off[nlev] == P && targets && counts && workspace && loss_out, "fcos_loss: bad args");
   FcosPtrs fp;
   fp.nlev = nlev;

@@ -12,7 +12,9 @@ from .. import ops
 
 __all__ = ['RetinaLoss', 'FCOSLoss']
 
-_BOX_TYPES = {'SmoothL1': ops.BOX_SMOOTH_L1, 'IoU': ops.BOX_IOU, 'GIoU': ops.BOX_GIOU}
+_BOX_TYPES = {'SmoothL1': ops.BOX_SMOOTH_L1, 'IoU': ops.BOX_IOU, 'GIoU': ops.BOX_GIOU, 'DIoU': ops.BOX_DIOU,
+              'CIoU': ops.BOX_CIOU, 'EIoU': ops.BOX_EIOU}
+_IOU_TYPES = {'IoU': 0, 'GIoU': 1, 'DIoU': 2, 'CIoU': 3, 'EIoU': 4}
 
 
 class _ScaledGrad(torch.autograd.Function):
@@ -51,9 +53,6 @@ class RetinaLoss(nn.Module):
                  beta=1.0 / 9.0, cls_loss_weight=1., box_loss_weight=1., box_loss_type='SmoothL1'):
         super().__init__()
         assert box_loss_type in ['SmoothL1', 'IoU', 'GIoU', 'DIoU', 'CIoU', 'EIoU'], 'wrong IoU type!'
-        if box_loss_type not in _BOX_TYPES:
-            raise NotImplementedError(f'box_loss_type={box_loss_type}: the HIP box-loss kernel implements '
-                                      'SmoothL1, IoU and GIoU')
         self.anchors = AnchorCache(areas, ratios, scales, strides)
         self.alpha, self.gamma, self.beta = alpha, gamma, beta
         self.cls_loss_weight, self.box_loss_weight = cls_loss_weight, box_loss_weight
@@ -121,8 +120,6 @@ class FCOSLoss(nn.Module):
                  center_sample_radius=1.5, use_center_sample=True):
         super().__init__()
         assert box_loss_iou_type in ['IoU', 'GIoU', 'DIoU', 'CIoU', 'EIoU'], 'wrong IoU type!'
-        if box_loss_iou_type not in ('IoU', 'GIoU'):
-            raise NotImplementedError(f'box_loss_iou_type={box_loss_iou_type}: the HIP kernel implements IoU and GIoU')
         self.positions = PointCache(strides)
         self.alpha, self.gamma = alpha, gamma
         self.strides, self.mi = strides, mi
@@ -151,7 +148,7 @@ class FCOSLoss(nn.Module):
         ctr_c = [p if p.is_contiguous() else p.contiguous() for p in ctr_preds]
         dcls = ops.focal_loss(cls_c, targets, counts, self.alpha, float(self.gamma), self.cls_loss_weight, values, 0,
                               want_grad=want_grad, tstride=8)
-        dreg, dctr = ops.fcos_reg_ctr_loss(reg_c, ctr_c, targets, counts, 0 if self.box_loss_iou_type == 'IoU' else 1,
+        dreg, dctr = ops.fcos_reg_ctr_loss(reg_c, ctr_c, targets, counts, _IOU_TYPES[self.box_loss_iou_type],
                                            self.box_loss_weight, self.center_ness_loss_weight, values, 1, 2,
                                            want_grad=want_grad)
         return values, counts, dcls, dreg, dctr

@@ -476,7 +476,7 @@ def focal_loss(cls_levels, targets, counts, alpha, gamma, weight, loss_out, slot
     return grads
 
 
-BOX_SMOOTH_L1, BOX_IOU, BOX_GIOU = 0, 1, 2
+BOX_SMOOTH_L1, BOX_IOU, BOX_GIOU, BOX_DIOU, BOX_CIOU, BOX_EIOU = 0, 1, 2, 3, 4, 5
 
 
 def retina_box_loss(reg_levels, targets, anchors, counts, box_type, beta, weight, loss_out, slot, want_grad=True):

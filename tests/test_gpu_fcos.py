@@ -67,7 +67,7 @@ def _oracle_loss(crit, preds_np, ann):
 
 
 @pytest.mark.parametrize('tag', ['TINY', 'MID', 'S1'])
-@pytest.mark.parametrize('iou', ['GIoU', 'IoU'])
+@pytest.mark.parametrize('iou', ['GIoU', 'IoU', 'DIoU', 'CIoU', 'EIoU'])
 def test_fcos_loss_and_grads(tag, iou):
     from sacv_amd.detection import losses
     H, W = gi.SHAPES[tag]

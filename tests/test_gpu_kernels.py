@@ -91,7 +91,7 @@ def _oracle_loss(crit, preds_np, ann):
 
 
 @pytest.mark.parametrize('tag', ['TINY', 'MID', 'S1'])
-@pytest.mark.parametrize('blt', ['SmoothL1', 'GIoU', 'IoU'])
+@pytest.mark.parametrize('blt', ['SmoothL1', 'GIoU', 'IoU', 'DIoU', 'CIoU', 'EIoU'])
 def test_retina_loss_and_grads(ops, tag, blt):
     from sacv_amd.detection import losses
     H, W = gi.SHAPES[tag]

@@ -78,7 +78,7 @@ int sacv_pack_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH,
                      void* stream);
 /* every data-gradient panel of a model in one launch.  descs: device array of 32-byte records
  * {const float* src; float* dst; int Cout, Cin, T, src_ohwi}; chunk_map: device int[nchunks][2] =
- * (record index, index of a 1024-element chunk of that weight). */
+ * (record index, 32x32 tile index = (tap * ceil(Cin/32) + ci_block) * ceil(Cout/32) + co_block). */
 int sacv_pack_dgrad_batched(const void* descs, const int* chunk_map, int nchunks, void* stream);
 
 /* im2col of the 7x7/s2 stem (backbones/resnet.py:42-49).  x is addressed by element strides, so both

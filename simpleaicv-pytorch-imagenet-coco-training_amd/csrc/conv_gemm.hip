@@ -830,7 +830,8 @@ __global__ void pack_w_dgrad_kernel(const float* __restrict__ w, float* __restri
     wd[idx] = w[w_src_index(co, ci, tap, Cin, T, src_ohwi)];
   }
 }
-// all data-gradient panels of a model in ONE launch: chunk_map[b] = (descriptor, first 1024-element chunk)
+// all data-gradient panels of a model in ONE launch: chunk_map[b] = (descriptor, tile index), tiles enumerated
+// as (tap, ci block of 32, co block of 32) with co fastest
 struct PackDesc {
   const float* src;
   float* dst;
@@ -838,19 +839,27 @@ struct PackDesc {
 };
 __global__ __launch_bounds__(256) void pack_dgrad_batched_kernel(const PackDesc* __restrict__ descs,
                                                                   const int* __restrict__ chunk_map) {
-  const int di = chunk_map[2 * blockIdx.x], chunk = chunk_map[2 * blockIdx.x + 1];
+  // one 32(co) x 32(ci) tile of one tap per block, transposed through LDS: reads run along ci (contiguous in a
+  // channels_last / 1x1 weight), writes along co (contiguous in the panel)
+  __shared__ float tile[32][33];
+  const int di = chunk_map[2 * blockIdx.x], t = chunk_map[2 * blockIdx.x + 1];
   const PackDesc d = descs[di];
-  const size_t total = (size_t)d.Cout * d.Cin * d.T;
+  const int nci = (d.Cin + 31) >> 5, nco = (d.Cout + 31) >> 5;
+  const int cob = t % nco;
+  const int q = t / nco;
+  const int cib = q % nci;
+  const int tap = q / nci;
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    size_t idx = (size_t)chunk * 1024 + e * 256 + threadIdx.x;
-    if (idx < total) {
-      int co = (int)(idx % d.Cout);
-      size_t q = idx / d.Cout;
-      int tap = (int)(q % d.T);
-      int ci = (int)(q / d.T);
-      d.dst[idx] = d.src[w_src_index(co, ci, tap, d.Cin, d.T, d.src_ohwi)];
-    }
+  for (int rr = 0; rr < 4; ++rr) {
+    const int co = cob * 32 + r + 8 * rr, ci = cib * 32 + c;
+    tile[r + 8 * rr][c] = (co < d.Cout && ci < d.Cin) ? d.src[w_src_index(co, ci, tap, d.Cin, d.T, d.src_ohwi)] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int ci = cib * 32 + r + 8 * rr, co = cob * 32 + c;
+    if (ci < d.Cin && co < d.Cout) d.dst[((size_t)ci * d.T + tap) * d.Cout + co] = tile[c][r + 8 * rr];
   }
 }
 // stem panel: wf[co][k], k = (kh*KW+kw)*Cin + ci for k < T*Cin, zero up to Kpad
@@ -1270,7 +1279,7 @@ int sacv_pack_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH,
 }
 
 // descs: device array of {const float* src; float* dst; int Cout, Cin, T, src_ohwi} (32 bytes each);
-// chunk_map: device int[nchunks][2] = (descriptor index, 1024-element chunk index within that weight)
+// chunk_map: device int[nchunks][2] = (descriptor index, 32x32 tile index = (tap*ceil(Cin/32) + ci_blk)*ceil(Cout/32) + co_blk)
 int sacv_pack_dgrad_batched(const void* descs, const int* chunk_map, int nchunks, void* stream) {
   SACV_CHECK_ARG(descs && chunk_map && nchunks > 0, "pack_dgrad_batched: bad args");
   static_assert(sizeof(PackDesc) == 32, "PackDesc layout is part of the ABI");

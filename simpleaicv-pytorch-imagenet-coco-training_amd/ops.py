@@ -592,7 +592,7 @@ class DgradPanels:
             out = torch.empty((ci, kh * kw * co), device=self.dev, dtype=torch.float32)
             self.panels[w.data_ptr()] = out
             recs[i] = (w.data_ptr(), out.data_ptr(), co, ci, kh * kw, weight_layout(w))
-            nchunk = (w.numel() + 1023) // 1024
+            nchunk = kh * kw * ((ci + 31) // 32) * ((co + 31) // 32)  # 32x32 (co, ci) tiles per tap
             cmap.append(np.stack([np.full(nchunk, i, dtype=np.int32), np.arange(nchunk, dtype=np.int32)], axis=1))
         cmap = np.concatenate(cmap)
         self.nchunks = int(cmap.shape[0])

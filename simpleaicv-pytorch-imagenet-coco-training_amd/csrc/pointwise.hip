@@ -217,8 +217,34 @@ __global__ __launch_bounds__(256) void eltwise_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------- column sum  out[c] (+)= sum_r x[r][c]
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial,
                                                               int R, int C, int rows_per_block) {
+  // C % 4 == 0: 16-byte loads, threads = (row lane, column group); the row lanes of a block are combined in a
+  // fixed order through LDS (deterministic).  Other C: one column per thread.
+  __shared__ float sm[256 * 4];
   const int r_begin = blockIdx.x * rows_per_block;
   const int r_end = min(R, r_begin + rows_per_block);
+  const int cg = C >> 2;
+  if ((C & 3) == 0 && cg <= 256) {
+    const int rl = 256 / cg;  // row lanes
+    const int c4 = threadIdx.x % cg, lane = threadIdx.x / cg;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    if (lane < rl) {
+      int r = r_begin + lane;
+      for (; r + rl < r_end; r += 2 * rl) {
+        s0 += *reinterpret_cast<const f32x4*>(x + (size_t)r * C + c4 * 4);
+        s1 += *reinterpret_cast<const f32x4*>(x + (size_t)(r + rl) * C + c4 * 4);
+      }
+      if (r < r_end) s0 += *reinterpret_cast<const f32x4*>(x + (size_t)r * C + c4 * 4);
+      s0 += s1;
+      *reinterpret_cast<f32x4*>(sm + (size_t)lane * C + c4 * 4) = s0;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float acc = 0.f;
+      for (int l = 0; l < rl; ++l) acc += sm[(size_t)l * C + c];
+      partial[(size_t)blockIdx.x * C + c] = acc;
+    }
+    return;
+  }
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s = 0.f;
     for (int r = r_begin; r < r_end; ++r) s += x[(size_t)r * C + c];

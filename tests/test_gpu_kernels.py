@@ -380,6 +380,11 @@ def test_colsum_and_eltwise(ops):
     out = torch.zeros(720).cuda()
     ops.colsum(x.cuda(), 720, out)
     np.testing.assert_allclose(out.cpu().numpy(), x.double().sum(0).float().numpy(), rtol=1e-5, atol=1e-4)
+    for r, c in ((33400, 256), (257, 8), (5000, 36), (131, 1000), (70, 2048), (999, 5), (1, 64)):
+        x = rnd(7, r, c)
+        out = torch.full((c,), 1.0).cuda()
+        ops.colsum(x.cuda(), c, out, accumulate=True)
+        np.testing.assert_allclose(out.cpu().numpy(), 1.0 + x.double().sum(0).float().numpy(), rtol=1e-5, atol=2e-4)
     a, b = rnd(2, 1003), torch.sigmoid(rnd(3, 1003))
     got = ops.eltwise(ops.EW_SCALE_SIGMOID_BWD, a.cuda(), b.cuda(), scalar=0.5).cpu()
     np.testing.assert_allclose(got.numpy(), (a * 0.5 * b * (1 - b)).numpy(), rtol=1e-6, atol=1e-7)

@@ -22,6 +22,9 @@ class DetectionTrainer:
                  accumulation_steps=1, process_group=None):
         self.model, self.criterion = model, criterion
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        if accumulation_steps != 1:
+            # engine.backward overwrites the gradient arena; accumulating micro-batches is not implemented
+            raise NotImplementedError('accumulation_steps > 1 (the reference recipes on this path use 1)')
         self.accumulation_steps = accumulation_steps
         self.group = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -74,6 +77,9 @@ class ClassificationTrainer:
                  process_group=None):
         self.model, self.criterion = model, criterion
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        if accumulation_steps != 1:
+            # engine.backward overwrites the gradient arena; accumulating micro-batches is not implemented
+            raise NotImplementedError('accumulation_steps > 1 (the reference recipes on this path use 1)')
         self.accumulation_steps = accumulation_steps
         self.group = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1

@@ -181,7 +181,8 @@ int sacv_fcos_split_bwd(const float* dreg, const float* dctr, const float* reg, 
 /* ---- postprocess (detection/decode.py) -------------------------------------------------------------- */
 long long sacv_decode_workspace_bytes(int B, int A, int topn);
 /* RetinaDecoder / FCOSDecoder + DecodeMethod + DetNMSMethod (decode.py:26-364).
- * kind 0 RetinaNet (geom = anchors), 1 FCOS (geom = points); nms_type 0 python_nms, 1 diou_python_nms */
+ * kind 0 RetinaNet (geom = anchors), 1 FCOS (geom = points); nms_type 0 python_nms, 1 diou_python_nms,
+ * 2 torch_nms (torchvision.ops.nms as documented: unclamped IoU, drop when IoU > threshold) */
 int sacv_decode_topk_nms(int kind, int nlev, const float* const* cls, const float* const* reg,
                          const float* const* ctr, const int* level_off, const float* geom, int B, int A, int C,
                          float min_score, int topn, int nms_type, float nms_thr, int max_obj, void* workspace,

@@ -13,6 +13,30 @@ from . import anchors as _anchors
 F32 = np.float32
 
 
+def torchvision_nms(boxes, nms_threshold=0.5):
+    """torchvision.ops.nms as documented (the reference's nms_type='torch_nms', decode.py:39-43): greedy over boxes
+    sorted by descending score; a box is dropped when its IoU with a kept box is > threshold; IoU = inter /
+    (area_a + area_b - inter) with unclamped areas (0/0 = nan never suppresses).  PARITY UNPINNED: torchvision is
+    not installed here, so this restates the published algorithm instead of being checked against the library."""
+    boxes = boxes.astype(F32)
+    areas = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    n = boxes.shape[0]
+    dead = np.zeros(n, dtype=bool)
+    keep = []
+    for i in range(n):
+        if dead[i]:
+            continue
+        keep.append(i)
+        o = boxes[i + 1:]
+        w = np.maximum(np.minimum(boxes[i, 2], o[:, 2]) - np.maximum(boxes[i, 0], o[:, 0]), F32(0))
+        h = np.maximum(np.minimum(boxes[i, 3], o[:, 3]) - np.maximum(boxes[i, 1], o[:, 1]), F32(0))
+        inter = w * h
+        with np.errstate(divide='ignore', invalid='ignore'):
+            iou = inter / (areas[i] + areas[i + 1:] - inter)
+        dead[i + 1:] |= iou > F32(nms_threshold)
+    return np.asarray(keep, dtype=np.int64)
+
+
 def greedy_nms(boxes, nms_threshold=0.5, diou=False):
     """Indices kept, boxes [N,4] fp32 already sorted by descending score."""
     boxes = boxes.astype(F32)
@@ -49,7 +73,7 @@ def greedy_nms(boxes, nms_threshold=0.5, diou=False):
 def select_detections(scores, classes, boxes, max_object_num=100, min_score_threshold=0.05,
                       topn=1000, nms_type='python_nms', nms_threshold=0.5):
     """decode.py:121-172.  scores [B,N] f32, classes [B,N] int, boxes [B,N,4] int32."""
-    assert nms_type in ('python_nms', 'diou_python_nms')
+    assert nms_type in ('python_nms', 'diou_python_nms', 'torch_nms')
     B = scores.shape[0]
     out_s = np.full((B, max_object_num), -1, dtype=F32)
     out_c = np.full((B, max_object_num), -1, dtype=F32)
@@ -63,7 +87,8 @@ def select_detections(scores, classes, boxes, max_object_num=100, min_score_thre
             continue
         order = np.argsort(-s)[:topn]
         s, c, b = s[order], c[order], b[order]
-        keep = greedy_nms(b, nms_threshold, diou=(nms_type == 'diou_python_nms'))
+        keep = (torchvision_nms(b, nms_threshold) if nms_type == 'torch_nms' else
+                greedy_nms(b, nms_threshold, diou=(nms_type == 'diou_python_nms')))
         keep = keep[:max_object_num]
         n = keep.shape[0]
         out_s[i, :n], out_c[i, :n], out_b[i, :n] = s[keep], c[keep], b[keep]

@@ -3,7 +3,8 @@
 // max_object_num.  Replaces the host NumPy path of simpleAICV/detection/decode.py:
 //   RetinaDecoder.__call__ :201-249, snap_txtytwth_to_x1y1x2y2 :251-271 (int32 truncation),
 //   FCOSDecoder :293-364, DecodeMethod.__call__ :121-172, DetNMSMethod python_nms /
-//   diou_python_nms :45-102 (class-agnostic, area = max(w*h,0), union clamped at 1e-4).
+//   diou_python_nms :45-102 (class-agnostic, area = max(w*h,0), union clamped at 1e-4); torch_nms :39-43 =
+//   torchvision.ops.nms as documented (unclamped IoU, drop when IoU > threshold; parity unpinned: no torchvision).
 // Equal scores: the reference's np.argsort(-scores) order is unspecified; here ties are broken
 // by ascending anchor index (deterministic).
 // Compiled with -ffp-contract=off so IoU arithmetic rounds like the NumPy fp32 ops.
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_sort_kernel(const float* _
 __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ s_scores,
                                                     const float* __restrict__ s_classes,
                                                     const float* __restrict__ s_boxes,
-                                                    const int* __restrict__ s_count, int topn, float thr, int diou,
+                                                    const int* __restrict__ s_count, int topn, float thr, int mode,
                                                     int max_obj, float* __restrict__ out_scores,
                                                     float* __restrict__ out_classes, float* __restrict__ out_boxes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ s_s
     f32x4 v = *reinterpret_cast<const f32x4*>(s_boxes + ((size_t)b * topn + tid) * 4);
     box[tid] = v;
     float w = v[2] - v[0], h = v[3] - v[1];
-    area[tid] = fmaxf(w * h, 0.f);
+    area[tid] = mode == 2 ? w * h : fmaxf(w * h, 0.f);  // torchvision.ops.nms does not clamp
   }
   __syncthreads();
   const int nwords = (n + 63) >> 6;
@@ -257,9 +258,10 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ s_s
       float brx = fminf(bi[2], bj[2]), bry = fminf(bi[3], bj[3]);
       float sw = fmaxf(brx - tlx, 0.f), sh = fmaxf(bry - tly, 0.f);
       float inter = sw * sh;
-      float uni = fmaxf((ai + area[j]) - inter, 1e-4f);
+      float uni = (ai + area[j]) - inter;
+      if (mode != 2) uni = fmaxf(uni, 1e-4f);
       float iou = inter / uni;
-      if (diou) {
+      if (mode == 1) {
         float ex = fmaxf(fmaxf(bi[2], bj[2]) - fminf(bi[0], bj[0]), 0.f);
         float ey = fmaxf(fmaxf(bi[3], bj[3]) - fminf(bi[1], bj[1]), 0.f);
         float c2 = fmaxf(ex * ex + ey * ey, 1e-4f);
@@ -269,7 +271,8 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ s_s
         float p2 = dx * dx + dy * dy;
         iou = iou - p2 / c2;
       }
-      if (!(iou < thr)) bits |= (1ull << jj);
+      // python_nms / diou_python_nms keep iou < thr; torch_nms (torchvision) drops iou > thr (nan keeps)
+      if (mode == 2 ? (iou > thr) : !(iou < thr)) bits |= (1ull << jj);
     }
     mask[(size_t)i * 16 + w] = bits;
   }
@@ -327,7 +330,8 @@ int sacv_decode_topk_nms(int kind, int nlev, const float* const* cls, const floa
   SACV_CHECK_ARG(nlev >= 1 && nlev <= DMAXL, "decode: nlev");
   SACV_CHECK_ARG(topn >= 1 && topn <= TOPN_MAX, "decode: topn must be in [1, %d]", TOPN_MAX);
   SACV_CHECK_ARG(max_obj >= 1 && max_obj <= 1024, "decode: max_object_num must be in [1, 1024]");
-  SACV_CHECK_ARG(nms_type == 0 || nms_type == 1, "decode: nms_type must be 0 (python_nms) or 1 (diou_python_nms)");
+  SACV_CHECK_ARG(nms_type >= 0 && nms_type <= 2,
+                 "decode: nms_type must be 0 (python_nms), 1 (diou_python_nms) or 2 (torch_nms)");
   SACV_CHECK_ARG(level_off[nlev] == A, "decode: level offsets do not sum to A");
   SACV_CHECK_ARG(geom && workspace && out_scores && out_classes && out_boxes, "decode: null pointer");
   SACV_CHECK_ARG(min_score >= 0.f, "decode: min_score_threshold must be >= 0");

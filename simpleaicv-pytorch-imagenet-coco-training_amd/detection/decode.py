@@ -13,7 +13,7 @@ from .losses import AnchorCache, PointCache
 
 __all__ = ['RetinaDecoder', 'FCOSDecoder']
 
-_NMS = {'python_nms': 0, 'diou_python_nms': 1}
+_NMS = {'python_nms': 0, 'diou_python_nms': 1, 'torch_nms': 2}  # torch_nms: torchvision.ops.nms semantics
 
 
 class RetinaDecoder:
@@ -22,9 +22,6 @@ class RetinaDecoder:
                  scales=[2**0, 2**(1.0 / 3.0), 2**(2.0 / 3.0)], strides=[8, 16, 32, 64, 128], max_object_num=100,
                  min_score_threshold=0.05, topn=1000, nms_type='python_nms', nms_threshold=0.5):
         assert nms_type in ['torch_nms', 'python_nms', 'diou_python_nms'], 'wrong nms type!'
-        if nms_type not in _NMS:
-            raise NotImplementedError('nms_type=torch_nms needs torchvision (absent); use python_nms / '
-                                      'diou_python_nms, which run as HIP kernels')
         self.anchors = AnchorCache(areas, ratios, scales, strides)
         self.max_object_num, self.min_score_threshold, self.topn = max_object_num, min_score_threshold, topn
         self.nms_type, self.nms_threshold = nms_type, nms_threshold
@@ -54,9 +51,6 @@ class FCOSDecoder:
     def __init__(self, strides=[8, 16, 32, 64, 128], max_object_num=100, min_score_threshold=0.05, topn=1000,
                  nms_type='python_nms', nms_threshold=0.6):
         assert nms_type in ['torch_nms', 'python_nms', 'diou_python_nms'], 'wrong nms type!'
-        if nms_type not in _NMS:
-            raise NotImplementedError('nms_type=torch_nms needs torchvision (absent); use python_nms / '
-                                      'diou_python_nms, which run as HIP kernels')
         self.positions = PointCache(strides)
         self.max_object_num, self.min_score_threshold, self.topn = max_object_num, min_score_threshold, topn
         self.nms_type, self.nms_threshold = nms_type, nms_threshold

@@ -54,8 +54,9 @@ def test_no_cpu_fallback():
     dec = decode.__dict__['RetinaDecoder']()
     with pytest.raises(RuntimeError, match='MI355X'):
         dec([[torch.zeros(1, 2, 2, 9, 80)], [torch.zeros(1, 2, 2, 9, 4)]])
-    with pytest.raises(NotImplementedError):
-        decode.__dict__['RetinaDecoder'](nms_type='torch_nms')
+    decode.__dict__['RetinaDecoder'](nms_type='torch_nms')  # torchvision.ops.nms semantics, no torchvision needed
+    with pytest.raises(AssertionError):
+        decode.__dict__['RetinaDecoder'](nms_type='soft_nms')
 
 
 def test_bench_generator_matches_fixture_generator():

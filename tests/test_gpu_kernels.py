@@ -408,7 +408,7 @@ def test_adamw_matches_torch(ops):
 
 # ----------------------------------------------------------------------------------------- decode / NMS
 @pytest.mark.parametrize('tag', ['TINY', 'MID', 'S1'])
-@pytest.mark.parametrize('nms_type', ['python_nms', 'diou_python_nms'])
+@pytest.mark.parametrize('nms_type', ['python_nms', 'diou_python_nms', 'torch_nms'])
 def test_retina_decoder(ops, tag, nms_type, golden_dir):
     from sacv_amd.detection import decode
     H, W = gi.SHAPES[tag]

@@ -171,3 +171,16 @@ def test_decoders(G, tag):
         assert np.array_equal(s, G.decode[key + '_scores'])
         assert np.array_equal(c, G.decode[key + '_classes'])
         assert np.array_equal(b, G.decode[key + '_boxes'])
+
+
+def test_torchvision_nms_restatement_agrees_with_python_nms_on_regular_boxes():
+    """nms_type='torch_nms' (torchvision.ops.nms; parity unpinned, torchvision absent): on boxes with positive area
+    and no IoU exactly at the threshold it must keep what the reference's python_nms keeps; a zero-area duplicate
+    (IoU 0/0) is kept by torchvision's rule."""
+    rng = np.random.default_rng(0)
+    xy = rng.uniform(0, 200, (300, 2)).astype(np.float32)
+    wh = rng.uniform(5, 80, (300, 2)).astype(np.float32)
+    boxes = np.trunc(np.concatenate([xy, xy + wh], axis=1)).astype(np.float32)
+    assert np.array_equal(odecode.torchvision_nms(boxes, 0.5), odecode.greedy_nms(boxes, 0.5))
+    deg = np.array([[10, 10, 10, 10], [10, 10, 10, 10], [0, 0, 30, 30]], dtype=np.float32)
+    assert odecode.torchvision_nms(deg, 0.5).tolist() == [0, 1, 2]

@@ -212,6 +212,16 @@ int sacv_sgd_step(float* params, const float* grads, float* momentum_buf, long l
 int sacv_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
                     long long split, float lr, float beta1, float beta2, float eps, float wd_lo, float wd_hi,
                     int step, float grad_scale, void* stream);
+/* skip gate of the training loop (tools/scripts.py:918-974: a batch whose loss is 0 / inf / nan on any rank is
+ * skipped by all ranks), evaluated on the device: loss_skip_flag -> (all-reduce SUM of flag) -> step_gate ->
+ * *_step_gated.  state = float[4] {optimizer steps taken, skip this step, 1-beta1^t, sqrt(1-beta2^t)}. */
+int sacv_loss_skip_flag(const float* values, int n, float* flag, void* stream);
+int sacv_step_gate(const float* flag, float* state, float beta1, float beta2, void* stream);
+int sacv_adamw_step_gated(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                          long long split, float lr, float beta1, float beta2, float eps, float wd_lo, float wd_hi,
+                          const float* state, float grad_scale, void* stream);
+int sacv_sgd_step_gated(float* params, const float* grads, float* momentum_buf, long long n, long long split, float lr,
+                        float momentum, float wd_lo, float wd_hi, const float* state, float grad_scale, void* stream);
 int sacv_fill(float* p, long long n, float value, void* stream);
 
 #ifdef __cplusplus

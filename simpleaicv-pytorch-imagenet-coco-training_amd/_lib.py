@@ -58,6 +58,10 @@ SIGNATURES = {
     'sacv_avgpool_bwd': (I, [P, P, I, I, I, P]),
     'sacv_softmax_ce_fwd_bwd': (I, [P, P, P, P, I, I, F, P, P]),
     'sacv_sgd_step': (I, [P, P, P, LL, LL, F, F, F, F, I, F, P]),
+    'sacv_loss_skip_flag': (I, [P, I, P, P]),
+    'sacv_step_gate': (I, [P, P, F, F, P]),
+    'sacv_adamw_step_gated': (I, [P, P, P, P, LL, LL, F, F, F, F, F, F, P, F, P]),
+    'sacv_sgd_step_gated': (I, [P, P, P, LL, LL, F, F, F, F, P, F, P]),
     'sacv_adamw_step': (I, [P, P, P, P, LL, LL, F, F, F, F, F, F, I, F, P]),
     'sacv_fill': (I, [P, LL, F, P]),
 }

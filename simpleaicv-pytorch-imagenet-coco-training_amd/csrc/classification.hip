@@ -76,7 +76,11 @@ __global__ void ce_finalize_kernel(const float* __restrict__ partial, int n, int
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ buf, size_t n, size_t split, float lr,
                                                    float momentum, float wd_lo, float wd_hi, int first,
-                                                   float grad_scale) {
+                                                   float grad_scale, const float* __restrict__ state) {
+  if (state) {  // gated form (sacv_step_gate): skip flag and the step count live on the device
+    if (state[1] > 0.f) return;
+    first = state[0] == 1.f;
+  }
   size_t n4 = n >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 pp = *reinterpret_cast<f32x4*>(p + i * 4);
@@ -137,8 +141,23 @@ int sacv_sgd_step(float* params, const float* grads, float* momentum_buf, long l
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf,
-                     (size_t)n, (size_t)split, lr, momentum, wd_lo, wd_hi, first_step, grad_scale);
+                     (size_t)n, (size_t)split, lr, momentum, wd_lo, wd_hi, first_step, grad_scale,
+                     (const float*)nullptr);
   SACV_CHECK_LAUNCH("sgd_step");
+  return SACV_OK;
+}
+
+// as sacv_sgd_step, gated by the device-side state of sacv_step_gate (skip flag, first step = steps taken == 1)
+int sacv_sgd_step_gated(float* params, const float* grads, float* momentum_buf, long long n, long long split, float lr,
+                        float momentum, float wd_lo, float wd_hi, const float* state, float grad_scale, void* stream) {
+  SACV_CHECK_ARG(params && grads && momentum_buf && state && n > 0 && n % 4 == 0 && split % 4 == 0 && split <= n,
+                 "sgd_step_gated: bad args");
+  size_t n4 = (size_t)n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf,
+                     (size_t)n, (size_t)split, lr, momentum, wd_lo, wd_hi, 0, grad_scale, state);
+  SACV_CHECK_LAUNCH("sgd_step_gated");
   return SACV_OK;
 }
 

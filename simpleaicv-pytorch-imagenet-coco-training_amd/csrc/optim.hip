@@ -37,6 +37,65 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// ---- skip gate (tools/scripts.py:918-974): a step whose loss is 0 / inf / nan on ANY rank is skipped by every
+// rank -- no optimizer update, no step count.  Evaluated on the device so the step needs no host round trip:
+//   loss_skip_flag : flag[0] = 1 when sum(values) == 0 or a value is not finite      (per rank)
+//   [all-reduce SUM of flag over the ranks]
+//   step_gate      : state = {optimizer steps taken, skip this step, 1 - beta1^t, sqrt(1 - beta2^t)}
+//   *_step_gated   : the optimizer kernels read `state` and return at once when the step is skipped
+__global__ void loss_skip_flag_kernel(const float* __restrict__ values, int n, float* __restrict__ flag) {
+  float s = 0.f;
+  bool bad = false;
+  for (int i = 0; i < n; ++i) {
+    float v = values[i];
+    bad = bad || !(fabsf(v) <= 3.402823466e38f);  // inf or nan
+    s += v;
+  }
+  bad = bad || !(fabsf(s) <= 3.402823466e38f) || s == 0.f;
+  flag[0] = bad ? 1.f : 0.f;
+}
+__global__ void step_gate_kernel(const float* __restrict__ flag, float* __restrict__ state, float beta1, float beta2) {
+  const bool skip = flag[0] > 0.f;
+  state[1] = skip ? 1.f : 0.f;
+  if (!skip) {
+    const float t = state[0] + 1.f;
+    state[0] = t;
+    state[2] = (float)(1.0 - pow((double)beta1, (double)t));
+    state[3] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+  }
+}
+__global__ __launch_bounds__(256) void adamw_gated_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                           size_t split, float lr, float beta1, float beta2, float eps,
+                                                           float wd_lo, float wd_hi, const float* __restrict__ state,
+                                                           float grad_scale) {
+  if (state[1] > 0.f) return;
+  const float bc1 = state[2], bc2_sqrt = state[3];
+  size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 pp = *reinterpret_cast<f32x4*>(p + i * 4);
+    f32x4 gg = *reinterpret_cast<const f32x4*>(g + i * 4);
+    f32x4 mm = *reinterpret_cast<f32x4*>(m + i * 4);
+    f32x4 vv = *reinterpret_cast<f32x4*>(v + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float wd = (i * 4 + e) < split ? wd_lo : wd_hi;
+      float gr = gg[e] * grad_scale;
+      float x = pp[e] * (1.f - lr * wd);
+      float m1 = beta1 * mm[e] + (1.f - beta1) * gr;
+      float v1 = beta2 * vv[e] + (1.f - beta2) * gr * gr;
+      float denom = sqrtf(v1) / bc2_sqrt + eps;
+      x = x - (lr / bc1) * (m1 / denom);
+      pp[e] = x;
+      mm[e] = m1;
+      vv[e] = v1;
+    }
+    *reinterpret_cast<f32x4*>(p + i * 4) = pp;
+    *reinterpret_cast<f32x4*>(m + i * 4) = mm;
+    *reinterpret_cast<f32x4*>(v + i * 4) = vv;
+  }
+}
+
 __global__ void fill_kernel(float* __restrict__ p, size_t n, float value) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     p[i] = value;
@@ -60,6 +119,35 @@ int sacv_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
                      exp_avg_sq, (size_t)n, (size_t)split, lr, beta1, beta2, eps, wd_lo, wd_hi, (float)bc1,
                      (float)sqrt(bc2), grad_scale);
   SACV_CHECK_LAUNCH("adamw_step");
+  return SACV_OK;
+}
+
+int sacv_loss_skip_flag(const float* values, int n, float* flag, void* stream) {
+  SACV_CHECK_ARG(values && flag && n > 0, "loss_skip_flag: bad args");
+  hipLaunchKernelGGL(loss_skip_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, values, n, flag);
+  SACV_CHECK_LAUNCH("loss_skip_flag");
+  return SACV_OK;
+}
+
+// state: float[4] = {steps taken, skip flag of this step, 1 - beta1^t, sqrt(1 - beta2^t)}; flag[0] > 0 = skip
+int sacv_step_gate(const float* flag, float* state, float beta1, float beta2, void* stream) {
+  SACV_CHECK_ARG(flag && state, "step_gate: null pointer");
+  hipLaunchKernelGGL(step_gate_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, state, beta1, beta2);
+  SACV_CHECK_LAUNCH("step_gate");
+  return SACV_OK;
+}
+
+int sacv_adamw_step_gated(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                          long long split, float lr, float beta1, float beta2, float eps, float wd_lo, float wd_hi,
+                          const float* state, float grad_scale, void* stream) {
+  SACV_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && state, "adamw_step_gated: null pointer");
+  SACV_CHECK_ARG(n > 0 && n % 4 == 0 && split % 4 == 0 && split >= 0 && split <= n, "adamw_step_gated: bad sizes");
+  size_t n4 = (size_t)n / 4;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adamw_gated_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                     exp_avg_sq, (size_t)n, (size_t)split, lr, beta1, beta2, eps, wd_lo, wd_hi, state, grad_scale);
+  SACV_CHECK_LAUNCH("adamw_step_gated");
   return SACV_OK;
 }
 

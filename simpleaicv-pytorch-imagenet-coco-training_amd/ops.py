@@ -609,3 +609,27 @@ class DgradPanels:
 
     def get(self, w):
         return self.panels.get(w.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------ skip gate
+def loss_skip_flag(values):
+    """values: f32[k] loss terms -> f32[1] = 1 when their sum is 0 or any is inf/nan (tools/scripts.py:918-930)."""
+    flag = torch.empty(1, device=values.device, dtype=torch.float32)
+    check(lib.sacv_loss_skip_flag(_ptr(values), values.numel(), _ptr(flag), _stream()), 'loss_skip_flag')
+    return flag
+
+
+def step_gate(flag, state, beta1=0.9, beta2=0.999):
+    check(lib.sacv_step_gate(_ptr(flag), _ptr(state), beta1, beta2, _stream()), 'step_gate')
+
+
+def adamw_step_gated(params, grads, exp_avg, exp_avg_sq, split, lr, beta1, beta2, eps, wd_lo, wd_hi, state,
+                     grad_scale=1.0):
+    check(lib.sacv_adamw_step_gated(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), split,
+                                    lr, beta1, beta2, eps, wd_lo, wd_hi, _ptr(state), grad_scale, _stream()),
+          'adamw_step_gated')
+
+
+def sgd_step_gated(params, grads, momentum_buf, split, lr, momentum, wd_lo, wd_hi, state, grad_scale=1.0):
+    check(lib.sacv_sgd_step_gated(_ptr(params), _ptr(grads), _ptr(momentum_buf), params.numel(), split, lr, momentum,
+                                  wd_lo, wd_hi, _ptr(state), grad_scale, _stream()), 'sgd_step_gated')

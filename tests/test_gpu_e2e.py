@@ -170,4 +170,43 @@ def test_trainer_step_matches_cpu_adamw():
                     assert float(d.max()) <= 0.1 * lr, (name, float(d.max()))
             assert checked > 1_000_000
     fin = trainer.finish_step(got)
-    assert set(fin) == {'cls_loss', 'reg_loss', 'loss'} and abs(fin['loss'] - fin['cls_loss'] - fin['reg_loss']) < 1e-6
+    assert set(fin) == {'cls_loss', 'reg_loss', 'loss', 'optimizer_steps', 'skipped'}
+    assert abs(fin['loss'] - fin['cls_loss'] - fin['reg_loss']) < 1e-6 and fin['optimizer_steps'] == 2 and not fin['skipped']
+
+
+def test_trainer_skips_zero_loss_batches_like_the_reference():
+    """tools/scripts.py:918-974: a batch whose loss is 0 (no positive anchor: RetinaLoss returns zeros) or inf/nan is
+    skipped -- no parameter, moment or step-count update.  The next regular batch must then be the optimizer's
+    FIRST step (bias corrections of t = 1), exactly as if the skipped batch had never been seen (BatchNorm running
+    statistics excepted: the reference also runs the forward pass of a batch it skips)."""
+    from sacv_amd.detection import losses
+    from sacv_amd.train import DetectionTrainer
+    H, W = gi.TINY
+    sd = omodel.init_retinanet_state(0)
+    net = build_gpu_model(sd)
+    tr = DetectionTrainer(net, losses.__dict__['RetinaLoss'](), lr=1e-4, weight_decay=1e-3)
+    images = torch.tensor(synth.images(5, 2, H, W)).cuda()
+    empty = torch.tensor(synth.annotations(1, 2, H, W, boxes_per_image=0)).cuda()
+    boxes = torch.tensor(synth.annotations(3, 2, H, W, boxes_per_image=8)).cuda()
+    p0 = net.arena.params.clone()
+    fin = tr.finish_step(tr.step(images, empty))
+    assert fin['skipped'] and fin['optimizer_steps'] == 0 and fin['loss'] == 0.0
+    assert torch.equal(net.arena.params, p0)
+    assert float(tr.exp_avg.abs().max()) == 0.0 and float(tr.exp_avg_sq.abs().max()) == 0.0
+    # reference run of the same first real step with torch.optim.AdamW state at t = 1
+    fin = tr.finish_step(tr.step(images, boxes))
+    assert not fin['skipped'] and fin['optimizer_steps'] == 1
+    g = net.arena.grads.clone()
+    m = 0.1 * g
+    v = 0.001 * g * g
+    upd = (m / 0.1) / ((v.sqrt() / (0.001**0.5)) + 1e-8)  # t = 1: bc1 = 0.1, bc2 = 0.001
+    wd = torch.zeros_like(p0)
+    wd[net.arena.split:] = 1e-3
+    want = p0 * (1 - 1e-4 * wd) - 1e-4 * upd
+    torch.testing.assert_close(net.arena.params, want, rtol=1e-5, atol=2e-7)
+    # a nan loss term skips as well
+    from sacv_amd import ops
+    flag = ops.loss_skip_flag(torch.tensor([0.5, float('nan')]).cuda())
+    assert float(flag) == 1.0
+    assert float(ops.loss_skip_flag(torch.tensor([0.5, 0.25]).cuda())) == 0.0
+    assert float(ops.loss_skip_flag(torch.tensor([float('inf'), 0.25]).cuda())) == 1.0

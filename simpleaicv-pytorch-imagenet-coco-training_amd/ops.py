@@ -213,11 +213,19 @@ def conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, accumulate=False, cin_pad=
     chunk = _wgrad_chunk([b * h * w for b, h, w in zip(nb, ho, wo)], cout, kh * kw * cin_pad)
     nbytes = lib.sacv_conv2d_wgrad_workspace_bytes(n, iarr(nb), iarr(ho), iarr(wo), cin_pad, cout, kh, kw, chunk)
     ws = workspace(nbytes, dys[0].device, 'wgrad')
-    check(lib.sacv_conv2d_wgrad(
-        n, parr([d.data_ptr() for d in dys]), parr([x.data_ptr() for x in xs]), iarr(nb),
-        iarr([x.shape[1] for x in xs]), iarr([x.shape[2] for x in xs]), iarr(ho), iarr(wo),
-        _ptr(dw), ws.data_ptr(), cin, cin_pad, cout, kh, kw, stride, pad, chunk, int(accumulate), dw_taps,
-        dw_layout, _stream()), 'conv2d_wgrad')
+    def launch():
+        check(lib.sacv_conv2d_wgrad(
+            n, parr([d.data_ptr() for d in dys]), parr([x.data_ptr() for x in xs]), iarr(nb),
+            iarr([x.shape[1] for x in xs]), iarr([x.shape[2] for x in xs]), iarr(ho), iarr(wo),
+            _ptr(dw), ws.data_ptr(), cin, cin_pad, cout, kh, kw, stride, pad, chunk, int(accumulate), dw_taps,
+            dw_layout, _stream()), 'conv2d_wgrad')
+
+    if TIMER is not None:  # algorithmic flops of the weight gradient (+ its slab reduction, same event pair)
+        taps = dw_taps if dw_taps else kh * kw
+        flops = 2.0 * sum(b * h * w for b, h, w in zip(nb, ho, wo)) * cout * cin * taps
+        TIMER.time(f'conv_tn|k{kh} s{stride} ci{cin} co{cout} np{n}', flops, launch)
+    else:
+        launch()
     return dw
 
 

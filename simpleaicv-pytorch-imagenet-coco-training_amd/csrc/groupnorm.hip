@@ -63,27 +63,31 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const float* __r
   }
 }
 
-// forward second stage: stats[n][g] = (mean, invstd)
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nb, int N, int HW, int C, int G, float eps,
-                                   float* __restrict__ stats) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * G) return;
-  int n = i / G, g = i - n * G;
-  int cpg = C / G;
+// forward second stage: stats[n][g] = (mean, invstd).  One wave per (image, group): lane l sums the elements
+// l, l+64, ... of the nb x (C/G) partials in fp64, then a fixed shuffle tree (deterministic).
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nb, int N, int HW,
+                                                          int C, int G, float eps, float* __restrict__ stats) {
+  const int i = blockIdx.x;  // (n, g)
+  const int n = i / G, g = i - n * G;
+  const int cpg = C / G;
+  const int total = nb * cpg;
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nb; ++b) {
+  for (int e = threadIdx.x; e < total; e += 64) {
+    const int b = e / cpg, c = g * cpg + (e - b * cpg);
     const float* p = partial + ((size_t)n * nb + b) * 2 * C;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-      s += (double)p[c];
-      q += (double)p[C + c];
-    }
+    s += (double)p[c];
+    q += (double)p[C + c];
   }
-  double m = (double)HW * cpg;
-  double mean = s / m;
-  double var = q / m - mean * mean;
-  if (var < 0.0) var = 0.0;
-  stats[(size_t)i * 2] = (float)mean;
-  stats[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  s = wave_sum_d(s);
+  q = wave_sum_d(q);
+  if (threadIdx.x == 0) {
+    double m = (double)HW * cpg;
+    double mean = s / m;
+    double var = q / m - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(size_t)i * 2] = (float)mean;
+    stats[(size_t)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
@@ -113,48 +117,67 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 // backward second stage.  Per (n,c): A = sum_hw g, B = sum_hw g*xhat.
 //   dbeta[c] (+)= sum_n A, dgamma[c] (+)= sum_n B
 //   coef[n][g] = (sum_{c in g} gamma[c]*A / m, sum_{c in g} gamma[c]*B / m),  m = HW * C/G
-__global__ void gn_bwd_finalize_kernel(const float* __restrict__ partial, int nb, int N, int HW, int C, int G,
-                                       const float* __restrict__ gamma, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ coef, int accumulate) {
-  extern __shared__ double sh[];  // [N][2][C]
-  const int tid = threadIdx.x;
-  for (int i = tid; i < N * C; i += blockDim.x) {
-    int n = i / C, c = i - n * C;
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < nb; ++k) {
+// One block per group g: the N x C/G (image, channel) pairs of the group share the block's 256 threads, `lanes`
+// threads per pair summing every lanes-th partial row in fp64; fixed-order combines through LDS (deterministic).
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partial, int nb, int N, int HW,
+                                                               int C, int G, const float* __restrict__ gamma,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ coef, int accumulate) {
+  __shared__ double shA[256], shB[256];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int cpg = C / G;
+  const int pairs = N * cpg;  // <= 256 (checked on the host)
+  const int lanes = 256 / pairs;
+  const int pair = tid / lanes, lane = tid - pair * lanes;
+  double a = 0.0, b = 0.0;
+  if (pair < pairs) {
+    const int n = pair / cpg, c = g * cpg + (pair - n * cpg);
+    for (int k = lane; k < nb; k += lanes) {
       const float* p = partial + ((size_t)n * nb + k) * 2 * C;
       a += (double)p[c];
       b += (double)p[C + c];
     }
-    sh[((size_t)n * 2) * C + c] = a;
-    sh[((size_t)n * 2 + 1) * C + c] = b;
+  }
+  shA[tid] = a;
+  shB[tid] = b;
+  __syncthreads();
+  if (pair < pairs && lane == 0) {
+    for (int l = 1; l < lanes; ++l) {
+      a += shA[tid + l];
+      b += shB[tid + l];
+    }
   }
   __syncthreads();
-  for (int c = tid; c < C; c += blockDim.x) {
-    double a = 0.0, b = 0.0;
+  if (pair < pairs && lane == 0) {  // compact: pair p at index p
+    shA[pair] = a;
+    shB[pair] = b;
+  }
+  __syncthreads();
+  if (tid < cpg) {  // parameter gradients of channel c: sum over the images
+    const int c = g * cpg + tid;
+    double sa = 0.0, sb = 0.0;
     for (int n = 0; n < N; ++n) {
-      a += sh[((size_t)n * 2) * C + c];
-      b += sh[((size_t)n * 2 + 1) * C + c];
+      sa += shA[n * cpg + tid];
+      sb += shB[n * cpg + tid];
     }
     if (accumulate) {
-      dbeta[c] += (float)a;
-      dgamma[c] += (float)b;
+      dbeta[c] += (float)sa;
+      dgamma[c] += (float)sb;
     } else {
-      dbeta[c] = (float)a;
-      dgamma[c] = (float)b;
+      dbeta[c] = (float)sa;
+      dgamma[c] = (float)sb;
     }
   }
-  const int cpg = C / G;
-  const double m = (double)HW * cpg;
-  for (int i = tid; i < N * G; i += blockDim.x) {
-    int n = i / G, g = i - n * G;
+  if (tid >= 64 && tid < 64 + N) {  // coefficients of (image n, group g)
+    const int n = tid - 64;
+    const double m = (double)HW * cpg;
     double s1 = 0.0, s2 = 0.0;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-      s1 += (double)gamma[c] * sh[((size_t)n * 2) * C + c];
-      s2 += (double)gamma[c] * sh[((size_t)n * 2 + 1) * C + c];
+    for (int c = 0; c < cpg; ++c) {
+      s1 += (double)gamma[g * cpg + c] * shA[n * cpg + c];
+      s2 += (double)gamma[g * cpg + c] * shB[n * cpg + c];
     }
-    coef[(size_t)i * 2] = (float)(s1 / m);
-    coef[(size_t)i * 2 + 1] = (float)(s2 / m);
+    coef[((size_t)n * G + g) * 2] = (float)(s1 / m);
+    coef[((size_t)n * G + g) * 2 + 1] = (float)(s2 / m);
   }
 }
 
@@ -220,8 +243,7 @@ int sacv_groupnorm_fwd(const float* x, const float* gamma, const float* beta, fl
   hipLaunchKernelGGL((gn_partial_kernel<0>), dim3(nb, N), dim3(GN_THREADS), lds, st, x, nullptr, nullptr, nullptr,
                      HW, C, G, rpb, workspace);
   SACV_CHECK_LAUNCH("gn_partial");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((N * G + 63) / 64), dim3(64), 0, st, workspace, nb, N, HW, C, G, eps,
-                     stats);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(64), 0, st, workspace, nb, N, HW, C, G, eps, stats);
   SACV_CHECK_LAUNCH("gn_finalize");
   size_t total = (size_t)N * HW * (C / 4);
   int blocks = (int)((total + 255) / 256);
@@ -237,7 +259,7 @@ int sacv_groupnorm_bwd(const float* x, const float* dz, const float* zmask, cons
                        float* workspace, void* stream) {
   SACV_CHECK_ARG(x && dz && stats && gamma && dx && dgamma && dbeta && workspace, "groupnorm_bwd: null pointer");
   SACV_CHECK_ARG(C % G == 0 && (C / G) % 4 == 0 && C / 4 <= GN_THREADS, "groupnorm_bwd: bad C/G");
-  SACV_CHECK_ARG((size_t)N * 2 * C * sizeof(double) <= 64 * 1024, "groupnorm_bwd: N*C too large");
+  SACV_CHECK_ARG(N * (C / G) <= 256 && N <= 192, "groupnorm_bwd: N * C/G must be <= 256");
   int rpb;
   int nb = gn_blocks(HW, &rpb);
   hipStream_t st = (hipStream_t)stream;
@@ -247,8 +269,8 @@ int sacv_groupnorm_bwd(const float* x, const float* dz, const float* zmask, cons
   hipLaunchKernelGGL((gn_partial_kernel<1>), dim3(nb, N), dim3(GN_THREADS), lds, st, x, dz, zmask, stats, HW, C, G,
                      rpb, workspace);
   SACV_CHECK_LAUNCH("gn_bwd_partial");
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), (size_t)N * 2 * C * sizeof(double), st, workspace,
-                     nb, N, HW, C, G, gamma, dgamma, dbeta, coef, accumulate);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(G), dim3(256), 0, st, workspace, nb, N, HW, C, G, gamma, dgamma,
+                     dbeta, coef, accumulate);
   SACV_CHECK_LAUNCH("gn_bwd_finalize");
   size_t total = (size_t)N * HW * (C / 4);
   int blocks = (int)((total + 255) / 256);

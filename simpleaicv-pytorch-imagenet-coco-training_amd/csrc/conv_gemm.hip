@@ -917,18 +917,34 @@ __global__ void im2col_stem_kernel(const float* __restrict__ x, float* __restric
 }
 
 // stem: part[s][co][k], k = tap*Cin + ci (k < T*Cin), row length Kpad -> dw[co][ci][tap]
-__global__ void wgrad_reduce_stem_kernel(const float* __restrict__ part, float* __restrict__ dw, int nchunks,
-                                         int Cout, int Cin, int T, int Kpad, int accumulate) {
-  size_t slab = (size_t)Cout * Kpad;
-  int total = Cout * T * Cin;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    int k = idx % (T * Cin);
-    int co = idx / (T * Cin);
-    int tap = k / Cin, ci = k - tap * Cin;
+__global__ __launch_bounds__(256) void wgrad_reduce_stem_kernel(const float* __restrict__ part,
+                                                                 float* __restrict__ dw, int nchunks, int Cout,
+                                                                 int Cin, int T, int Kpad, int accumulate) {
+  // 16 consecutive elements per block, 16 threads per element each summing every 16th slab; fixed-order combine
+  // through LDS (hundreds of slabs: a single thread per element was a 512-deep serial chain of loads)
+  __shared__ float red[256];
+  const size_t slab = (size_t)Cout * Kpad;
+  const int total = Cout * T * Cin;
+  const int el = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  for (int base = blockIdx.x * 16; base < total; base += gridDim.x * 16) {
+    const int idx = base + el;
     float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += part[(size_t)c * slab + (size_t)co * Kpad + k];
-    size_t o = ((size_t)co * Cin + ci) * T + tap;
-    dw[o] = accumulate ? dw[o] + s : s;
+    int k = 0, co = 0;
+    if (idx < total) {
+      k = idx % (T * Cin);
+      co = idx / (T * Cin);
+      for (int c = lane; c < nchunks; c += 16) s += part[(size_t)c * slab + (size_t)co * Kpad + k];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (lane == 0 && idx < total) {
+      float t = 0.f;
+      for (int l = 0; l < 16; ++l) t += red[l * 16 + el];
+      const int tap = k / Cin, ci = k - tap * Cin;
+      const size_t o = ((size_t)co * Cin + ci) * T + tap;
+      dw[o] = accumulate ? dw[o] + t : t;
+    }
+    __syncthreads();
   }
 }
 
@@ -1243,6 +1259,7 @@ int sacv_conv2d_wgrad(int nseg, const float* const* dy, const float* const* x, c
   if (dw_taps > 0) {
     // reinterpret: N2 = Kpad, real k < dw_taps*Cin laid out tap-major
     // handled by the generic reduce with T=dw_taps, Cin_pad=Cin when Kpad == padded T*Cin: use stem reducer
+    blocks = (Cout * dw_taps * Cin + 15) / 16;
     hipLaunchKernelGGL(wgrad_reduce_stem_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw, chunks, Cout, Cin,
                        dw_taps, Cin_pad, accumulate);
   } else {

@@ -149,7 +149,7 @@ def main():
            f'{r["algorithmic_gflop_per_launch"] * r["launches_per_step"] / 2 / tn_ms:.1f} TFLOP/s, plus `wgrad_reduce`.',
            '* HBM-bound classes (algorithmic bytes / rocprof time, peak 8 TB/s spec):', '',
            '| kernel | algorithmic GB/step | ms/step | achieved TB/s | frac of 8 TB/s | bytes counted |', '|---|---|---|---|---|---|']
-    extra = [('adamw_kernel', 37968692 * 4 * 7 / 1e9, 'read p,g,m,v write p,m,v'),
+    extra = [('adamw_gated_kernel', 37968692 * 4 * 7 / 1e9, 'read p,g,m,v write p,m,v'),
              ('im2col_stem_kernel', (2 * 3 * 800 * 1333 + 2 * 400 * 667 * 160) * 4 / 1e9, 'read image, write im2col matrix')]
     md += hbm_table(by, steps, 2, 800, 1333, extra)
     md += mfma_md

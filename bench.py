@@ -54,6 +54,27 @@ def cpu_baseline(max_steps=2):
                        f'RetinaNet-R50 fwd+RetinaLoss+bwd+AdamW, torch-CPU fp32 oracle, {t:.2f} s/step')
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` from a plain shell: start N rank processes with torch.distributed.run (the same
+    command line the driver uses) as a child, stream its output, return its exit code.  Mirrors the reference's
+    launch line `torchrun --nproc_per_node=N tools/train_detection_model.py` (train.sh of each recipe;
+    tools/train_detection_model.py:50-59 reads LOCAL_RANK and calls init_process_group('nccl'))."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        print(f'bench.py: the {n}-rank run failed with exit code {rc}', file=sys.stderr, flush=True)
+    sys.exit(rc)
+
+
 def bench_classification(args, rank, world, group, ops, synth):
     """Secondary workload: 0.classification_training/imagenet/resnet50/train_config.py --
     batch 256, 224x224, CELoss, SGD(0.1, 0.9, wd 1e-4) -- in fp32 (the reference recipe runs fp16 autocast)."""
@@ -138,14 +159,22 @@ def main():
     ap.add_argument('--no-kernel-timer', action='store_true')
     args = ap.parse_args()
 
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet (no torch.cuda
+        # call, no HIP library loaded), so starting the ranks as CHILD processes is safe; this process only
+        # forwards their output and exit code.
+        return launch_ranks(args.gpus)
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU '
+                         f'(torch.distributed.run --nproc-per-node {args.gpus}) or run bench.py without a launcher')
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} needs one process per GPU: launch with torch.distributed.run '
-                         f'--nproc-per-node {args.gpus} (WORLD_SIZE={world})')
+    if world > 1 and not os.environ.get('SACV_SHARE_GPU') and torch.cuda.device_count() < world:
+        raise SystemExit(f'--gpus {world}: only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU; '
+                         'SACV_SHARE_GPU=1 SACV_DIST_BACKEND=gloo rehearses the multi-rank path on one GPU)')
     # SACV_DIST_BACKEND=gloo + SACV_SHARE_GPU=1: rehearsal of the multi-rank path on a one-GPU box (all ranks on
     # cuda:0, collectives through the host).  The real run uses RCCL ("nccl") with one GPU per rank.
     backend = os.environ.get('SACV_DIST_BACKEND', 'nccl')

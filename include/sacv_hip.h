@@ -212,17 +212,45 @@ int sacv_sgd_step(float* params, const float* grads, float* momentum_buf, long l
 int sacv_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
                     long long split, float lr, float beta1, float beta2, float eps, float wd_lo, float wd_hi,
                     int step, float grad_scale, void* stream);
-/* skip gate of the training loop (tools/scripts.py:918-974: a batch whose loss is 0 / inf / nan on any rank is
- * skipped by all ranks), evaluated on the device: loss_skip_flag -> (all-reduce SUM of flag) -> step_gate ->
- * *_step_gated.  state = float[4] {optimizer steps taken, skip this step, 1-beta1^t, sqrt(1-beta2^t)}. */
-int sacv_loss_skip_flag(const float* values, int n, float* flag, void* stream);
+/* step gate of the training loop (tools/scripts.py:852-1050), evaluated on the device (no host round trip):
+ *   sacv_fill(flag, 1, 0) -> sacv_nonfinite_flag(images / annotations: the inf/nan input guard, :878-884)
+ *   -> sacv_loss_skip_flag(loss terms: zero / inf / nan loss, :918-930) [-> sacv_nonfinite_flag(grads, nan_only):
+ *   skip_inf_nan_grad, :951-961] -> (all-reduce SUM of flag: a batch bad on any rank is skipped by all, :963-974)
+ *   -> sacv_step_gate -> [sacv_grad_clip_coef: clip_grad_value_ / clip_grad_norm_, :978-990] -> *_step_gated.
+ * state = float[8] {optimizer steps taken, skip this step, 1-beta1^t, sqrt(1-beta2^t), clip multiplier,
+ *                   gradient norm, 0, 0}. */
+int sacv_nonfinite_flag(const float* x, long long n, int nan_only, float* flag, void* stream);
+int sacv_loss_skip_flag(const float* values, int n, float* flag, int accumulate, void* stream);
 int sacv_step_gate(const float* flag, float* state, float beta1, float beta2, void* stream);
+long long sacv_grad_clip_workspace_bytes(void);
+int sacv_grad_clip_coef(const float* grads, long long n, float grad_scale, float clip_value, float max_norm,
+                        float* state, void* workspace, void* stream);
+/* [0,split) = the 1-D tensors (lr_lo, wd_lo), the rest the >=2-D tensors (lr_hi, wd_hi): the two param_groups of
+ * build_optimizer (tools/utils.py:480-582), whose 'lr' entries Scheduler.step rewrites (tools/utils.py:199-223) */
 int sacv_adamw_step_gated(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
-                          long long split, float lr, float beta1, float beta2, float eps, float wd_lo, float wd_hi,
-                          const float* state, float grad_scale, void* stream);
-int sacv_sgd_step_gated(float* params, const float* grads, float* momentum_buf, long long n, long long split, float lr,
-                        float momentum, float wd_lo, float wd_hi, const float* state, float grad_scale, void* stream);
+                          long long split, float lr_lo, float lr_hi, float beta1, float beta2, float eps, float wd_lo,
+                          float wd_hi, const float* state, float grad_scale, float clip_value, void* stream);
+int sacv_sgd_step_gated(float* params, const float* grads, float* momentum_buf, long long n, long long split,
+                        float lr_lo, float lr_hi, float momentum, float wd_lo, float wd_hi, int nesterov,
+                        const float* state, float grad_scale, float clip_value, void* stream);
 int sacv_fill(float* p, long long n, float value, void* stream);
+
+/* ---- data-parallel exchange over RCCL / xGMI (replaces nn.parallel.DistributedDataParallel of
+ *      tools/utils.py:166-185; process group of tools/train_detection_model.py:50-59).  One communicator per
+ *      process = per GPU.  RCCL is dlopen'ed on first use (librccl.so.1, a copy already in the process first). ---- */
+int sacv_comm_unique_id_bytes(void);
+/* rank 0: rendezvous id into a HOST buffer of sacv_comm_unique_id_bytes() bytes; pass it to the other ranks */
+int sacv_comm_unique_id(void* id_out /*host*/);
+/* collective; binds to the calling thread's current HIP device */
+int sacv_comm_init(const void* id /*host*/, int rank, int world, void** comm_out);
+int sacv_comm_destroy(void* comm);
+/* gradient bucket buf[0..count) <- sum over ranks, in place, on the communicator's side HIP stream, which first
+ * waits (event) for what `producer_stream` holds so far: the transfer overlaps with later backward kernels */
+int sacv_allreduce_bucket(void* comm, float* buf, long long count, void* producer_stream);
+/* `consumer_stream` (the optimizer's) waits for every bucket enqueued so far; no host synchronisation */
+int sacv_comm_wait(void* comm, void* consumer_stream);
+/* DDP init_sync / broadcast_buffers: rank `root`'s buf overwrites every rank's, in order on `stream` */
+int sacv_comm_broadcast(void* comm, float* buf, long long count, int root, void* stream);
 
 #ifdef __cplusplus
 }

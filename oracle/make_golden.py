@@ -321,8 +321,11 @@ def _e2e(ref, name, H, W, fcos, box_loss_type='SmoothL1', ann_seed=3):
     gn = {k: float(p.grad.double().norm()) for k, p in net.named_parameters()}
     meta['grad_norm'] = gn
     # a few full small gradients and the BN running stats after one training forward
+    head = (('clsregcnt_head.cls_out.bias', 'clsregcnt_head.reg_out.bias', 'scales') if fcos else
+            ('cls_head.cls_out.bias', 'reg_head.reg_out.bias'))
     for k in ('backbone.conv1.layer.1.weight', 'backbone.layer1.0.conv1.layer.1.bias', 'fpn.P5_1.bias',
-              'backbone.layer4.2.conv3.layer.1.weight'):
+              'backbone.layer4.2.conv3.layer.1.weight', 'backbone.layer1.0.conv1.layer.0.weight',
+              'backbone.layer3.0.downsample_conv.layer.1.bias') + head:
         arrs[f'{name}_grad_{k}'] = dict(net.named_parameters())[k].grad.numpy()
     sd = net.state_dict()
     for k in ('backbone.conv1.layer.1.running_mean', 'backbone.conv1.layer.1.running_var',
@@ -422,8 +425,254 @@ def sec_cls(ref):
     json.dump(meta, open(os.path.join(GOLD, 'cls.json'), 'w'), indent=0)
 
 
+def sec_e2e_s2(ref):
+    """Full 1333x1333 batch (the collater's square padding): losses, output samples, gradient norms
+    and a few full gradients of the reference model, RetinaNet and FCOS."""
+    out, meta = {}, {}
+    for name, fcos in (('retina_S2', False), ('fcos_S2', True)):
+        m, a = _e2e(ref, name, S2[0], S2[1], fcos)
+        assert m['feature_sizes'] == synth.feature_sizes(*S2)
+        meta[name] = m
+        out.update(a)
+        print(name, m['loss'])
+    np.savez_compressed(os.path.join(GOLD, 'e2e_s2.npz'), **out)
+    json.dump(meta, open(os.path.join(GOLD, 'e2e_s2.json'), 'w'), indent=0)
+
+
+class _Cfg:
+    pass
+
+
+def _sched_cfg(name, params, epochs, lr):
+    c = _Cfg()
+    c.scheduler = (name, params)
+    c.epochs = epochs
+    c.optimizer = ('AdamW', {'lr': lr})
+    return c
+
+
+class _FakeOpt:
+    def __init__(self, lrs):
+        self.param_groups = [{'lr': v} for v in lrs]
+
+
+SCHED_CASES = {
+    # 3.detection_training/coco/res50_retinanet_retinaresize800/train_config.py:137-146 (13 epochs)
+    'retina_multistep': ('MultiStepLR', {'warm_up_epochs': 0, 'gamma': 0.1, 'milestones': [8, 12]}, 13, 1e-4, [1e-4, 1e-4]),
+    # 0.classification_training/imagenet/resnet50/train_config.py (100 epochs, milestones 30/60/90)
+    'r50_multistep': ('MultiStepLR', {'warm_up_epochs': 0, 'gamma': 0.1, 'milestones': [30, 60, 90]}, 100, 0.1, [0.1, 0.1]),
+    'warm_multistep': ('MultiStepLR', {'warm_up_epochs': 2, 'gamma': 0.5, 'milestones': [3, 5]}, 6, 2e-4, [2e-4, 5e-5]),
+    'cosine_warm': ('CosineLR', {'warm_up_epochs': 1, 'min_lr': 1e-6}, 8, 1e-3, [1e-3, 2.5e-4]),
+    'cosine_nomin': ('CosineLR', {'warm_up_epochs': 0}, 5, 0.1, [0.1]),
+    'poly': ('PolyLR', {'warm_up_epochs': 1, 'power': 0.9, 'min_lr': 1e-5}, 7, 0.01, [0.01, 0.02]),
+}
+
+
+def load_reference_tools_utils():
+    load_reference()
+    import importlib
+    if ROOT in sys.path:  # the repo has no `tools` package, but keep the reference's first
+        pass
+    return importlib.import_module('tools.utils')
+
+
+def sec_scheduler(ref):
+    """LR sequences of the reference Scheduler (tools/utils.py:188-272) driven the way train_detection drives it:
+    every iteration with epoch = iter_index / iters + (epoch - 1) (tools/scripts.py:1031-1033)."""
+    tu = load_reference_tools_utils()
+    out = {}
+    iters = 7
+    for key, (name, params, epochs, lr, group_lrs) in SCHED_CASES.items():
+        cfg = _sched_cfg(name, params, epochs, lr)
+        opt = _FakeOpt(group_lrs)
+        sch = tu.Scheduler(cfg, opt)
+        seq = []
+        for epoch in range(1, epochs + 1):
+            for it in range(1, iters + 1):
+                e = it / iters + (epoch - 1)
+                sch.step(opt, e)
+                seq.append([e, sch.current_lr] + [g['lr'] for g in opt.param_groups])
+        out[key] = dict(name=name, params=params, epochs=epochs, lr=lr, group_lrs=group_lrs, iters=iters, seq=seq)
+    json.dump(out, open(os.path.join(GOLD, 'scheduler.json'), 'w'))
+    print('scheduler ok', {k: len(v['seq']) for k, v in out.items()})
+
+
+def _module_of(name):
+    parts = name.split('.')
+    return '.'.join(parts[:2]) if parts[0] == 'backbone' else parts[0]
+
+
+def _run_reference_loop(ref, tu, H, W, n_iters, accumulation_steps=1, clip_grad_value=0.0, clip_max_norm=0.0,
+                        sched=('MultiStepLR', {'warm_up_epochs': 0, 'gamma': 0.1, 'milestones': [1, 2]}), epochs=3,
+                        iters_per_epoch=2, bad_iter=None):
+    """The body of tools/scripts.py::train_detection (:866-1036) for world size 1 on CPU, with the reference's
+    model, loss, build_optimizer and Scheduler objects (the function itself needs CUDA and a process group)."""
+    models, losses, decode = ref
+    net = models.__dict__['resnet50_retinanet'](num_classes=80)
+    net.load_state_dict(omodel.init_retinanet_state(0), strict=True)
+    net.train()
+    crit = losses.__dict__['RetinaLoss']()
+    cfg = _Cfg()
+    cfg.optimizer = ('AdamW', {'lr': 1e-4, 'global_weight_decay': False, 'weight_decay': 1e-3,
+                               'no_weight_decay_layer_name_list': []})
+    cfg.scheduler = sched
+    cfg.epochs = epochs
+    optimizer, layer_list = tu.build_optimizer(cfg, net)
+    scheduler = tu.Scheduler(cfg, optimizer)
+    rec = dict(groups=[dict(n=len(g['params']), weight_decay=g['weight_decay'], lr=g['lr'])
+                       for g in optimizer.param_groups], iters=[])
+    iter_index, epoch, seen = 1, 1, 0
+    data_i = 0
+    while seen < n_iters:
+        images = torch.tensor(synth.images(40 + data_i, 2, H, W))
+        annots = torch.tensor(synth.annotations(60 + data_i, 2, H, W, boxes_per_image=6))
+        if bad_iter is not None and data_i == bad_iter:
+            annots[0, 0, 0] = float('inf')  # an inf in the annotations: the input guard must skip the batch
+        data_i += 1
+        seen += 1
+        skip = bool(torch.any(torch.isinf(images)) or torch.any(torch.isinf(annots)) or
+                    torch.any(torch.isnan(images)) or torch.any(torch.isnan(annots)))
+        outs = net(images)
+        loss_value = crit(outs, annots)
+        loss = sum(loss_value.values())
+        bad = any(bool(torch.any(torch.isinf(v)) or torch.any(torch.isnan(v))) for v in loss_value.values())
+        if loss == 0. or bad:
+            skip = True
+        loss = loss / accumulation_steps
+        it = dict(loss={k: float(v) / accumulation_steps for k, v in loss_value.items()}, skipped=False,
+                  iter_index=iter_index)
+        loss.backward()
+        if skip:
+            optimizer.zero_grad()
+            it['skipped'] = True
+            rec['iters'].append(it)
+            continue
+        if iter_index % accumulation_steps == 0:
+            if clip_grad_value > 0 or clip_max_norm > 0:
+                if clip_grad_value > 0:
+                    torch.nn.utils.clip_grad_value_(net.parameters(), clip_grad_value)
+                if clip_max_norm > 0:
+                    it['grad_norm'] = float(torch.nn.utils.clip_grad_norm_(net.parameters(), clip_max_norm))
+            optimizer.step()
+            optimizer.zero_grad()
+            scheduler.step(optimizer, iter_index / iters_per_epoch + (epoch - 1))
+            it['lr_after'] = [g['lr'] for g in optimizer.param_groups]
+        if iter_index == iters_per_epoch:
+            iter_index, epoch = 0, epoch + 1
+        iter_index += 1
+        rec['iters'].append(it)
+    mods = {}
+    for k, p in net.named_parameters():
+        mods.setdefault(_module_of(k), 0.0)
+        mods[_module_of(k)] += float(p.detach().double().pow(2).sum())
+    rec['module_param_norm'] = {k: float(np.sqrt(v)) for k, v in mods.items()}
+    init, dmods = omodel.init_retinanet_state(0), {}
+    for k, p in net.named_parameters():  # how far the optimizer moved each module (sensitive to lr / clip / skips)
+        dmods.setdefault(_module_of(k), 0.0)
+        dmods[_module_of(k)] += float((p.detach().double() - init[k].double()).pow(2).sum())
+    rec['module_delta_norm'] = {k: float(np.sqrt(v)) for k, v in dmods.items()}
+    rec['param_norm'] = {k: float(p.detach().double().norm()) for k, p in net.named_parameters()}
+    sd = optimizer.state_dict()
+    rec['opt_steps'] = sorted({float(v['step']) for v in sd['state'].values()})
+    # optimizer-state digests: parameter index -> (name, norms of the moments)
+    names = [n for grp in layer_list for n in grp['name']]
+    rec['opt_state_norm'] = {names[i]: [float(v['exp_avg'].double().norm()), float(v['exp_avg_sq'].double().norm())]
+                             for i, v in sd['state'].items()}
+    return rec, net
+
+
+def sec_trainer(ref):
+    """a-13: the reference's training loop for 3 iterations (model + RetinaLoss + build_optimizer AdamW + Scheduler),
+    plain / with gradient accumulation + clipping / with a batch the input guard must skip."""
+    tu = load_reference_tools_utils()
+    out = {}
+    H, W = TINY
+    rec, _ = _run_reference_loop(ref, tu, H, W, 3)
+    out['plain3'] = rec
+    rec, _ = _run_reference_loop(ref, tu, H, W, 4, accumulation_steps=2, clip_grad_value=0.05, clip_max_norm=0.5,
+                                 iters_per_epoch=4, epochs=3,
+                                 sched=('CosineLR', {'warm_up_epochs': 1, 'min_lr': 1e-6}))
+    out['accum2_clip'] = rec
+    rec, _ = _run_reference_loop(ref, tu, H, W, 3, bad_iter=1)
+    out['skip_inf_annot'] = rec
+    H, W = MID
+    rec, _ = _run_reference_loop(ref, tu, H, W, 3)
+    out['plain3_MID'] = rec
+    json.dump(out, open(os.path.join(GOLD, 'trainer.json'), 'w'))
+    for k, v in out.items():
+        print(k, [(i['loss'], i['skipped']) for i in v['iters']], v['opt_steps'])
+
+
+def sec_collate(ref):
+    """Normalize + DetectionCollater of the reference (simpleAICV/detection/common.py:223-286) on seeded uint8
+    images of ragged sizes: full output for a small yolo-style size, sha256 + strided samples at 1333."""
+    load_reference()
+    import importlib
+    common = importlib.import_module('simpleAICV.detection.common')
+    out, meta = {}, {}
+    for tag, resize, rtype, shapes in (('yolo64', 64, 'yolo_style', [(40, 64), (64, 33), (17, 21)]),
+                                       ('retina800', 800, 'retina_style', [(800, 1201), (750, 1333)]),
+                                       ('retina96', 96, 'retina_style', [(96, 160), (60, 100), (1, 1)])):
+        samples = []
+        for i, (h, w) in enumerate(shapes):
+            img = synth.uint8_image(900 + 7 * i, h, w)
+            na = [3, 0, 100][i % 3]
+            ann = synth.annotations(901 + i, 1, h, w, boxes_per_image=na, max_objects=max(na, 1))[0][:na]
+            s = dict(image=img.astype(np.float32), annots=ann.astype(np.float32), scale=np.float32(1.0 + 0.25 * i),
+                     size=np.array([h, w], dtype=np.float32))
+            s = common.Normalize()(s)
+            samples.append(s)
+        coll = common.DetectionCollater(resize=resize, resize_type=rtype, max_annots_num=100)
+        res = coll(samples)
+        img = res['image']
+        assert img.shape[1] == 3 and not img.is_contiguous()  # logical NCHW, channels_last storage
+        a = img.permute(0, 2, 3, 1).contiguous().numpy()      # [B,R,R,3]
+        meta[tag] = dict(resize=resize, resize_type=rtype, shapes=shapes, R=int(a.shape[1]), sha=sha(a),
+                         annots_sha=sha(res['annots'].numpy()), sum=float(a.astype(np.float64).sum()),
+                         strides=list(img.stride()))
+        if a.size <= 64 * 64 * 3 * 3:
+            out[f'{tag}_image'] = a
+        else:
+            out[f'{tag}_samples'] = a.reshape(-1)[::9973].copy()
+        out[f'{tag}_annots'] = res['annots'].numpy()
+        out[f'{tag}_scale'] = res['scale']
+        out[f'{tag}_size'] = res['size']
+    np.savez_compressed(os.path.join(GOLD, 'collate.npz'), **out)
+    json.dump(meta, open(os.path.join(GOLD, 'collate.json'), 'w'))
+    print('collate ok', {k: v['sha'][:12] for k, v in meta.items()})
+
+
+def sec_evalpost(ref):
+    """evaluate_coco_detection's post-steps (tools/scripts.py:742-758) applied to the reference decoder's own output.
+    tools/scripts.py cannot be imported (pycocotools), so the few array statements are replayed here on the arrays:
+    boxes /= scales[:,None,None]; per image: clip x1,y1 at 0 and x2,y2 at (w,h); xyxy -> xywh."""
+    models, losses, decode = ref
+    out = {}
+    for tag, (H, W) in (('TINY', TINY), ('MID', MID)):
+        dec = decode.__dict__['RetinaDecoder'](nms_type='python_nms', nms_threshold=0.5)
+        cls, reg = synth_preds_decode(21, 2, H, W)
+        scores, classes, boxes = dec([[torch.tensor(x) for x in cls], [torch.tensor(x) for x in reg]])
+        scales = np.array([1.25, 0.6], dtype=np.float32)
+        sizes = np.array([[H * 0.7, W * 0.8], [H / 0.6 - 3, W / 0.6 - 5]], dtype=np.float32)
+        out[f'{tag}_boxes_in'] = boxes.copy()
+        boxes /= np.expand_dims(np.expand_dims(scales, axis=-1), axis=-1)
+        for per_image_boxes, per_image_size in zip(boxes, sizes):
+            per_image_boxes[:, 0] = np.maximum(per_image_boxes[:, 0], 0)
+            per_image_boxes[:, 1] = np.maximum(per_image_boxes[:, 1], 0)
+            per_image_boxes[:, 2] = np.minimum(per_image_boxes[:, 2], per_image_size[1])
+            per_image_boxes[:, 3] = np.minimum(per_image_boxes[:, 3], per_image_size[0])
+            per_image_boxes[:, 2:] -= per_image_boxes[:, :2]
+        out[f'{tag}_boxes_out'] = boxes
+        out[f'{tag}_scales'] = scales
+        out[f'{tag}_sizes'] = sizes
+    np.savez_compressed(os.path.join(GOLD, 'evalpost.npz'), **out)
+    print('evalpost ok')
+
+
+
 SECTIONS = dict(cls=sec_cls, contract=sec_contract, anchors=sec_anchors, assign=sec_assign, losses=sec_losses,
-                decode=sec_decode, e2e=sec_e2e, e2e_s1=sec_e2e_s1)
+                decode=sec_decode, e2e=sec_e2e, e2e_s1=sec_e2e_s1, e2e_s2=sec_e2e_s2, scheduler=sec_scheduler,
+                trainer=sec_trainer, collate=sec_collate, evalpost=sec_evalpost)
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)

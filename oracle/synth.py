@@ -43,6 +43,11 @@ def images(seed, batch, height, width):
     return uniform(seed, (batch, 3, height, width))
 
 
+def uint8_image(seed, height, width):
+    """[H,W,3] uint8 RGB image (what cv2.imread + cvtColor hand the dataset pipeline)."""
+    return np.floor(uniform(seed, (height, width, 3)).astype(np.float64) * 256.0).astype(np.uint8)
+
+
 def annotations(seed, batch, height, width, boxes_per_image=8, max_objects=100,
                 num_classes=80, size_lo=40.0, size_hi=400.0):
     """[B, max_objects, 5] fp32 (x1,y1,x2,y2,cls); padding rows are -1 (common.py:270-276)."""

@@ -58,12 +58,22 @@ SIGNATURES = {
     'sacv_avgpool_bwd': (I, [P, P, I, I, I, P]),
     'sacv_softmax_ce_fwd_bwd': (I, [P, P, P, P, I, I, F, P, P]),
     'sacv_sgd_step': (I, [P, P, P, LL, LL, F, F, F, F, I, F, P]),
-    'sacv_loss_skip_flag': (I, [P, I, P, P]),
+    'sacv_nonfinite_flag': (I, [P, LL, I, P, P]),
+    'sacv_loss_skip_flag': (I, [P, I, P, I, P]),
     'sacv_step_gate': (I, [P, P, F, F, P]),
-    'sacv_adamw_step_gated': (I, [P, P, P, P, LL, LL, F, F, F, F, F, F, P, F, P]),
-    'sacv_sgd_step_gated': (I, [P, P, P, LL, LL, F, F, F, F, P, F, P]),
+    'sacv_grad_clip_workspace_bytes': (LL, []),
+    'sacv_grad_clip_coef': (I, [P, LL, F, F, F, P, P, P]),
+    'sacv_adamw_step_gated': (I, [P, P, P, P, LL, LL, F, F, F, F, F, F, F, P, F, F, P]),
+    'sacv_sgd_step_gated': (I, [P, P, P, LL, LL, F, F, F, F, F, I, P, F, F, P]),
     'sacv_adamw_step': (I, [P, P, P, P, LL, LL, F, F, F, F, F, F, I, F, P]),
     'sacv_fill': (I, [P, LL, F, P]),
+    'sacv_comm_unique_id_bytes': (I, []),
+    'sacv_comm_unique_id': (I, [P]),
+    'sacv_comm_init': (I, [P, I, I, P]),
+    'sacv_comm_destroy': (I, [P]),
+    'sacv_allreduce_bucket': (I, [P, P, LL, P]),
+    'sacv_comm_wait': (I, [P, P]),
+    'sacv_comm_broadcast': (I, [P, P, LL, I, P]),
 }
 
 
@@ -84,7 +94,11 @@ def _load():
     return lib
 
 
+ABI_VERSION = 2
 lib = _load()
+if lib.sacv_abi_version() != ABI_VERSION:
+    raise ImportError(f'{LIB_PATH} has ABI version {lib.sacv_abi_version()}, this package needs {ABI_VERSION}: rebuild it '
+                      '(__graft_entry__.build())')
 
 
 def check(rc, what=''):

@@ -72,14 +72,17 @@ __global__ void ce_finalize_kernel(const float* __restrict__ partial, int n, int
   if (threadIdx.x == 0) loss_out[0] = (float)(s / (double)N);
 }
 
-// torch.optim.SGD (momentum, dampening 0, no nesterov): g += wd*p; buf = first ? g : mom*buf + g; p -= lr*buf
+// torch.optim.SGD (momentum, dampening 0): g += wd*p; buf = first ? g : mom*buf + g; p -= lr * (nesterov ? g + mom*buf : buf)
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ buf, size_t n, size_t split, float lr,
-                                                   float momentum, float wd_lo, float wd_hi, int first,
-                                                   float grad_scale, const float* __restrict__ state) {
-  if (state) {  // gated form (sacv_step_gate): skip flag and the step count live on the device
+                                                   float* __restrict__ buf, size_t n, size_t split, float lr_lo,
+                                                   float lr_hi, float momentum, float wd_lo, float wd_hi, int first,
+                                                   int nesterov, float grad_scale, float clip_value,
+                                                   const float* __restrict__ state) {
+  float gmul = 1.f;
+  if (state) {  // gated form (sacv_step_gate): skip flag, step count and clip multiplier live on the device
     if (state[1] > 0.f) return;
     first = state[0] == 1.f;
+    gmul = state[4];
   }
   size_t n4 = n >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -88,10 +91,14 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
     f32x4 bb = *reinterpret_cast<f32x4*>(buf + i * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float wd = (i * 4 + e) < split ? wd_lo : wd_hi;
-      float gr = gg[e] * grad_scale + wd * pp[e];
+      const bool lo = (i * 4 + e) < split;
+      const float wd = lo ? wd_lo : wd_hi;
+      const float lr = lo ? lr_lo : lr_hi;
+      float gr = gg[e] * grad_scale;
+      if (clip_value > 0.f) gr = fminf(fmaxf(gr, -clip_value), clip_value);
+      gr = gr * gmul + wd * pp[e];
       float b = first ? gr : momentum * bb[e] + gr;
-      pp[e] = pp[e] - lr * b;
+      pp[e] = pp[e] - lr * (nesterov ? gr + momentum * b : b);
       bb[e] = b;
     }
     *reinterpret_cast<f32x4*>(p + i * 4) = pp;
@@ -141,22 +148,25 @@ int sacv_sgd_step(float* params, const float* grads, float* momentum_buf, long l
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf,
-                     (size_t)n, (size_t)split, lr, momentum, wd_lo, wd_hi, first_step, grad_scale,
+                     (size_t)n, (size_t)split, lr, lr, momentum, wd_lo, wd_hi, first_step, 0, grad_scale, 0.f,
                      (const float*)nullptr);
   SACV_CHECK_LAUNCH("sgd_step");
   return SACV_OK;
 }
 
-// as sacv_sgd_step, gated by the device-side state of sacv_step_gate (skip flag, first step = steps taken == 1)
-int sacv_sgd_step_gated(float* params, const float* grads, float* momentum_buf, long long n, long long split, float lr,
-                        float momentum, float wd_lo, float wd_hi, const float* state, float grad_scale, void* stream) {
+// as sacv_sgd_step, gated by the device-side state of sacv_step_gate (skip flag, first step = steps taken == 1,
+// clip multiplier), with one learning rate per parameter group and torch's nesterov option
+int sacv_sgd_step_gated(float* params, const float* grads, float* momentum_buf, long long n, long long split,
+                        float lr_lo, float lr_hi, float momentum, float wd_lo, float wd_hi, int nesterov,
+                        const float* state, float grad_scale, float clip_value, void* stream) {
   SACV_CHECK_ARG(params && grads && momentum_buf && state && n > 0 && n % 4 == 0 && split % 4 == 0 && split <= n,
                  "sgd_step_gated: bad args");
   size_t n4 = (size_t)n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, momentum_buf,
-                     (size_t)n, (size_t)split, lr, momentum, wd_lo, wd_hi, 0, grad_scale, state);
+                     (size_t)n, (size_t)split, lr_lo, lr_hi, momentum, wd_lo, wd_hi, 0, nesterov, grad_scale,
+                     clip_value, state);
   SACV_CHECK_LAUNCH("sgd_step_gated");
   return SACV_OK;
 }

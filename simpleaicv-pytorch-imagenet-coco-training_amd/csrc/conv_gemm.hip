@@ -21,6 +21,7 @@
 // LDS image [row][36] floats: ds_write_b128 per 8-lane row group and ds_read_b128 per lane are
 // both bank-conflict free (row stride 36 dwords = 9 x 16 B, 9 odd).
 #include "sacv_common.h"
+#include <mutex>
 #include <stdlib.h>
 
 #define SACV_MAXP 8
@@ -34,6 +35,15 @@
 #define CF_ACCUM 8
 #define CF_MASK 16
 #define CF_STATS 32
+#define CF_PUBLIC_MASK 63  // the flags the C ABI accepts
+
+// Ablation switches (skip gathers / LDS stores / the K-loop barrier / fragment addressing) exist only in a
+// -DSACV_ABLATE diagnostic build (scripts/ablate_conv.py); the shipped kernel has none of them.
+#ifdef SACV_ABLATE
+#define SACV_ABL(bit) ((a.flags & (bit)) != 0)
+#else
+#define SACV_ABL(bit) false
+#endif
 
 // 16 bytes of zeros in device memory: masked-out gathers (padding taps, rows beyond M, channels beyond Cs) READ
 // THIS instead of being loaded and then replaced by zeros.  A select on the loaded VALUE makes the compiler
@@ -384,9 +394,9 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
       const bool last = (kt + 1 == ke);
       const bool have_next = !last || more;
       if (last && more) setup(sidx + 1);  // switch the gather state to the next segment
-      load_begin(last ? k_begin : kt + 1, have_next && !(a.flags & 1024));
-      const float* cA = sA + ((a.flags & 8192) ? 0 : cur * BM * LS + (wm0 + l31) * LS + 4 * lh);
-      const float* cB = sB + ((a.flags & 8192) ? 0 : cur * BN * LS + (wn0 + l31) * LS + 4 * lh);
+      load_begin(last ? k_begin : kt + 1, have_next && !SACV_ABL(1024));
+      const float* cA = sA + (SACV_ABL(8192) ? 0 : cur * BM * LS + (wm0 + l31) * LS + 4 * lh);
+      const float* cB = sB + (SACV_ABL(8192) ? 0 : cur * BN * LS + (wn0 + l31) * LS + 4 * lh);
       // The next slab's gathers (address arithmetic + 16-byte loads) and the next fragments' LDS reads
       // are issued in the shadow of the current MFMAs (an fp32 32x32x2 MFMA occupies the matrix pipe
       // for 64 cycles but the issue port for 8), so a wave keeps the pipe busy on its own instead of
@@ -445,8 +455,8 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
       // the slab of the NEXT segment stays in registers across the epilogue (the LDS is needed to stage
       // the output tile); within a segment it goes straight to the other LDS buffer
       __builtin_amdgcn_s_setprio(0);
-      if (!last && !(a.flags & 2048)) store_tile(cur ^ 1);
-      if (!(a.flags & 4096)) __syncthreads();
+      if (!last && !SACV_ABL(2048)) store_tile(cur ^ 1);
+      if (!SACV_ABL(4096)) __syncthreads();
       cur ^= 1;
     }
     SACV_STAMP_HERE();  // end of K loop
@@ -956,16 +966,17 @@ static int log2_exact(int v) {
   return ((1 << l) == v) ? l : -1;
 }
 
-static int g_num_cus = 0;
 static int num_cus() {
-  if (g_num_cus == 0) {
+  static std::once_flag once;
+  static int cus = 256;
+  std::call_once(once, [] {
     int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      g_num_cus = prop.multiProcessorCount;
-    if (g_num_cus <= 0) g_num_cus = 256;
-  }
-  return g_num_cus;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  });
+  return cus;
 }
 
 #ifndef SACV_NT_BLOCKS_PER_CU
@@ -980,6 +991,12 @@ struct NtPlan {
   double cost;  // in units of one 128x128 K-iteration
 };
 
+#ifndef SACV_SK_POLICY
+#define SACV_SK_POLICY 3  // tuning builds: -DSACV_SK_POLICY=n (scripts/), never an environment variable
+#endif
+#ifndef SACV_SK_EXTRA
+#define SACV_SK_EXTRA 6.0
+#endif
 #ifndef SACV_SK_MIN_ITERS
 #define SACV_SK_MIN_ITERS 4  // a stream-K range shorter than this is not worth its slab + fix-up
 #endif
@@ -1004,14 +1021,8 @@ static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w) {
   // Stream-K equalises the work of every CU but costs a second (partial) epilogue in the workgroups whose
   // range crosses a tile boundary and more slabs per tile in the fix-up: measured ~+12 us per launch
   // (~6 K-iterations) over a uniform split, so it wins on the long-K problems (3x3 convs, head towers).
-  static int policy = -1;
-  static double sk_extra = 6.0;
-  if (policy < 0) {
-    const char* e = getenv("SACV_SK_POLICY");  // tuning: 0 none, 1 uniform only, 2 stream-K only, 3 auto
-    policy = e ? atoi(e) : 3;
-    const char* x = getenv("SACV_SK_EXTRA");
-    if (x) sk_extra = atof(x);
-  }
+  constexpr int policy = SACV_SK_POLICY;       // 0 none, 1 uniform only, 2 stream-K only, 3 auto
+  constexpr double sk_extra = SACV_SK_EXTRA;
   p.sk_blocks = p.rem;
   double tail = KT + epi;
   if (has_ws && policy > 0) {
@@ -1053,12 +1064,11 @@ static int launch_nt(ConvArgs& a, const NtPlan& plan, float* workspace, hipStrea
   size_t lds = (size_t)2 * (BM + BN) * 36 * sizeof(float);
   size_t lds_epi = ((size_t)BM * (BN + 4) + 2 * (128 * WN / (BN / 4)) * BN) * sizeof(float);
   if (lds_epi > lds) lds = lds_epi;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;  // one per template instance; lds is a compile-time function of it
+  std::call_once(attr_once, [lds] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN, MODE, WN>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
   int launch_blocks = a.base > 0 ? grid : a.sk_blocks;
   SACV_CHECK_ARG(a.sk_blocks <= grid && (a.sk_blocks == 0 || a.sk_blocks >= a.rem_tiles),
                  "conv2d_gemm: stream-K plan outside the workspace (%d ranges)", a.sk_blocks);
@@ -1077,12 +1087,11 @@ static int launch_tn(const WgradArgs& a, int chunks, hipStream_t st) {
   size_t lds = (size_t)2 * 32 * (BM + BN) * sizeof(float);
   size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);
   if (lds_epi > lds) lds = lds_epi;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [lds] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tn_kernel<BM, BN>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
   hipLaunchKernelGGL((conv_tn_kernel<BM, BN>), dim3(ntm * ntn * chunks), dim3(256), lds, st, a);
   SACV_CHECK_LAUNCH("conv_tn_kernel");
   return SACV_OK;
@@ -1108,6 +1117,9 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
   SACV_CHECK_ARG((long long)N * KH * KW * Cs < (1LL << 30), "conv2d_gemm: weight panel too large");
   SACV_CHECK_ARG(N % 4 == 0, "conv2d_gemm: N=%d must be a multiple of 4", N);
   SACV_CHECK_ARG(!(flags & CF_STATS) || stats, "conv2d_gemm: CF_STATS without a stats buffer");
+#ifndef SACV_ABLATE
+  SACV_CHECK_ARG((flags & ~CF_PUBLIC_MASK) == 0, "conv2d_gemm: unknown flag bits 0x%x", flags & ~CF_PUBLIC_MASK);
+#endif
   ConvArgs a;
   const int BM = 128;
   int tiles = 0;

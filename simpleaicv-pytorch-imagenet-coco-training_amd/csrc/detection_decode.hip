@@ -9,6 +9,7 @@
 // by ascending anchor index (deterministic).
 // Compiled with -ffp-contract=off so IoU arithmetic rounds like the NumPy fp32 ops.
 #include "sacv_common.h"
+#include <mutex>
 #include <math.h>
 
 #define DMAXL 8
@@ -368,12 +369,11 @@ int sacv_decode_topk_nms(int kind, int nlev, const float* const* cls, const floa
                      min_score, s_scores, s_classes, s_boxes, s_count);
   SACV_CHECK_LAUNCH("select_sort_kernel");
   size_t lds = 1024 * 24 + 16 + (size_t)1024 * 16 * 8;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
-    attr_set = true;
-  }
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [lds] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  });
   hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), lds, st, s_scores, s_classes, s_boxes, s_count, topn, nms_thr,
                      nms_type, max_obj, out_scores, out_classes, out_boxes);
   SACV_CHECK_LAUNCH("nms_kernel");

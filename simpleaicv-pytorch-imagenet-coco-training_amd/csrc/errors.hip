@@ -12,4 +12,4 @@ void sacv_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* sacv_last_error(void) { return g_err; }
-extern "C" int sacv_abi_version(void) { return 1; }
+extern "C" int sacv_abi_version(void) { return 2; }

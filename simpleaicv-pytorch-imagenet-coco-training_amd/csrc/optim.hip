@@ -37,13 +37,36 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
-// ---- skip gate (tools/scripts.py:918-974): a step whose loss is 0 / inf / nan on ANY rank is skipped by every
-// rank -- no optimizer update, no step count.  Evaluated on the device so the step needs no host round trip:
-//   loss_skip_flag : flag[0] = 1 when sum(values) == 0 or a value is not finite      (per rank)
-//   [all-reduce SUM of flag over the ranks]
-//   step_gate      : state = {optimizer steps taken, skip this step, 1 - beta1^t, sqrt(1 - beta2^t)}
+// ---- step gate of the training loop (tools/scripts.py:852-1050), evaluated on the device so a step needs no host
+// round trip.  state = float[8]:
+//   [0] optimizer steps taken            [1] skip this step (0/1)
+//   [2] 1 - beta1^t                      [3] sqrt(1 - beta2^t)
+//   [4] gradient multiplier of clip_grad_norm_ (1 when off)   [5] total gradient norm (diagnostic)   [6],[7] reserved
+//   nonfinite_flag : flag[0] = 1 when any element is inf/nan          (images / annotations guard, :878-884;
+//                    nan_only = the reference's skip_inf_nan_grad test, which checks isnan twice, :951-961)
+//   loss_skip_flag : flag[0] |= sum(values) == 0 or a value is not finite                     (:918-930)
+//   [all-reduce SUM of flag over the ranks]                                                    (:963-966)
+//   step_gate      : updates state[0..3]
+//   grad_clip_coef : clip_grad_value_ + clip_grad_norm_ (:978-990) as a clamp inside the optimizer kernel and one
+//                    global multiplier state[4] = min(1, max_norm / (||clamp(g * grad_scale)|| + 1e-6))
 //   *_step_gated   : the optimizer kernels read `state` and return at once when the step is skipped
-__global__ void loss_skip_flag_kernel(const float* __restrict__ values, int n, float* __restrict__ flag) {
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ x, size_t n, int nan_only,
+                                                              float* __restrict__ flag) {
+  bool bad = false;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bad = bad || (nan_only ? (v[e] != v[e]) : !(fabsf(v[e]) <= 3.402823466e38f));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
+    float v = x[n4 * 4 + threadIdx.x];
+    bad = bad || (nan_only ? (v != v) : !(fabsf(v) <= 3.402823466e38f));
+  }
+  if (bad) flag[0] = 1.f;  // every writer stores the same value
+}
+__global__ void loss_skip_flag_kernel(const float* __restrict__ values, int n, float* __restrict__ flag,
+                                      int accumulate) {
   float s = 0.f;
   bool bad = false;
   for (int i = 0; i < n; ++i) {
@@ -52,11 +75,13 @@ __global__ void loss_skip_flag_kernel(const float* __restrict__ values, int n, f
     s += v;
   }
   bad = bad || !(fabsf(s) <= 3.402823466e38f) || s == 0.f;
+  if (accumulate) bad = bad || flag[0] > 0.f;
   flag[0] = bad ? 1.f : 0.f;
 }
 __global__ void step_gate_kernel(const float* __restrict__ flag, float* __restrict__ state, float beta1, float beta2) {
   const bool skip = flag[0] > 0.f;
   state[1] = skip ? 1.f : 0.f;
+  state[4] = 1.f;
   if (!skip) {
     const float t = state[0] + 1.f;
     state[0] = t;
@@ -64,13 +89,53 @@ __global__ void step_gate_kernel(const float* __restrict__ flag, float* __restri
     state[3] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
   }
 }
+// sum of squares of clamp(g * grad_scale, +-clip_value): per-block partials in double, fixed-order second stage
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* __restrict__ g, size_t n, float grad_scale,
+                                                          float clip_value, double* __restrict__ partial) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(g + i * 4);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float x = v[e] * grad_scale;
+      if (clip_value > 0.f) x = fminf(fmaxf(x, -clip_value), clip_value);
+      s += x * x;
+    }
+    acc += (double)s;
+  }
+  acc = wave_sum_d(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void grad_clip_coef_kernel(const double* __restrict__ partial, int nblocks, float max_norm,
+                                      float* __restrict__ state) {
+  __shared__ double red[64];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) acc += partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 64; ++i) t += red[i];
+    const float norm = (float)sqrt(t);
+    state[5] = norm;
+    float coef = 1.f;
+    if (max_norm > 0.f) coef = fminf(max_norm / (norm + 1e-6f), 1.f);  // torch.nn.utils.clip_grad_norm_
+    state[4] = coef;
+  }
+}
 __global__ __launch_bounds__(256) void adamw_gated_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                            float* __restrict__ m, float* __restrict__ v, size_t n,
-                                                           size_t split, float lr, float beta1, float beta2, float eps,
-                                                           float wd_lo, float wd_hi, const float* __restrict__ state,
-                                                           float grad_scale) {
+                                                           size_t split, float lr_lo, float lr_hi, float beta1,
+                                                           float beta2, float eps, float wd_lo, float wd_hi,
+                                                           const float* __restrict__ state, float grad_scale,
+                                                           float clip_value) {
   if (state[1] > 0.f) return;
-  const float bc1 = state[2], bc2_sqrt = state[3];
+  const float bc1 = state[2], bc2_sqrt = state[3], gmul = state[4];
   size_t n4 = n >> 2;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 pp = *reinterpret_cast<f32x4*>(p + i * 4);
@@ -79,8 +144,12 @@ __global__ __launch_bounds__(256) void adamw_gated_kernel(float* __restrict__ p,
     f32x4 vv = *reinterpret_cast<f32x4*>(v + i * 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float wd = (i * 4 + e) < split ? wd_lo : wd_hi;
+      const bool lo = (i * 4 + e) < split;
+      const float wd = lo ? wd_lo : wd_hi;
+      const float lr = lo ? lr_lo : lr_hi;
       float gr = gg[e] * grad_scale;
+      if (clip_value > 0.f) gr = fminf(fmaxf(gr, -clip_value), clip_value);
+      gr *= gmul;
       float x = pp[e] * (1.f - lr * wd);
       float m1 = beta1 * mm[e] + (1.f - beta1) * gr;
       float v1 = beta2 * vv[e] + (1.f - beta2) * gr * gr;
@@ -122,14 +191,29 @@ int sacv_adamw_step(float* params, const float* grads, float* exp_avg, float* ex
   return SACV_OK;
 }
 
-int sacv_loss_skip_flag(const float* values, int n, float* flag, void* stream) {
+// flag[0] = 1 when x holds an inf/nan (nan_only: a nan).  `flag` must have been zeroed (sacv_fill) or written by an
+// earlier flag kernel: this one only ever raises it.
+int sacv_nonfinite_flag(const float* x, long long n, int nan_only, float* flag, void* stream) {
+  SACV_CHECK_ARG(x && flag && n >= 0, "nonfinite_flag: bad args");
+  SACV_CHECK_ARG(((uintptr_t)x & 15) == 0, "nonfinite_flag: x must be 16-byte aligned");
+  if (n == 0) return SACV_OK;
+  int blocks = (int)(((size_t)n / 4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, nan_only,
+                     flag);
+  SACV_CHECK_LAUNCH("nonfinite_flag");
+  return SACV_OK;
+}
+
+int sacv_loss_skip_flag(const float* values, int n, float* flag, int accumulate, void* stream) {
   SACV_CHECK_ARG(values && flag && n > 0, "loss_skip_flag: bad args");
-  hipLaunchKernelGGL(loss_skip_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, values, n, flag);
+  hipLaunchKernelGGL(loss_skip_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, values, n, flag, accumulate);
   SACV_CHECK_LAUNCH("loss_skip_flag");
   return SACV_OK;
 }
 
-// state: float[4] = {steps taken, skip flag of this step, 1 - beta1^t, sqrt(1 - beta2^t)}; flag[0] > 0 = skip
+// state: float[8], see the layout above; flag[0] > 0 = skip
 int sacv_step_gate(const float* flag, float* state, float beta1, float beta2, void* stream) {
   SACV_CHECK_ARG(flag && state, "step_gate: null pointer");
   hipLaunchKernelGGL(step_gate_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, state, beta1, beta2);
@@ -137,16 +221,36 @@ int sacv_step_gate(const float* flag, float* state, float beta1, float beta2, vo
   return SACV_OK;
 }
 
+long long sacv_grad_clip_workspace_bytes(void) { return 1024 * (long long)sizeof(double); }
+
+// state[5] = || clamp(grads * grad_scale, +-clip_value) ||_2 over the whole arena (clip_value <= 0: no clamp),
+// state[4] = min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: 1).  Call after sacv_step_gate, before *_step_gated.
+int sacv_grad_clip_coef(const float* grads, long long n, float grad_scale, float clip_value, float max_norm,
+                        float* state, void* workspace, void* stream) {
+  SACV_CHECK_ARG(grads && state && workspace && n > 0 && n % 4 == 0, "grad_clip_coef: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = (int)(((size_t)n / 4 + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(blocks), dim3(256), 0, st, grads, (size_t)n, grad_scale, clip_value,
+                     (double*)workspace);
+  SACV_CHECK_LAUNCH("grad_sumsq");
+  hipLaunchKernelGGL(grad_clip_coef_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, blocks, max_norm,
+                     state);
+  SACV_CHECK_LAUNCH("grad_clip_coef");
+  return SACV_OK;
+}
+
 int sacv_adamw_step_gated(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
-                          long long split, float lr, float beta1, float beta2, float eps, float wd_lo, float wd_hi,
-                          const float* state, float grad_scale, void* stream) {
+                          long long split, float lr_lo, float lr_hi, float beta1, float beta2, float eps, float wd_lo,
+                          float wd_hi, const float* state, float grad_scale, float clip_value, void* stream) {
   SACV_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && state, "adamw_step_gated: null pointer");
   SACV_CHECK_ARG(n > 0 && n % 4 == 0 && split % 4 == 0 && split >= 0 && split <= n, "adamw_step_gated: bad sizes");
   size_t n4 = (size_t)n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(adamw_gated_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
-                     exp_avg_sq, (size_t)n, (size_t)split, lr, beta1, beta2, eps, wd_lo, wd_hi, state, grad_scale);
+                     exp_avg_sq, (size_t)n, (size_t)split, lr_lo, lr_hi, beta1, beta2, eps, wd_lo, wd_hi, state,
+                     grad_scale, clip_value);
   SACV_CHECK_LAUNCH("adamw_step_gated");
   return SACV_OK;
 }

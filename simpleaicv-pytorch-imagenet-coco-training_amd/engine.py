@@ -42,28 +42,13 @@ class DetectorEngine:
         self.num_classes, self.num_anchors, self.planes, self.fcos = num_classes, num_anchors, planes, fcos
         self.ctx = None
         self.bp = 'backbone.'  # key prefix of the trunk in the state_dict ('' for the bare classifier)
-        # Weight gradients are leaves of the backward dependency graph (nothing downstream reads them until
-        # the optimizer / all-reduce), so they CAN run on a side HIP stream next to the BatchNorm / data-
-        # gradient chain.  Measured on MI355X: no gain (45.9 vs 44.8 ms/step) -- the persistent conv kernels
-        # already hold every CU's LDS, so the two streams' workgroups cannot co-reside and only serialise
-        # with extra event traffic.  Kept behind a switch, off by default.
-        self.use_side_stream = False
-        self.side = None
-        self._keep = []
+        # (Weight gradients on a side HIP stream next to the BatchNorm / data-gradient chain were measured in round 1:
+        # no gain, 45.9 vs 44.8 ms/step -- the persistent conv kernels already hold every CU's LDS, so two streams'
+        # workgroups cannot co-reside.  The switch was removed; weight gradients run in stream order.)
         self._panels = None  # data-gradient weight panels, refreshed by one launch per training step
 
     def _wgrad(self, dys, xs, dw, cin, kh, kw, stride, pad, **kw_args):
-        if not self.use_side_stream:
-            ops.conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, **kw_args)
-            return
-        if self.side is None:
-            self.side = torch.cuda.Stream()
-        ev = torch.cuda.Event()
-        ev.record()
-        with torch.cuda.stream(self.side):
-            self.side.wait_event(ev)
-            ops.conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, **kw_args)
-        self._keep.append((dys, xs))  # keep the operands alive until the side stream is joined
+        ops.conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, **kw_args)
 
     def _dgrad_panel(self, w):
         """[Cin][KH*KW*Cout] panel of a weight: from the batched per-step refresh when the weight is one of the
@@ -82,11 +67,6 @@ class DetectorEngine:
             self._panels = ops.DgradPanels(ws) if ws else None
         if self._panels is not None:
             self._panels.refresh()
-
-    def _join_side(self):
-        if self.use_side_stream and self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
-        self._keep.clear()
 
     # ------------------------------------------------------------------ building blocks
     def _cba_fwd(self, x, prefix, k, stride, pad, relu, training, residual=None, keep=True):
@@ -470,11 +450,9 @@ class DetectorEngine:
     def _trunk_bwd(self, dfeat, on_stage):
         ctx = self.ctx
         if on_stage:
-            self._join_side()
             on_stage('heads')  # head gradients are final: their all-reduce can start now
         dc3, dc4, dc5 = self._fpn_bwd(dfeat)
         self._backbone_bwd(dc5, dc4, dc3, on_stage)
-        self._join_side()
         if on_stage:
             on_stage('rest')
         self.ctx = None
@@ -491,8 +469,7 @@ class DetectorEngine:
                 accum_target = dc3
             dout = self._bottleneck_bwd(c1, c2, c3, cd, dout, accum_target)
             if on_stage and bi == 0 and li in (3, 4):
-                self._join_side()
-                on_stage('neck' if li == 4 else 'mid')  # fpn + layer4 / layer3 gradients are final
+                    on_stage('neck' if li == 4 else 'mid')  # fpn + layer4 / layer3 gradients are final
         # max pool + stem
         dpool = ops.maxpool_bwd(dout, ctx['pool_idx'], ctx['pool_in_shape'], 3, 2, 1)
         st = ctx['stem']
@@ -580,10 +557,8 @@ class ClassifierEngine(DetectorEngine):
         dpooled = self._dgrad(dy, w.view(nout, nin, 1, 1), ctx['pooled'].shape, 1, 1, 0)
         dc5 = ops.avgpool_bwd(dpooled, ctx['c5_shape'])
         if on_stage:
-            self._join_side()
             on_stage('heads')
         self._backbone_bwd(dc5, None, None, on_stage)
-        self._join_side()
         if on_stage:
             on_stage('rest')
         self.ctx = None

@@ -619,11 +619,29 @@ class DgradPanels:
         return self.panels.get(w.data_ptr())
 
 
-# ------------------------------------------------------------------------------------------ skip gate
-def loss_skip_flag(values):
-    """values: f32[k] loss terms -> f32[1] = 1 when their sum is 0 or any is inf/nan (tools/scripts.py:918-930)."""
-    flag = torch.empty(1, device=values.device, dtype=torch.float32)
-    check(lib.sacv_loss_skip_flag(_ptr(values), values.numel(), _ptr(flag), _stream()), 'loss_skip_flag')
+# ------------------------------------------------------------------------------------------ step gate
+STATE_FLOATS = 8  # {steps taken, skip, 1-beta1^t, sqrt(1-beta2^t), clip multiplier, grad norm, 0, 0}
+
+
+def nonfinite_flag(x, flag, nan_only=False):
+    """flag[0] = 1 when x (any float32 CUDA tensor) holds an inf/nan (nan_only: a nan); never lowers the flag."""
+    if x.dtype != torch.float32:
+        x = x.float()
+    # any dense storage order will do (the scan is order-free): no copy of a channels_last batch
+    dense = x.is_contiguous() or (x.ndim == 4 and x.is_contiguous(memory_format=torch.channels_last))
+    if not dense or x.data_ptr() % 16:
+        x = x.contiguous().clone()
+    check(lib.sacv_nonfinite_flag(_ptr(x), x.numel(), int(nan_only), _ptr(flag), _stream()), 'nonfinite_flag')
+    return flag
+
+
+def loss_skip_flag(values, flag=None):
+    """values: f32[k] loss terms -> f32[1] = 1 when their sum is 0 or any is inf/nan (tools/scripts.py:918-930).
+    With `flag` given the result is OR-ed into it (input guard / gradient guard share the flag)."""
+    acc = flag is not None
+    if flag is None:
+        flag = torch.empty(1, device=values.device, dtype=torch.float32)
+    check(lib.sacv_loss_skip_flag(_ptr(values), values.numel(), _ptr(flag), int(acc), _stream()), 'loss_skip_flag')
     return flag
 
 
@@ -631,13 +649,23 @@ def step_gate(flag, state, beta1=0.9, beta2=0.999):
     check(lib.sacv_step_gate(_ptr(flag), _ptr(state), beta1, beta2, _stream()), 'step_gate')
 
 
+def grad_clip_coef(grads, state, grad_scale=1.0, clip_value=0.0, max_norm=0.0):
+    """state[5] = ||clamp(grads*grad_scale, +-clip_value)||, state[4] = min(1, max_norm/(norm+1e-6))."""
+    ws = workspace(lib.sacv_grad_clip_workspace_bytes(), grads.device, 'clip')
+    check(lib.sacv_grad_clip_coef(_ptr(grads), grads.numel(), grad_scale, clip_value, max_norm, _ptr(state),
+                                  ws.data_ptr(), _stream()), 'grad_clip_coef')
+
+
 def adamw_step_gated(params, grads, exp_avg, exp_avg_sq, split, lr, beta1, beta2, eps, wd_lo, wd_hi, state,
-                     grad_scale=1.0):
+                     grad_scale=1.0, clip_value=0.0, lr_hi=None):
+    """lr = learning rate of the 1-D group, lr_hi (default: the same) of the >=2-D group."""
     check(lib.sacv_adamw_step_gated(_ptr(params), _ptr(grads), _ptr(exp_avg), _ptr(exp_avg_sq), params.numel(), split,
-                                    lr, beta1, beta2, eps, wd_lo, wd_hi, _ptr(state), grad_scale, _stream()),
-          'adamw_step_gated')
+                                    lr, lr if lr_hi is None else lr_hi, beta1, beta2, eps, wd_lo, wd_hi, _ptr(state),
+                                    grad_scale, clip_value, _stream()), 'adamw_step_gated')
 
 
-def sgd_step_gated(params, grads, momentum_buf, split, lr, momentum, wd_lo, wd_hi, state, grad_scale=1.0):
-    check(lib.sacv_sgd_step_gated(_ptr(params), _ptr(grads), _ptr(momentum_buf), params.numel(), split, lr, momentum,
-                                  wd_lo, wd_hi, _ptr(state), grad_scale, _stream()), 'sgd_step_gated')
+def sgd_step_gated(params, grads, momentum_buf, split, lr, momentum, wd_lo, wd_hi, state, grad_scale=1.0,
+                   clip_value=0.0, lr_hi=None, nesterov=False):
+    check(lib.sacv_sgd_step_gated(_ptr(params), _ptr(grads), _ptr(momentum_buf), params.numel(), split, lr,
+                                  lr if lr_hi is None else lr_hi, momentum, wd_lo, wd_hi, int(nesterov), _ptr(state),
+                                  grad_scale, clip_value, _stream()), 'sgd_step_gated')

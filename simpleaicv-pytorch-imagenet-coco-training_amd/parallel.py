@@ -40,34 +40,100 @@ def stage_ranges(arena_order, offsets, numel, split):
             'rest': (0, mid_begin)}
 
 
-class GradExchanger:
+class RcclComm:
+    """Communicator of the C ABI (`sacv_comm_*`, include/sacv_hip.h): RCCL called directly from libsacv_hip.so, the
+    bucket all-reduces on a communicator-owned side HIP stream that is event-chained to the launch stream.  The
+    rendezvous id travels over the already initialised torch.distributed group (any backend)."""
 
-    def __init__(self, grads_flat, ranges, group=None):
+    def __init__(self, group=None):
+        import ctypes
+        from ._lib import lib, check
+        self._lib, self._check = lib, check
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        nbytes = lib.sacv_comm_unique_id_bytes()
+        buf = ctypes.create_string_buffer(nbytes)
+        if self.rank == 0:
+            check(lib.sacv_comm_unique_id(buf), 'comm_unique_id')
+        box = [bytes(buf.raw)]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                                       group=group)
+        handle = ctypes.c_void_p()
+        check(lib.sacv_comm_init(ctypes.create_string_buffer(box[0], nbytes), self.rank, self.world,
+                                 ctypes.byref(handle)), 'comm_init')
+        self.handle = handle
+
+    def all_reduce(self, t):
+        self._check(self._lib.sacv_allreduce_bucket(self.handle, t.data_ptr(), t.numel(),
+                                                    torch.cuda.current_stream().cuda_stream), 'allreduce_bucket')
+
+    def wait(self):
+        self._check(self._lib.sacv_comm_wait(self.handle, torch.cuda.current_stream().cuda_stream), 'comm_wait')
+
+    def broadcast(self, t, root=0):
+        self._check(self._lib.sacv_comm_broadcast(self.handle, t.data_ptr(), t.numel(), root,
+                                                  torch.cuda.current_stream().cuda_stream), 'comm_broadcast')
+
+    def close(self):
+        if self.handle:
+            self._lib.sacv_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GradExchanger:
+    """transport 'torch': torch.distributed all-reduces (backend "nccl" = RCCL on ROCm, or gloo on CPU tensors);
+    transport 'rccl': the C ABI's sacv_allreduce_bucket (RcclComm).  Same stage protocol either way."""
+
+    def __init__(self, grads_flat, ranges, group=None, comm=None):
         self.g = grads_flat
         self.ranges = ranges
         self.group = group
+        self.comm = comm
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if comm is not None:
+            self.world = comm.world
         self.pending = []
+        self.enabled = True  # False inside a gradient-accumulation window (DDP.no_sync)
 
     def stage_done(self, stage):
         """Called by the backward pass when every gradient of `stage` has been enqueued."""
-        if self.world == 1:
+        if self.world == 1 or not self.enabled:
             return
         b, e = self.ranges[stage]
-        if e > b:
+        if e <= b:
+            return
+        if self.comm is not None:
+            self.comm.all_reduce(self.g[b:e])
+            self.pending.append(None)
+        else:
             self.pending.append(dist.all_reduce(self.g[b:e], op=dist.ReduceOp.SUM, group=self.group,
                                                 async_op=True))
 
     def wait(self):
         """Make the current stream wait for all outstanding all-reduces (sums; divide by world)."""
-        for w in self.pending:
-            w.wait()
+        if self.comm is not None:
+            if self.pending:
+                self.comm.wait()
+        else:
+            for w in self.pending:
+                w.wait()
         self.pending = []
 
 
-def broadcast_buffers(flat_buffers, group=None, src=0):
+def broadcast_buffers(flat_buffers, group=None, src=0, comm=None):
     """DDP's broadcast_buffers=True: rank 0's BatchNorm running statistics overwrite every rank's
     before each forward (one flat 208 KB broadcast instead of 106 tensors)."""
+    if comm is not None:
+        if comm.world > 1 and flat_buffers.numel() > 0:
+            comm.broadcast(flat_buffers, src)
+        return
     if dist.is_initialized() and dist.get_world_size(group) > 1 and flat_buffers.numel() > 0:
         dist.broadcast(flat_buffers, src=src, group=group)
 

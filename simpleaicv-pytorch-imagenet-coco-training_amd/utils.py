@@ -1,0 +1,77 @@
+"""Host-side pieces of the training loop that sit next to the step driver (reference: tools/utils.py).
+
+`Scheduler` mirrors tools/utils.py:188-272: a stateless function of the (fractional) epoch that is called every
+iteration with `iter_index / iters + (epoch - 1)` (tools/scripts.py:1031-1033) and rewrites `param_groups[i]['lr']`
+of whatever it is given -- a torch optimizer in the reference, a sacv_amd trainer here (same attribute).  It is
+pure host arithmetic, written so that the floating-point operation ORDER equals the reference's and the LR sequence
+is bit-identical (tests/golden/scheduler.json).
+"""
+import math
+
+__all__ = ['Scheduler', 'build_trainer']
+
+
+class Scheduler:
+
+    def __init__(self, config, optimizer):
+        self.scheduler_name = config.scheduler[0]
+        self.scheduler_parameters = config.scheduler[1]
+        self.warm_up_epochs = self.scheduler_parameters['warm_up_epochs']
+        self.epochs = config.epochs
+        self.optimizer_parameters = config.optimizer[1]
+        self.lr = self.optimizer_parameters['lr']
+        self.current_lr = self.lr
+        self.init_param_groups_lr = [g['lr'] for g in optimizer.param_groups]
+        assert self.scheduler_name in ['MultiStepLR', 'CosineLR', 'PolyLR'], 'Unsupported scheduler!'
+        assert self.warm_up_epochs >= 0, 'Illegal warm_up_epochs!'
+        assert self.epochs > 0, 'Illegal epochs!'
+
+    def _lr_at(self, base_lr, epoch):
+        """Learning rate of a group whose initial rate is base_lr at fractional epoch `epoch`."""
+        sp, warm = self.scheduler_parameters, self.warm_up_epochs
+        if epoch < warm:  # linear warm-up from 0
+            return epoch / warm * base_lr
+        if self.scheduler_name == 'MultiStepLR':
+            passed = len([m for m in sp['milestones'] if m <= epoch])
+            return sp['gamma']**passed * base_lr
+        min_lr = sp['min_lr'] if 'min_lr' in sp else 0.
+        progress = (epoch - warm) / (self.epochs - warm)
+        if self.scheduler_name == 'CosineLR':
+            return 0.5 * (math.cos(progress * math.pi) + 1) * (base_lr - min_lr) + min_lr
+        return ((1 - progress)**sp['power']) * (base_lr - min_lr) + min_lr  # PolyLR
+
+    def step(self, optimizer, epoch):
+        assert len(self.init_param_groups_lr) == len(optimizer.param_groups)
+        for group, base_lr in zip(optimizer.param_groups, self.init_param_groups_lr):
+            group['lr'] = self._lr_at(base_lr, epoch)
+        self.current_lr = self._lr_at(self.lr, epoch)
+
+    def state_dict(self):
+        return dict(self.__dict__)
+
+    def load_state_dict(self, state_dict):
+        self.__dict__.update(state_dict)
+
+
+def build_trainer(config, model, criterion, process_group=None, transport='torch'):
+    """What build_optimizer (tools/utils.py:275-582) + build_training_mode (:166-185) set up for the step, for the
+    configurations this path supports: optimizer ('AdamW' for detection, 'SGD' for classification), two weight-decay
+    groups (global_weight_decay False), accumulation_steps, clip_grad_value / clip_max_norm, skip_inf_nan_grad."""
+    from .train import DetectionTrainer, ClassificationTrainer
+    name, prm = config.optimizer
+    assert name in ['SGD', 'AdamW'], 'Unsupported optimizer!'
+    if prm.get('global_weight_decay', False):
+        raise NotImplementedError('global_weight_decay=True (weight decay on 1-D tensors) is not on this path')
+    for k in ('no_weight_decay_layer_name_list', 'sub_layer_weight_decay', 'sub_layer_lr', 'lr_layer_decay'):
+        if prm.get(k):
+            raise NotImplementedError(f"optimizer option '{k}' is not on this path")
+    common = dict(lr=prm['lr'], weight_decay=prm['weight_decay'],
+                  accumulation_steps=getattr(config, 'accumulation_steps', 1), process_group=process_group,
+                  clip_grad_value=getattr(config, 'clip_grad_value', 0.0) or 0.0,
+                  clip_max_norm=getattr(config, 'clip_max_norm', 0.0) or 0.0,
+                  skip_inf_nan_grad=getattr(config, 'skip_inf_nan_grad', False), transport=transport)
+    if name == 'AdamW':
+        return DetectionTrainer(model, criterion, betas=(prm.get('beta1', 0.9), prm.get('beta2', 0.999)),
+                                eps=prm.get('eps', 1e-8), **common)
+    return ClassificationTrainer(model, criterion, momentum=prm['momentum'], nesterov=prm.get('nesterov', False),
+                                 **common)

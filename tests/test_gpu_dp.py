@@ -80,3 +80,136 @@ def test_two_rank_step_shared_gpu():
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert set(ret.keys()) == {0, 1}
     assert ret[0] == ret[1]  # averaged loss and parameter checksum agree bit for bit
+
+
+def _ddp_worker(rank, world, port, ret):
+    """Class-level path: the model wrapped in torch's DistributedDataParallel exactly as the reference's
+    build_training_mode does (tools/utils.py:178-180), loss.backward() through autograd."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import model as omodel, synth
+        from sacv_amd.detection import models, losses
+        H, W = 96, 128
+        net = models.__dict__['resnet50_retinanet'](num_classes=80)
+        net.load_state_dict(omodel.init_retinanet_state(rank))  # DDP must overwrite rank 1 with rank 0's weights
+        net = net.cuda().train()
+        ddp = torch.nn.parallel.DistributedDataParallel(net)
+        crit = losses.__dict__['RetinaLoss']()
+        images = torch.tensor(synth.images(100 + rank, 2, H, W)).cuda()
+        annots = torch.tensor(synth.annotations(200 + rank, 2, H, W, boxes_per_image=8)).cuda()
+        # each rank's own gradient first (no_sync), then the synchronised one
+        with ddp.no_sync():
+            ld = crit(ddp(images), annots)
+            sum(ld.values()).backward()
+        own = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        for p in net.parameters():
+            p.grad = None
+        ld = crit(ddp(images), annots)
+        sum(ld.values()).backward()
+        worst = 0.0
+        for n, p in net.named_parameters():
+            tot = own[n].clone()
+            dist.all_reduce(tot)
+            want = tot / world  # DDP averages
+            scale = float(want.abs().max()) + 1e-12
+            worst = max(worst, float((p.grad - want).abs().max()) / scale)
+        # BatchNorm statistics differ per rank's batch; the gradients of two consecutive forwards differ only through
+        # nothing (same weights, same inputs, train-mode batch statistics): rounding level
+        assert worst <= 1e-5, worst
+        w0 = net.backbone.layer1[0].conv2.layer[0].weight.detach().clone()
+        dist.broadcast(w0, src=0)
+        assert torch.equal(w0, net.backbone.layer1[0].conv2.layer[0].weight.detach())
+        ret[rank] = float(ld['cls_loss'])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_model_wrapped_in_torch_ddp_shared_gpu():
+    """INTEGRATION.md's claim that nn.parallel.DistributedDataParallel(model) works on the class-level path."""
+    assert torch.cuda.is_available()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ddp_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert set(ret.keys()) == {0, 1}
+
+
+def test_rccl_communicator_of_the_c_abi_world1():
+    """sacv_comm_* / sacv_allreduce_bucket with the real RCCL on the one GPU of this box: rendezvous id, communicator,
+    a bucket all-reduce on the side stream chained by events to the launch stream, the join, a broadcast."""
+    from sacv_amd.parallel import RcclComm, GradExchanger
+    comm = RcclComm()
+    assert comm.world == 1 and comm.rank == 0
+    g = torch.arange(1 << 20, dtype=torch.float32, device='cuda')
+    want = g.clone()
+    ex = GradExchanger(g, {'heads': (1 << 19, 1 << 20), 'rest': (0, 1 << 19)}, comm=comm)
+    ex.world = 2  # force the exchange path (a 1-rank sum is the identity)
+    torch.mul(g, 2.0, out=g)  # producer work on the launch stream that the side stream must wait for
+    ex.stage_done('heads')
+    ex.stage_done('rest')
+    ex.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(g, want * 2.0)
+    comm.broadcast(g[:1024])
+    torch.cuda.synchronize()
+    comm.close()
+
+
+def _nccl_worker(rank, world, port, ret, transport):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(rank)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    try:
+        from oracle import model as omodel, synth
+        from sacv_amd.detection import models, losses
+        from sacv_amd.train import DetectionTrainer
+        H, W = 96, 128
+        net = models.__dict__['resnet50_retinanet'](num_classes=80)
+        net.load_state_dict(omodel.init_retinanet_state(rank))
+        net = net.cuda().train()
+        tr = DetectionTrainer(net, losses.__dict__['RetinaLoss'](), process_group=dist.group.WORLD,
+                              transport=transport)
+        out = tr.step(torch.tensor(synth.images(100 + rank, 2, H, W)).cuda(),
+                      torch.tensor(synth.annotations(200 + rank, 2, H, W, boxes_per_image=8)).cuda())
+        fin = tr.finish_step(out)
+        p = net.arena.params.clone()
+        ref = p.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(p, ref), 'parameters diverged between ranks'
+        ret[rank] = (fin['loss'], float(p.double().sum()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('transport', ['torch', 'rccl'])
+def test_two_rank_step_over_rccl(transport):
+    """Real RCCL (backend "nccl"), one GPU per rank: needs two GPUs, skipped on a one-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs (the driver scaling run exercises this path on the 8-GPU node)')
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_worker, args=(2, _free_port(), ret, transport), nprocs=2, join=True)
+    assert ret[0] == ret[1]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain shell must start the two ranks itself and print ONE JSON line with
+    n_gpus 2 (rehearsed on this one GPU: both ranks share cuda:0, collectives through gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SACV_SHARE_GPU='1', SACV_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['value'] > 0 and d['scaling'] == 'weak'

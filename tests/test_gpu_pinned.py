@@ -1,0 +1,102 @@
+"""GPU parity against fixtures produced by the REFERENCE itself (oracle/make_golden.py) for what round 1 had only
+against the restatement: the full-size S1 (800x1333) and S2 (1333x1333) training forward/backward of RetinaNet and
+FCOS incl. elementwise gradients, the device-side Normalize + DetectionCollater, and the evaluation post-steps."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import model as omodel, synth
+from tests import golden_inputs as gi
+from tests.test_scheduler_cpu import collate_samples
+
+
+@pytest.mark.parametrize('kind,tag', [('retina', 'S1'), ('fcos', 'S1'), ('retina', 'S2'), ('fcos', 'S2')])
+def test_full_size_step_against_reference_fixture(golden_dir, kind, tag):
+    """loss dict 1e-4 (north-star tolerance), 256 samples of every output level 2e-4, all gradient norms, and the
+    full gradients of 8-9 small tensors elementwise (relative L2 and max-abs vs the tensor's scale)."""
+    from sacv_amd.detection import models, losses
+    f = 'e2e_s1' if tag == 'S1' else 'e2e_s2'
+    name = f'{kind}_{tag}'
+    meta = json.load(open(os.path.join(golden_dir, f + '.json')))[name]
+    arrs = np.load(os.path.join(golden_dir, f + '.npz'))
+    H, W = gi.SHAPES[tag]
+    fcos = kind == 'fcos'
+    net = models.__dict__['resnet50_fcos' if fcos else 'resnet50_retinanet'](num_classes=80)
+    net.load_state_dict(omodel.init_retinanet_state(0, fcos=fcos))
+    net = net.cuda().train()
+    crit = losses.__dict__['FCOSLoss' if fcos else 'RetinaLoss']()
+    outs = net(torch.tensor(synth.images(5, 2, H, W)).cuda())
+    assert [[o.shape[2], o.shape[1]] for o in outs[0]] == meta['feature_sizes']
+    ld = crit(outs, torch.tensor(synth.annotations(3, 2, H, W, boxes_per_image=8)).cuda())
+    assert set(ld) == set(meta['loss'])
+    for k, v in meta['loss'].items():
+        assert abs(float(ld[k]) - v) <= 1e-4 * max(1.0, abs(v)), (k, float(ld[k]), v)
+    for g_, grp in enumerate(outs):
+        for l, o in enumerate(grp):
+            d = gi.digest(o.detach().cpu().numpy(), 256)
+            np.testing.assert_allclose(d['samples'], arrs[f'{name}_out{g_}_l{l}_samples'], rtol=2e-4, atol=5e-6)
+    sum(ld.values()).backward()
+    rel = []
+    for pname, p in net.named_parameters():
+        n = float(p.grad.double().norm())
+        rel.append(abs(n - meta['grad_norm'][pname]) / (meta['grad_norm'][pname] + 1e-12))
+    print(f'{name}: grad-norm rel err median {np.median(rel):.2e} max {max(rel):.2e}')
+    assert float(np.median(rel)) <= 1e-2 and max(rel) <= (1e-1 if fcos else 5e-2)
+    params = dict(net.named_parameters())
+    checked = 0
+    for key in arrs.files:
+        if not key.startswith(f'{name}_grad_'):
+            continue
+        pname = key[len(f'{name}_grad_'):]
+        want = arrs[key].astype(np.float64)
+        got = params[pname].grad.detach().cpu().numpy().astype(np.float64)
+        l2 = np.linalg.norm(got - want) / (np.linalg.norm(want) + 1e-30)
+        mx = np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
+        print(f'  {pname}: rel-L2 {l2:.2e} max-abs/scale {mx:.2e}')
+        assert l2 <= 2e-2 and mx <= 3e-2, (pname, l2, mx)
+        checked += 1
+    assert checked >= 8
+    sd = net.state_dict()
+    for key in arrs.files:
+        if key.startswith(f'{name}_buf_'):
+            np.testing.assert_allclose(sd[key[len(f'{name}_buf_'):]].cpu().numpy(), arrs[key], rtol=1e-4, atol=5e-6)
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_device_collater_against_the_reference_collater(golden_dir):
+    """sacv_collate_u8 through the class mirror vs Normalize + DetectionCollater of the reference
+    (simpleAICV/detection/common.py:223-286), bit-exact, incl. the real 1333x1333 padded batch."""
+    from sacv_amd.detection import common
+    meta = json.load(open(os.path.join(golden_dir, 'collate.json')))
+    arrs = np.load(os.path.join(golden_dir, 'collate.npz'))
+    for tag, m in meta.items():
+        samples = collate_samples([tuple(s) for s in m['shapes']])
+        for i, s in enumerate(samples):
+            s['scale'] = float(arrs[f'{tag}_scale'][i])
+            s['size'] = arrs[f'{tag}_size'][i]
+        out = common.DetectionCollater(resize=m['resize'], resize_type=m['resize_type'], max_annots_num=100)(samples)
+        img = out['image']
+        assert tuple(img.shape) == (len(samples), 3, m['R'], m['R'])
+        assert list(img.stride()) == m['strides']  # the reference hands over channels_last-strided NCHW
+        a = img.permute(0, 2, 3, 1).cpu().numpy()
+        assert _sha(a) == m['sha'], tag
+        assert _sha(out['annots'].numpy()) == m['annots_sha'], tag
+        assert np.array_equal(out['scale'], arrs[f'{tag}_scale']) and np.array_equal(out['size'], arrs[f'{tag}_size'])
+
+
+def test_eval_postprocess_against_the_reference_statements(golden_dir):
+    from sacv_amd.detection import common
+    arrs = np.load(os.path.join(golden_dir, 'evalpost.npz'))
+    for tag in ('TINY', 'MID'):
+        got = common.eval_postprocess(torch.tensor(arrs[f'{tag}_boxes_in']).cuda(), arrs[f'{tag}_scales'],
+                                      arrs[f'{tag}_sizes']).cpu().numpy()
+        assert np.array_equal(got, arrs[f'{tag}_boxes_out']), tag

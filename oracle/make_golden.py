@@ -670,9 +670,62 @@ def sec_evalpost(ref):
 
 
 
+def sec_cifar(ref):
+    """BASELINE.json config #1: resnet18cifar on CIFAR-100 shaped batches (32x32, bs 32), the recipe's step
+    (0.classification_training/cifar100/resnet18cifar/train_config.py: CELoss, SGD lr 0.1 momentum 0.9 wd 5e-4
+    on ndim>1, total batch 128): contract, logits / loss / gradient norms, two reference SGD steps; plus resnet34cifar's contract."""
+    load_reference()
+    import importlib
+    rc = importlib.import_module('simpleAICV.classification.backbones.resnetforcifar')
+    closses = importlib.import_module('simpleAICV.classification.losses')
+    meta, arrs = {}, {}
+    for arch, layers in (('resnet18cifar', (2, 2, 2, 2)), ('resnet34cifar', (3, 4, 6, 3))):
+        net = rc.__dict__[arch](num_classes=100)
+        meta[arch + '_contract'] = dict(
+            keys=[[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in net.state_dict().items()],
+            params=[[k, list(v.shape)] for k, v in net.named_parameters()],
+            n_params=int(sum(p.numel() for p in net.parameters())))
+    for name, B, R, nc in (('r18c_32', 32, 32, 100), ('r18c_8', 4, 8, 10)):
+        net = rc.resnet18cifar(num_classes=nc)
+        net.load_state_dict(omodel.init_resnet_cls_state(0, nc), strict=True)
+        net.train()
+        crit = closses.CELoss()
+        x = torch.tensor(synth.images(31, B, R, R))
+        lab = torch.tensor(labels_for(37, B, nc))
+        logits = net(x)
+        loss = crit(logits, lab)
+        loss.backward()
+        m = dict(B=B, R=R, num_classes=nc, loss=float(loss.detach()), labels=lab.tolist(),
+                 grad_norm={k: float(p.grad.double().norm()) for k, p in net.named_parameters()})
+        arrs[f'{name}_logits'] = logits.detach().numpy()
+        for k in ('fc.bias', 'conv1.layer.1.weight', 'conv1.layer.0.weight', 'layer4.1.conv2.layer.1.bias',
+                  'layer2.0.downsample_conv.layer.0.weight'):
+            arrs[f'{name}_grad_{k}'] = dict(net.named_parameters())[k].grad.numpy().copy()
+        arrs[f'{name}_buf_conv1.layer.1.running_var'] = net.state_dict()['conv1.layer.1.running_var'].numpy().copy()
+        one_d = [p for p in net.parameters() if p.ndim == 1]
+        multi = [p for p in net.parameters() if p.ndim > 1]
+        opt = torch.optim.SGD([{'params': one_d, 'weight_decay': 0.0}, {'params': multi, 'weight_decay': 5e-4}],
+                              lr=0.01, momentum=0.9)  # a linear-regime rate: lr 0.1 on random init is chaotic (cls)
+        opt.step()
+        opt.zero_grad()
+        loss2 = crit(net(x), lab)
+        loss2.backward()
+        opt.step()
+        m['loss_step1'] = float(loss2)
+        m['param_norm_after2'] = {k: float(p.detach().double().norm()) for k, p in net.named_parameters()}
+        net.eval()
+        with torch.no_grad():
+            arrs[f'{name}_eval_logits'] = net(x).numpy()
+        meta[name] = m
+        print(name, m['loss'], m['loss_step1'])
+    np.savez_compressed(os.path.join(GOLD, 'cifar.npz'), **arrs)
+    json.dump(meta, open(os.path.join(GOLD, 'cifar.json'), 'w'), indent=0)
+
+
+
 SECTIONS = dict(cls=sec_cls, contract=sec_contract, anchors=sec_anchors, assign=sec_assign, losses=sec_losses,
                 decode=sec_decode, e2e=sec_e2e, e2e_s1=sec_e2e_s1, e2e_s2=sec_e2e_s2, scheduler=sec_scheduler,
-                trainer=sec_trainer, collate=sec_collate, evalpost=sec_evalpost)
+                trainer=sec_trainer, collate=sec_collate, evalpost=sec_evalpost, cifar=sec_cifar)
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)

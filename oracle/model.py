@@ -226,3 +226,69 @@ def sgd_momentum_step(params, grads, bufs, lr, momentum, weight_decay, first):
         g = grads[k] + (weight_decay * params[k] if params[k].ndim > 1 else 0.0)
         bufs[k] = g.clone() if first else momentum * bufs[k] + g
         params[k] = params[k] - lr * bufs[k]
+
+
+# ----------------------------------------------------------------------------- general ResNet classifiers
+# (BASELINE.json config #1: resnet18cifar, CIFAR-100; classification/backbones/resnetforcifar.py:27-108,
+#  BasicBlock classification/backbones/resnet.py:51-97)
+def init_resnet_cls_state(seed=0, num_classes=100, block='BasicBlock', layers=(2, 2, 2, 2), stem='cifar'):
+    """State dict of ResNet / ResNetCifar for any block type: kaiming-normal fan_out convs, BN (1, 0), nn.Linear
+    default law for fc; values from the portable generator, seeded per tensor name."""
+    sd = {}
+    expansion = 4 if block == 'Bottleneck' else 1
+
+    def conv_bn(prefix, cin, cout, k):
+        w = torch.from_numpy(synth.normal(seed * 1000003 + zlib.crc32(prefix.encode()), (cout, cin, k, k)))
+        sd[prefix + '.layer.0.weight'] = w * math.sqrt(2.0 / (cout * k * k))
+        sd[prefix + '.layer.1.weight'] = torch.ones(cout)
+        sd[prefix + '.layer.1.bias'] = torch.zeros(cout)
+        sd[prefix + '.layer.1.running_mean'] = torch.zeros(cout)
+        sd[prefix + '.layer.1.running_var'] = torch.ones(cout)
+        sd[prefix + '.layer.1.num_batches_tracked'] = torch.tensor(0, dtype=torch.long)
+
+    conv_bn('conv1', 3, 64, 7 if stem == 'imagenet' else 3)
+    inpl = 64
+    for li, (n, pl) in enumerate(zip(layers, [64, 128, 256, 512]), start=1):
+        for bi in range(n):
+            p = f'layer{li}.{bi}'
+            stride = 2 if (bi == 0 and li > 1) else 1
+            if block == 'Bottleneck':
+                conv_bn(p + '.conv1', inpl, pl, 1)
+                conv_bn(p + '.conv2', pl, pl, 3)
+                conv_bn(p + '.conv3', pl, pl * 4, 1)
+            else:
+                conv_bn(p + '.conv1', inpl, pl, 3)
+                conv_bn(p + '.conv2', pl, pl, 3)
+            if stride != 1 or inpl != pl * expansion:
+                conv_bn(p + '.downsample_conv', inpl, pl * expansion, 1)
+            inpl = pl * expansion
+    bound = 1.0 / math.sqrt(inpl)
+    u = lambda key, *shape: torch.from_numpy(synth.uniform(seed * 1000003 + zlib.crc32(key.encode()) + 17, shape))
+    sd['fc.weight'] = (u('fc.w', num_classes, inpl) * 2 - 1) * bound
+    sd['fc.bias'] = (u('fc.b', num_classes) * 2 - 1) * bound
+    return sd
+
+
+def resnet_cls_forward(sd, images, training=True, block='BasicBlock', layers=(2, 2, 2, 2), stem='cifar'):
+    """ResNetCifar.forward (resnetforcifar.py:88-101) / ResNet.forward (resnet.py:224-245)."""
+    if stem == 'imagenet':
+        x = F.max_pool2d(_cba(sd, 'conv1', images, 2, 3, True, training), 3, 2, 1)
+    else:
+        x = _cba(sd, 'conv1', images, 1, 1, True, training)
+    for li, n in enumerate(layers, start=1):
+        for bi in range(n):
+            p = f'layer{li}.{bi}'
+            stride = 2 if (bi == 0 and li > 1) else 1
+            idt = x
+            if block == 'Bottleneck':
+                y = _cba(sd, p + '.conv1', x, 1, 0, True, training)
+                y = _cba(sd, p + '.conv2', y, stride, 1, True, training)
+                y = _cba(sd, p + '.conv3', y, 1, 0, False, training)
+            else:
+                y = _cba(sd, p + '.conv1', x, stride, 1, True, training)
+                y = _cba(sd, p + '.conv2', y, 1, 1, False, training)
+            if (p + '.downsample_conv.layer.0.weight') in sd:
+                idt = _cba(sd, p + '.downsample_conv', x, stride, 0, False, training)
+            x = F.relu(y + idt)
+    x = F.adaptive_avg_pool2d(x, (1, 1)).flatten(1)
+    return F.linear(x, sd['fc.weight'], sd['fc.bias'])

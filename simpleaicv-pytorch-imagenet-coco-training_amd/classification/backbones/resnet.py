@@ -1,5 +1,5 @@
-"""ResNet50 classifier with the reference's constructor, module tree and state_dict keys
-(simpleAICV/classification/backbones/resnet.py:158-268), executed by the HIP engine.
+"""ResNet classifiers (ResNet18/34 BasicBlock, ResNet50/101/152 Bottleneck) with the reference's constructor, module
+tree and state_dict keys (simpleAICV/classification/backbones/resnet.py:158-300), executed by the HIP engine.
 
 As for the detectors, the torch.nn modules are parameter containers only; forward runs the hand-written
 kernels (implicit-GEMM convolutions with fused BatchNorm statistics, global average pool, FC as a 1x1 GEMM
@@ -10,9 +10,9 @@ import torch.nn as nn
 
 from ...engine import ClassifierEngine
 from ...detection.models._arena import ParamArena
-from ...detection.models._base import _resnet50_backbone
+from ...detection.models._base import _resnet_trunk
 
-__all__ = ['resnet50', 'ResNet']
+__all__ = ['resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152', 'ResNet']
 
 
 class _ClassifierFunction(torch.autograd.Function):
@@ -31,20 +31,28 @@ class _ClassifierFunction(torch.autograd.Function):
 
 class ResNet(nn.Module):
 
+    STEM = 'imagenet'
+
     def __init__(self, block='Bottleneck', layer_nums=(3, 4, 6, 3), inplanes=64, num_classes=1000,
                  use_gradient_checkpoint=False):
         super().__init__()
-        if block != 'Bottleneck' or tuple(layer_nums) != (3, 4, 6, 3) or inplanes != 64:
-            raise NotImplementedError('only ResNet50 (Bottleneck, [3,4,6,3], 64) is on the MI355X hot path')
+        block = getattr(block, '__name__', block)  # the reference passes the block class
+        if block not in ('Bottleneck', 'BasicBlock') or inplanes != 64 or len(layer_nums) != 4:
+            raise NotImplementedError('ResNet with Bottleneck/BasicBlock stages and 64 stem channels is what the '
+                                      'MI355X engine executes')
         if use_gradient_checkpoint:
             raise NotImplementedError('use_gradient_checkpoint: activations are kept in HBM (288 GB) instead')
-        self.layer_nums, self.num_classes, self.inplanes = list(layer_nums), num_classes, 2048
-        self.planes, self.expansion = [64, 128, 256, 512], 4
+        self.block = block
+        self.expansion = 4 if block == 'Bottleneck' else 1
+        self.layer_nums, self.num_classes = list(layer_nums), num_classes
+        self.planes = [64, 128, 256, 512]
+        self.inplanes = 512 * self.expansion
         self.use_gradient_checkpoint = use_gradient_checkpoint
-        _resnet50_backbone(self)  # conv1, layer1..layer4 (kaiming fan_out / BN 1,0 init, resnet.py:205-212)
-        self.maxpool1 = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        _resnet_trunk(self, block, layer_nums, 64, self.STEM)  # kaiming fan_out / BN 1,0 init (resnet.py:205-212)
+        if self.STEM == 'imagenet':
+            self.maxpool1 = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
-        self.fc = nn.Linear(2048, num_classes)
+        self.fc = nn.Linear(512 * self.expansion, num_classes)
         self._arena = self._engine = self._param_list = None
 
     def prepare(self):
@@ -56,7 +64,8 @@ class ResNet(nn.Module):
         self._param_list = list(self._arena.order)
         tensors = {n: p.data for n, p in self.named_parameters()}
         tensors.update({n: b for n, b in self.named_buffers()})
-        self._engine = ClassifierEngine(tensors, self._arena.grad_views, self.num_classes)
+        self._engine = ClassifierEngine(tensors, self._arena.grad_views, self.num_classes, block=self.block,
+                                        layers=self.layer_nums, stem=self.STEM)
         return self
 
     def _ready(self):
@@ -83,5 +92,21 @@ class ResNet(nn.Module):
         return self._engine.forward(x, training=self.training, keep=False)
 
 
+def resnet18(**kwargs):
+    return ResNet('BasicBlock', [2, 2, 2, 2], 64, **kwargs)
+
+
+def resnet34(**kwargs):
+    return ResNet('BasicBlock', [3, 4, 6, 3], 64, **kwargs)
+
+
 def resnet50(**kwargs):
     return ResNet('Bottleneck', [3, 4, 6, 3], 64, **kwargs)
+
+
+def resnet101(**kwargs):
+    return ResNet('Bottleneck', [3, 4, 23, 3], 64, **kwargs)
+
+
+def resnet152(**kwargs):
+    return ResNet('Bottleneck', [3, 8, 36, 3], 64, **kwargs)

@@ -26,16 +26,29 @@ def _bottleneck(cin, planes, stride):
     return blk
 
 
-def _resnet50_backbone(bb=None):
-    """ResNet50 trunk containers; populates `bb` (the bare classifier registers them on itself)."""
+def _basic_block(cin, planes, stride):
+    blk = nn.Module()
+    blk.conv1 = _conv_bn_act(cin, planes, 3, stride, 1)
+    blk.conv2 = _conv_bn_act(planes, planes, 3, 1, 1, act=False)
+    if stride != 1 or cin != planes:
+        blk.downsample_conv = _conv_bn_act(cin, planes, 1, stride, 0, act=False)
+    return blk
+
+
+def _resnet_trunk(bb=None, block='Bottleneck', layer_nums=RESNET50_LAYERS, inplanes=64, stem='imagenet'):
+    """ResNet trunk containers (conv1, layer1..layer4 with the reference's key layout and initialisers,
+    backbones/resnet.py:158-212, resnetforcifar.py:27-75); populates `bb` (the bare classifiers register them on
+    themselves)."""
     bb = nn.Module() if bb is None else bb
-    bb.conv1 = _conv_bn_act(3, 64, 7, 2, 3)
-    cin = 64
-    for li, (n, planes) in enumerate(zip(RESNET50_LAYERS, (64, 128, 256, 512)), start=1):
+    bb.conv1 = _conv_bn_act(3, inplanes, 7, 2, 3) if stem == 'imagenet' else _conv_bn_act(3, inplanes, 3, 1, 1)
+    expansion = 4 if block == 'Bottleneck' else 1
+    make = _bottleneck if block == 'Bottleneck' else _basic_block
+    cin = inplanes
+    for li, (n, planes) in enumerate(zip(layer_nums, (inplanes, inplanes * 2, inplanes * 4, inplanes * 8)), start=1):
         blocks = []
         for bi in range(n):
-            blocks.append(_bottleneck(cin, planes, 2 if (bi == 0 and li > 1) else 1))
-            cin = planes * 4
+            blocks.append(make(cin, planes, 2 if (bi == 0 and li > 1) else 1))
+            cin = planes * expansion
         setattr(bb, f'layer{li}', nn.Sequential(*blocks))
     for m in bb.modules():  # backbones/resnet.py:76-83
         if isinstance(m, nn.Conv2d):
@@ -43,8 +56,13 @@ def _resnet50_backbone(bb=None):
         elif isinstance(m, nn.BatchNorm2d):
             nn.init.constant_(m.weight, 1)
             nn.init.constant_(m.bias, 0)
-    bb.out_channels = [256, 512, 1024, 2048]
+    bb.out_channels = [inplanes * expansion, inplanes * 2 * expansion, inplanes * 4 * expansion,
+                       inplanes * 8 * expansion]
     return bb
+
+
+def _resnet50_backbone(bb=None):
+    return _resnet_trunk(bb)
 
 
 def _fpn(inplanes, planes, use_p5):

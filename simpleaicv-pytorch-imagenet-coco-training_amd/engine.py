@@ -37,8 +37,14 @@ class DetectorEngine:
     g: dict name -> gradient tensor of the same shape (views into the flat gradient arena)
     """
 
-    def __init__(self, p, g, num_classes=80, num_anchors=9, planes=256, fcos=False):
+    def __init__(self, p, g, num_classes=80, num_anchors=9, planes=256, fcos=False, block='Bottleneck',
+                 layers=RESNET50_LAYERS, stem='imagenet'):
         self.p, self.g = p, g
+        # trunk: Bottleneck / BasicBlock residual stages (classification/backbones/resnet.py:51-155) behind the
+        # ImageNet stem (7x7/s2 conv + 3x3/s2 max pool, :176-188) or the CIFAR stem (3x3/s1 conv, no pool,
+        # resnetforcifar.py:38-45)
+        assert block in ('Bottleneck', 'BasicBlock') and stem in ('imagenet', 'cifar')
+        self.block, self.layers, self.stem = block, tuple(layers), stem
         self.num_classes, self.num_anchors, self.planes, self.fcos = num_classes, num_anchors, planes, fcos
         self.ctx = None
         self.bp = 'backbone.'  # key prefix of the trunk in the state_dict ('' for the bare classifier)
@@ -181,36 +187,67 @@ class DetectorEngine:
         return outs
 
     def _backbone_fwd(self, images, training, keep, ctx):
-        """ResNet50 trunk (classification/backbones/resnet.py:158-245): returns [C2, C3, C4, C5]."""
+        """ResNet trunk (classification/backbones/resnet.py:158-245): returns [C2, C3, C4, C5]."""
         p, bp = self.p, self.bp
         b, _, h, w = images.shape
-        # stem: explicit im2col (Cin=3) + GEMM, BN, ReLU, 3x3/s2 max pool
-        ho, wo = _out_hw(h, w, 7, 2, 3)
-        col = ops.im2col_stem(images, ho, wo)
+        # stem: explicit im2col (Cin=3) + GEMM, BN, ReLU (+ 3x3/s2 max pool for the ImageNet stem)
+        sk, ss, sp = (7, 2, 3) if self.stem == 'imagenet' else (3, 1, 1)
+        kpad = ops.stem_kpad(sk)
+        ho, wo = _out_hw(h, w, sk, ss, sp)
+        col = ops.im2col_stem(images, ho, wo, sk, sk, ss, sp)
         wst = ops.pack_weight(p[bp + 'conv1.layer.0.weight'], PACK_STEM)
         if training:
             (y,), st = ops.conv_gemm([col], wst, 64, 1, 1, 1, 0, 0, [(ho, wo)], stats=True)
         else:
             y, st = ops.conv_gemm([col], wst, 64, 1, 1, 1, 0, 0, [(ho, wo)])[0], None
-        z, c = self._bn_fwd(col, y, bp + 'conv1', 7, 2, 3, True, training, None, keep, st)
-        x, pool_idx = ops.maxpool_fwd(z, 3, 2, 1, want_idx=keep)
+        z, c = self._bn_fwd(col, y, bp + 'conv1', sk, ss, sp, True, training, None, keep, st)
+        if self.stem == 'imagenet':
+            x, pool_idx = ops.maxpool_fwd(z, 3, 2, 1, want_idx=keep)
+        else:
+            x, pool_idx = z, None
         if keep:
             ctx['stem'] = c
             ctx['pool_idx'] = pool_idx
             ctx['pool_in_shape'] = tuple(z.shape)
         feats = []
         blocks = []
-        for li, n in enumerate(RESNET50_LAYERS, start=1):
+        fwd = self._bottleneck_fwd if self.block == 'Bottleneck' else self._basicblock_fwd
+        for li, n in enumerate(self.layers, start=1):
             for bi in range(n):
                 pre = f'{bp}layer{li}.{bi}'
                 stride = 2 if (bi == 0 and li > 1) else 1
-                out, (c1, c2, c3, cd) = self._bottleneck_fwd(x, pre, stride, training, keep)
-                blocks.append((c1, c2, c3, cd, li, bi))
+                out, saved = fwd(x, pre, stride, training, keep)
+                blocks.append((saved, li, bi))
                 x = out
             feats.append(x)
         if keep:
             ctx['blocks'] = blocks
         return feats
+
+    def _basicblock_fwd(self, x, pre, stride, training, keep=True):
+        """BasicBlock.forward (classification/backbones/resnet.py:51-97): 3x3(stride) -> 3x3, shortcut (1x1 conv + BN
+        when the shape changes), add + ReLU fused into the last BN pass."""
+        has_ds = (pre + '.downsample_conv.layer.0.weight') in self.p
+        z1, c1 = self._cba_fwd(x, pre + '.conv1', 3, stride, 1, True, training, keep=keep)
+        if has_ds:
+            idt, cd = self._cba_fwd(x, pre + '.downsample_conv', 1, stride, 0, False, training, keep=keep)
+        else:
+            idt, cd = x, None
+        out, c2 = self._cba_fwd(z1, pre + '.conv2', 3, 1, 1, True, training, residual=idt, keep=keep)
+        return out, (c1, c2, cd)
+
+    def _basicblock_bwd(self, saved, dout, accum_target):
+        c1, c2, cd = saved
+        dz1, gshared = self._cba_bwd(c2, dout, want_g=True)
+        if cd is None:
+            dx, _ = self._cba_bwd(c1, dz1, dx_out=gshared, dx_accum=True)
+            return dx
+        if accum_target is not None:
+            dx, _ = self._cba_bwd(c1, dz1, dx_out=accum_target, dx_accum=True)
+        else:
+            dx, _ = self._cba_bwd(c1, dz1)
+        self._cba_bwd(cd, gshared, dx_out=dx, dx_accum=True)
+        return dx
 
     def _bottleneck_fwd(self, x, pre, stride, training, keep=True):
         """Bottleneck.forward (classification/backbones/resnet.py:141-155): 1x1 -> 3x3(stride) -> 1x1,
@@ -461,25 +498,30 @@ class DetectorEngine:
         """Backward of the trunk, last block first; dc4 / dc3 are the FPN lateral gradients that join the
         data gradient at the inputs of layer4 / layer3 (None for the classifier)."""
         ctx, bp = self.ctx, self.bp
-        for c1, c2, c3, cd, li, bi in reversed(ctx['blocks']):
+        bwd = self._bottleneck_bwd if self.block == 'Bottleneck' else self._basicblock_bwd
+        for saved, li, bi in reversed(ctx['blocks']):
             accum_target = None
             if bi == 0 and li == 4:
                 accum_target = dc4
             elif bi == 0 and li == 3:
                 accum_target = dc3
-            dout = self._bottleneck_bwd(c1, c2, c3, cd, dout, accum_target)
+            dout = bwd(saved, dout, accum_target)
             if on_stage and bi == 0 and li in (3, 4):
                     on_stage('neck' if li == 4 else 'mid')  # fpn + layer4 / layer3 gradients are final
         # max pool + stem
-        dpool = ops.maxpool_bwd(dout, ctx['pool_idx'], ctx['pool_in_shape'], 3, 2, 1)
+        if self.stem == 'imagenet':
+            dpool = ops.maxpool_bwd(dout, ctx['pool_idx'], ctx['pool_in_shape'], 3, 2, 1)
+        else:
+            dpool = dout
         st = ctx['stem']
         bn = bp + 'conv1.layer.1.'
         dy, _ = ops.bn_train_bwd(dpool, None, st.y, st.mean, st.invstd, self.p[bn + 'weight'], self.g[bn + 'weight'],
                                  self.g[bn + 'bias'], relu_beta=self.p[bn + 'bias'])
         self._wgrad([dy], [st.x], self.g[bp + 'conv1.layer.0.weight'], 3, 1, 1, 1, 0,
-                    cin_pad=ops.STEM_KPAD, dw_taps=49)
+                    cin_pad=ops.stem_kpad(st.k), dw_taps=st.k * st.k)
 
-    def _bottleneck_bwd(self, c1, c2, c3, cd, dout, accum_target):
+    def _bottleneck_bwd(self, saved, dout, accum_target):
+        c1, c2, c3, cd = saved
         # out = relu(bn3(conv3(z2)) + idt): g is the masked gradient shared by both branches
         dz2, gshared = self._cba_bwd(c3, dout, want_g=True)
         dz1, _ = self._cba_bwd(c2, dz2)
@@ -522,11 +564,12 @@ class DetectorEngine:
 
 
 class ClassifierEngine(DetectorEngine):
-    """ResNet50 ImageNet classifier (classification/backbones/resnet.py:158-245): the trunk of
-    the detector engine + global average pool + FC (a 1x1 problem of the conv GEMM kernels)."""
+    """ResNet classifiers (ResNet50 ImageNet, classification/backbones/resnet.py:158-245; BASELINE
+    config #1: ResNet18 CIFAR-100, resnetforcifar.py:27-108): the trunk of the detector engine + global average pool
+    + FC (a 1x1 problem of the conv GEMM kernels)."""
 
-    def __init__(self, p, g, num_classes=1000):
-        super().__init__(p, g, num_classes=num_classes)
+    def __init__(self, p, g, num_classes=1000, block='Bottleneck', layers=RESNET50_LAYERS, stem='imagenet'):
+        super().__init__(p, g, num_classes=num_classes, block=block, layers=layers, stem=stem)
         self.bp = ''
 
     def forward(self, images, training=True, keep=True):
@@ -536,25 +579,56 @@ class ClassifierEngine(DetectorEngine):
             self._refresh_dgrad_panels()
         c5 = self._backbone_fwd(images, training, keep, ctx)[3]
         pooled = ops.avgpool_fwd(c5)
-        w = self.p['fc.weight']
+        w, bias = self._fc_padded()
+        nout = self.p['fc.weight'].shape[0]
         wp = ops.fwd_panel(w.view(w.shape[0], w.shape[1], 1, 1))
-        logits = ops.conv_gemm([pooled], wp, w.shape[0], 1, 1, 1, 0, 0, [(1, 1)], bias=self.p['fc.bias'])[0]
+        logits = ops.conv_gemm([pooled], wp, w.shape[0], 1, 1, 1, 0, 0, [(1, 1)], bias=bias)[0]
+        logits = logits.view(logits.shape[0], w.shape[0])
+        if w.shape[0] != nout:
+            logits = logits[:, :nout].contiguous()
         if keep:
             ctx['pooled'] = pooled
             ctx['c5_shape'] = tuple(c5.shape)
+            ctx['fc_w'] = w
             self.ctx = ctx
-        return logits.view(logits.shape[0], w.shape[0])
+        return logits
+
+    def _fc_padded(self):
+        """fc weight / bias with the output count padded to a multiple of 4 (the GEMM's N granule): zero rows for
+        e.g. the 10 classes of CIFAR-10.  Plain views when num_classes % 4 == 0."""
+        w, b = self.p['fc.weight'], self.p['fc.bias']
+        nout = w.shape[0]
+        npad = -(-nout // 4) * 4
+        if npad == nout:
+            return w, b
+        wp = torch.zeros((npad, w.shape[1]), device=w.device, dtype=torch.float32)
+        bp = torch.zeros(npad, device=w.device, dtype=torch.float32)
+        wp[:nout].copy_(w)
+        bp[:nout].copy_(b)
+        return wp, bp
 
     def backward(self, dlogits, on_stage=None):
         ctx = self.ctx
         if ctx is None:
             raise RuntimeError('backward() without a preceding forward(keep=True)')
-        w = self.p['fc.weight']
-        nout, nin = w.shape
-        dy = dlogits.contiguous().view(dlogits.shape[0], 1, 1, nout)
-        self._wgrad([dy], [ctx['pooled']], self.g['fc.weight'].view(nout, nin, 1, 1), nin, 1, 1, 1, 0)
-        ops.colsum(dy.view(-1, nout), nout, self.g['fc.bias'])
-        dpooled = self._dgrad(dy, w.view(nout, nin, 1, 1), ctx['pooled'].shape, 1, 1, 0)
+        w = ctx['fc_w']
+        nout, nin = self.p['fc.weight'].shape
+        npad = w.shape[0]
+        dl = dlogits.contiguous()
+        if npad != nout:
+            dy = torch.zeros((dl.shape[0], npad), device=dl.device, dtype=torch.float32)
+            dy[:, :nout].copy_(dl)
+            dwp = torch.empty((npad, nin, 1, 1), device=dl.device, dtype=torch.float32)
+            dbp = torch.empty(npad, device=dl.device, dtype=torch.float32)
+        else:
+            dy, dwp, dbp = dl, self.g['fc.weight'].view(nout, nin, 1, 1), self.g['fc.bias']
+        dy = dy.view(dy.shape[0], 1, 1, npad)
+        self._wgrad([dy], [ctx['pooled']], dwp, nin, 1, 1, 1, 0)
+        ops.colsum(dy.view(-1, npad), npad, dbp)
+        if npad != nout:
+            self.g['fc.weight'].copy_(dwp.view(npad, nin)[:nout])
+            self.g['fc.bias'].copy_(dbp[:nout])
+        dpooled = self._dgrad(dy, w.view(npad, nin, 1, 1), ctx['pooled'].shape, 1, 1, 0)
         dc5 = ops.avgpool_bwd(dpooled, ctx['c5_shape'])
         if on_stage:
             on_stage('heads')

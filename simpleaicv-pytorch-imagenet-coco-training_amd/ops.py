@@ -16,6 +16,11 @@ PACK_FWD, PACK_DGRAD, PACK_STEM = 0, 1, 2
 STEM_KPAD = 160  # 7*7*3 = 147 padded to a multiple of 32
 
 
+def stem_kpad(k, cin=3):
+    """GEMM-K of the im2col'ed stem convolution (k x k taps x cin), padded to a multiple of 32."""
+    return -(-(k * k * cin) // 32) * 32
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -99,7 +104,8 @@ def pack_weight(w_oihw, kind, out=None):
         check(lib.sacv_pack_weight(_ptr(w_oihw), _ptr(out), co, ci, kh, kw, 3, 0, _stream()), 'pack_weight')
         return out
     if kind == PACK_STEM:
-        shape, kpad = (co, STEM_KPAD), STEM_KPAD
+        kpad = stem_kpad(kh, ci)
+        shape = (co, kpad)
     elif kind == PACK_FWD:
         shape, kpad = (co, kh * kw * ci), 0
     else:
@@ -235,10 +241,11 @@ def im2col_stem(x_nchw_logical, ho, wo, kh=7, kw=7, stride=2, pad=3):
     if x.device.type != 'cuda' or x.dtype != torch.float32:
         raise ValueError('im2col_stem: expected an fp32 CUDA(HIP) tensor')
     n, c, h, w = x.shape
-    col = torch.empty((n, ho, wo, STEM_KPAD), device=x.device, dtype=torch.float32)
+    kpad = stem_kpad(kh, c)
+    col = torch.empty((n, ho, wo, kpad), device=x.device, dtype=torch.float32)
     sn, sc, sh, sw = x.stride()
     check(lib.sacv_im2col_stem(_ptr(x), _ptr(col), n, c, h, w, sn, sc, sh, sw, ho, wo, kh, kw, stride, pad,
-                               STEM_KPAD, _stream()), 'im2col_stem')
+                               kpad, _stream()), 'im2col_stem')
     return col
 
 

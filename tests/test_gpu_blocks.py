@@ -79,7 +79,7 @@ def test_bottleneck_fwd_bwd(cin, planes, stride, h, w):
     assert rel_l2(nchw(out), out_r.detach()) <= 1e-5
     base = rnd(3, *x.shape)
     for accum in (None, nhwc(base)) if cd is not None else (None,):
-        dx = eng._bottleneck_bwd(c1, c2, c3, cd, nhwc(dout), accum)
+        dx = eng._bottleneck_bwd((c1, c2, c3, cd), nhwc(dout), accum)
         eng._join_side()  # weight gradients run on a side stream
         ref = xr.grad if accum is None else xr.grad + base
         assert rel_l2(nchw(dx), ref) <= 1e-4, (accum is not None)

@@ -109,13 +109,19 @@ def _ddp_worker(rank, world, port, ret):
             p.grad = None
         ld = crit(ddp(images), annots)
         sum(ld.values()).backward()
-        worst = 0.0
+        worst, report = 0.0, []
         for n, p in net.named_parameters():
             tot = own[n].clone()
             dist.all_reduce(tot)
             want = tot / world  # DDP averages
             scale = float(want.abs().max()) + 1e-12
-            worst = max(worst, float((p.grad - want).abs().max()) / scale)
+            e = float((p.grad - want).abs().max()) / scale
+            if e > 1e-5 and len(report) < 6:
+                report.append((n, e, float((p.grad - own[n]).abs().max()) / scale, tuple(p.grad.stride()),
+                               tuple(own[n].stride())))
+            worst = max(worst, e)
+        if report:
+            print('DDP mismatch', rank, report, flush=True)
         # BatchNorm statistics differ per rank's batch; the gradients of two consecutive forwards differ only through
         # nothing (same weights, same inputs, train-mode batch statistics): rounding level
         assert worst <= 1e-5, worst

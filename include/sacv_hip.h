@@ -252,6 +252,45 @@ int sacv_comm_wait(void* comm, void* consumer_stream);
 /* DDP init_sync / broadcast_buffers: rank `root`'s buf overwrites every rank's, in order on `stream` */
 int sacv_comm_broadcast(void* comm, float* buf, long long count, int root, void* stream);
 
+/* ---- bf16 matrix-core path (the autocast ResNet50 ImageNet recipe, tools/scripts.py:108-267 with
+ *      use_amp, 0.classification_training/imagenet/resnet50/train_config.py:97).  Activations are NHWC bf16 in HBM,
+ *      accumulation, BatchNorm statistics, losses, master weights, gradients and optimizer state are fp32.
+ *      `const void*` activation / weight-panel pointers are bf16 device arrays. ------------------------------------ */
+#define SACV_CFH_OUT_F32 64 /* sacv_conv2d_gemm_bf16: dst is fp32 (the logits) */
+/* forward (mode 0) / data gradient (mode 1) of one convolution on v_mfma_f32_32x32x16_bf16; w = bf16 panel
+ * [N][KH*KW*Cs] (sacv_cast_bf16 of a channels_last / 1x1 weight; sacv_pack_dgrad_batched_bf16 for mode 1);
+ * flags SACV_CF_BIAS | SACV_CF_ACCUM | SACV_CF_STATS | SACV_CFH_OUT_F32; remap / ext as sacv_conv2d_gemm.
+ * SACV_CF_STATS sums the bf16-ROUNDED outputs (what BatchNorm reads). */
+int sacv_conv2d_gemm_bf16(const void* src, void* dst, int Nb, int Hs, int Ws, int Hd, int Wd, const void* w,
+                          const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode, int flags,
+                          int remap_s, int Hr, int Wr, const int* ext, float* stats, void* stream);
+long long sacv_conv2d_wgrad_bf16_workspace_bytes(int Nb, int Ho, int Wo, int Cin_pad, int Cout, int KH, int KW,
+                                                 int chunk);
+/* fp32 weight gradient from bf16 dy / x (fp32 slabs per `chunk` pixels, a multiple of 64, summed in fixed order) */
+int sacv_conv2d_wgrad_bf16(const void* dy, const void* x, int Nb, int Hx, int Wx, int Ho, int Wo, float* dw,
+                           float* workspace, int Cin, int Cin_pad, int Cout, int KH, int KW, int stride, int pad,
+                           int chunk, int accumulate, int dw_taps, int dw_layout, void* stream);
+int sacv_cast_bf16(const float* in, void* out, long long n, void* stream); /* round to nearest even */
+int sacv_cast_f32(const void* in, float* out, long long n, void* stream);
+/* as sacv_pack_dgrad_batched with fp32 sources and bf16 destinations */
+int sacv_pack_dgrad_batched_bf16(const void* descs, const int* chunk_map, int nchunks, void* stream);
+/* fp32 image -> bf16 im2col matrix of the stem, Kpad a multiple of 64 */
+int sacv_im2col_stem_bf16(const float* x, void* col, int Nb, int Cin, int H, int W, long long sN, long long sC,
+                          long long sH, long long sW, int Ho, int Wo, int KH, int KW, int stride, int pad, int Kpad,
+                          void* stream);
+int sacv_bn_apply_bf16(const void* y, const float* mean, const float* invstd_or_var, const float* gamma,
+                       const float* beta, const void* residual, void* z, long long numel, int C, int relu,
+                       int stat_is_var, float eps, void* stream);
+int sacv_bn_train_bwd_bf16(const void* dz, const void* zmask, const void* y, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, void* dy, void* g_out, float* dgamma, float* dbeta,
+                           int R, int C, int accumulate, float* workspace, void* stream);
+int sacv_maxpool_fwd_bf16(const void* x, void* y, unsigned char* idx, int Nb, int H, int W, int C, int Ho, int Wo,
+                          int k, int s, int p, void* stream);
+int sacv_maxpool_bwd_bf16(const void* dy, const unsigned char* idx, void* dx, int Nb, int H, int W, int C, int Ho,
+                          int Wo, int k, int s, int p, void* stream);
+int sacv_avgpool_fwd_bf16(const void* x, void* out, int N, int HW, int C, void* stream);
+int sacv_avgpool_bwd_bf16(const void* dy, void* dx, int N, int HW, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -723,9 +723,49 @@ def sec_cifar(ref):
 
 
 
+def sec_cls_bf16(ref):
+    """SURVEY.md 8f-1 as written (autocast): the reference ResNet50 + CELoss under torch.autocast('cpu', bfloat16) on the
+    inputs of section cls (fp32 results of the same inputs: cls.json) -- logits, loss, gradient norms, a few full
+    gradients.  The reference recipe autocasts to fp16 on CUDA with a GradScaler; BASELINE.json asks for bf16, whose
+    CPU autocast is what can run here (parity of the fp16-CUDA path itself is unpinned)."""
+    resnet, closses = load_reference_classification()
+    meta, arrs = {}, {}
+    for name, B, R, nc in (('cls_64', 4, 64, 1000), ('cls_224', 8, 224, 1000), ('cls_64_b32', 32, 64, 1000)):
+        net = resnet.resnet50(num_classes=nc)
+        net.load_state_dict(omodel.init_resnet50_cls_state(0, nc), strict=True)
+        net.train()
+        crit = closses.CELoss()
+        x = torch.tensor(synth.images(11, B, R, R))
+        lab = torch.tensor(labels_for(23, B, nc))
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            logits = net(x)
+            loss = crit(logits, lab)
+        loss.backward()
+        m = dict(B=B, R=R, num_classes=nc, loss=float(loss.detach()), logits_dtype=str(logits.dtype),
+                 grad_norm={k: float(p.grad.double().norm()) for k, p in net.named_parameters()})
+        arrs[f'{name}_logits'] = logits.detach().float().numpy()
+        for k in ('fc.bias', 'conv1.layer.1.weight', 'layer4.2.conv3.layer.1.bias', 'layer1.0.conv1.layer.0.weight'):
+            arrs[f'{name}_grad_{k}'] = dict(net.named_parameters())[k].grad.numpy().copy()
+        # fp32 run of the same inputs as the yardstick for what bf16 costs
+        net32 = resnet.resnet50(num_classes=nc)
+        net32.load_state_dict(omodel.init_resnet50_cls_state(0, nc), strict=True)
+        net32.train()
+        l32 = net32(x)
+        loss32 = crit(l32, lab)
+        loss32.backward()
+        m['loss_fp32'] = float(loss32.detach())
+        m['grad_norm_fp32'] = {k: float(p.grad.double().norm()) for k, p in net32.named_parameters()}
+        arrs[f'{name}_logits_fp32'] = l32.detach().numpy()
+        meta[name] = m
+        print(name, m['loss'], m['loss_fp32'], logits.dtype)
+    np.savez_compressed(os.path.join(GOLD, 'cls_bf16.npz'), **arrs)
+    json.dump(meta, open(os.path.join(GOLD, 'cls_bf16.json'), 'w'), indent=0)
+
+
+
 SECTIONS = dict(cls=sec_cls, contract=sec_contract, anchors=sec_anchors, assign=sec_assign, losses=sec_losses,
                 decode=sec_decode, e2e=sec_e2e, e2e_s1=sec_e2e_s1, e2e_s2=sec_e2e_s2, scheduler=sec_scheduler,
-                trainer=sec_trainer, collate=sec_collate, evalpost=sec_evalpost, cifar=sec_cifar)
+                trainer=sec_trainer, collate=sec_collate, evalpost=sec_evalpost, cifar=sec_cifar, cls_bf16=sec_cls_bf16)
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)

@@ -67,6 +67,19 @@ SIGNATURES = {
     'sacv_sgd_step_gated': (I, [P, P, P, LL, LL, F, F, F, F, F, I, P, F, F, P]),
     'sacv_adamw_step': (I, [P, P, P, P, LL, LL, F, F, F, F, F, F, I, F, P]),
     'sacv_fill': (I, [P, LL, F, P]),
+    'sacv_conv2d_gemm_bf16': (I, [P, P, I, I, I, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, P]),
+    'sacv_conv2d_wgrad_bf16_workspace_bytes': (LL, [I, I, I, I, I, I, I, I]),
+    'sacv_conv2d_wgrad_bf16': (I, [P, P, I, I, I, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    'sacv_cast_bf16': (I, [P, P, LL, P]),
+    'sacv_cast_f32': (I, [P, P, LL, P]),
+    'sacv_pack_dgrad_batched_bf16': (I, [P, P, I, P]),
+    'sacv_im2col_stem_bf16': (I, [P, P, I, I, I, I, LL, LL, LL, LL, I, I, I, I, I, I, I, P]),
+    'sacv_bn_apply_bf16': (I, [P, P, P, P, P, P, P, LL, I, I, I, F, P]),
+    'sacv_bn_train_bwd_bf16': (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
+    'sacv_maxpool_fwd_bf16': (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    'sacv_maxpool_bwd_bf16': (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
+    'sacv_avgpool_fwd_bf16': (I, [P, P, I, I, I, P]),
+    'sacv_avgpool_bwd_bf16': (I, [P, P, I, I, I, P]),
     'sacv_comm_unique_id_bytes': (I, []),
     'sacv_comm_unique_id': (I, [P]),
     'sacv_comm_init': (I, [P, I, I, P]),

@@ -54,6 +54,16 @@ class ResNet(nn.Module):
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
         self.fc = nn.Linear(512 * self.expansion, num_classes)
         self._arena = self._engine = self._param_list = None
+        self._amp = False
+
+    def set_amp(self, enabled=True):
+        """The reference's `use_amp` (autocast around forward + loss, tools/scripts.py:140-158): run the trunk on the
+        bf16 matrix cores -- bf16 activations and weight panels, fp32 accumulation, BatchNorm statistics, loss,
+        master weights, gradients and optimizer state."""
+        self._amp = bool(enabled)
+        if self._engine is not None:
+            self._engine.set_amp(self._amp, self._arena)
+        return self
 
     def prepare(self):
         dev = next(self.parameters()).device
@@ -66,7 +76,16 @@ class ResNet(nn.Module):
         tensors.update({n: b for n, b in self.named_buffers()})
         self._engine = ClassifierEngine(tensors, self._arena.grad_views, self.num_classes, block=self.block,
                                         layers=self.layer_nums, stem=self.STEM)
+        self._engine.set_amp(self._amp, self._arena)
         return self
+
+    def _apply(self, fn, recurse=True):
+        """.cuda() / .to(device) builds the arenas at once (see HipDetector._apply)."""
+        out = super()._apply(fn, recurse)
+        p = next(self.parameters(), None)
+        if p is not None and p.device.type == 'cuda':
+            self.prepare()
+        return out
 
     def _ready(self):
         if self._arena is None or not self._arena.is_current():

@@ -1,0 +1,804 @@
+// bf16 implicit-GEMM convolution engine for gfx950 (MI355X): v_mfma_f32_32x32x16_bf16, fp32 accumulate, bf16 NHWC
+// activations in HBM, fp32 master weights cast to bf16 panels once per step (the autocast recipe of
+// 0.classification_training/imagenet/resnet50/train_config.py:97, tools/scripts.py:108-267; nn.Conv2d call sites
+// simpleAICV/classification/backbones/resnet.py:33-39).
+//
+// Same decomposition as the fp32 engine (conv_gemm.hip):
+//   conv_nt_bf16_kernel  C[m][n] = sum_k A(m,k) * B[n][k]   forward (A = im2col gather of x) and data gradient
+//                        (A = transposed gather of dy), B = weight panel [N][taps*Cs] bf16
+//   conv_tn_bf16_kernel  dW[co][tap,ci] = sum_pix dy[pix][co] * x[pix@tap][ci], split over pixels into fp32 slabs
+//                        that the fp32 engine's wgrad_reduce sums in a fixed order into the fp32 gradient arena
+// but in bf16 these convolutions sit at or below the HBM/L2 ridge (AI 60-570 flop/B against 310), so the kernels are
+// built to stream: 16-byte gathers (8 channels), K tile = 64 channels = one 128-byte line per pixel row, LDS rows
+// padded to 144 bytes (conflict-free ds_write_b128 / ds_read_b128), one barrier per K tile, persistent round-robin
+// tiles.  Weight-gradient fragments are read with the hardware transposing LDS read (ds_read_b64_tr_b16): both
+// operands arrive pixel-major ([pix][channel]) from HBM and the MFMA wants channel-major k-runs.
+#include "sacv_common.h"
+#include <mutex>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define CF_BIAS 1
+#define CF_ACCUM 8
+#define CF_STATS 32
+#define CFH_OUT_F32 64  // dst is fp32 (the classifier's logits) instead of bf16
+
+// 16 zero bytes that masked gathers read (see conv_gemm.hip: a select on the ADDRESS keeps the gathered registers
+// untouched until the LDS store)
+static __device__ __attribute__((aligned(16))) float sacv_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct ConvArgsH {
+  const bf16* src;
+  void* dst;
+  int Nb, Hs, Ws;  // source tensor dims
+  int Hd, Wd;      // M-space spatial dims
+  int M;
+  int remap_s, Hr, Wr, remap_oh, remap_ow;
+  const bf16* w;
+  const float* bias;
+  int Cs, N, K;
+  int KH, KW, stride_log2, pad_h, pad_w;
+  int kh0, khs, kw0, kws, KWr;
+  int flags;
+  int ntiles;
+  float* stats;  // [mtiles][2][N]
+};
+
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_nt_bf16_kernel(const ConvArgsH a) {
+  constexpr int LSB = 144;                      // LDS row stride in bytes: 64 bf16 + 16 bytes of padding
+  constexpr int RA = BM / 32, RB = BN / 32;     // 16-byte gathers per thread per K tile
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + 2 * BM * LSB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int Cs = a.Cs;
+  const bf16* __restrict__ wgt = a.w;
+  const bf16* __restrict__ src = a.src;
+  const int cpt = (Cs + 63) >> 6;  // K tiles per tap
+  const int KT = a.KH * a.KW * cpt;
+  const int smask = (1 << a.stride_log2) - 1;
+  const int Hs = a.Hs, Ws = a.Ws;
+  const int ntn = (a.N + BN - 1) / BN;
+  const int kq = tid & 7, r0 = tid >> 3;
+  const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int nt = tile % ntn, mt = tile / ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+    int hb[RA], wb[RA], rowoff[RA], wrow[RB];
+    bool wok[RB];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int m = m0 + r0 + 32 * i;
+      if (m < a.M) {
+        const int hw = a.Hd * a.Wd;
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        const int hd = rem / a.Wd;
+        const int wd = rem - hd * a.Wd;
+        if (MODE == 0) {
+          hb[i] = (hd << a.stride_log2) - a.pad_h;
+          wb[i] = (wd << a.stride_log2) - a.pad_w;
+        } else {
+          hb[i] = hd + a.pad_h;
+          wb[i] = wd + a.pad_w;
+        }
+        rowoff[i] = (n * Hs * Ws + hb[i] * Ws + wb[i]) * Cs + kq * 8;
+        if (MODE == 1 && a.stride_log2 > 0) rowoff[i] = n * Hs * Ws * Cs + kq * 8;
+      } else {
+        hb[i] = -100000;
+        wb[i] = -100000;
+        rowoff[i] = 0;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int n = n0 + r0 + 32 * i;
+      wok[i] = n < a.N;
+      wrow[i] = n * a.K + kq * 8;
+    }
+
+    u32x4 ra[RA], rb[RB];
+    auto load_tile = [&](int kt) {
+      const int tap = kt / cpt;
+      const int c0 = (kt - tap * cpt) << 6;
+      const int kh = tap / a.KW;
+      const int kw = tap - kh * a.KW;
+      const int rtap = (a.kh0 + a.khs * kh) * a.KWr + (a.kw0 + a.kws * kw);
+      const int boff = rtap * Cs + c0;
+      const int aoff = (MODE == 0 ? (kh * Ws + kw) : -(kh * Ws + kw)) * Cs + c0;
+      const bool kok = (c0 + kq * 8) < Cs;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        bool ok;
+        int off;
+        if (MODE == 0) {
+          const int hs = hb[i] + kh, ws = wb[i] + kw;
+          ok = ((unsigned)hs < (unsigned)Hs) & ((unsigned)ws < (unsigned)Ws);
+          off = rowoff[i] + aoff;
+        } else if (a.stride_log2 == 0) {
+          const int hs = hb[i] - kh, ws = wb[i] - kw;
+          ok = ((unsigned)hs < (unsigned)Hs) & ((unsigned)ws < (unsigned)Ws);
+          off = rowoff[i] + aoff;
+        } else {
+          const int th = hb[i] - kh, tw = wb[i] - kw;
+          ok = (th >= 0) & (tw >= 0) & (((th | tw) & smask) == 0);
+          const int hs = th >> a.stride_log2, ws = tw >> a.stride_log2;
+          ok = ok & (hs < Hs) & (ws < Ws);
+          off = rowoff[i] + (hs * Ws + ws) * Cs + c0;
+        }
+        ok = ok & kok;
+        const void* ptr = ok ? (const void*)(src + (unsigned)off) : (const void*)sacv_zero16;
+        ra[i] = ld16(ptr);
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const bool ok = wok[i] & kok;
+        const void* ptr = ok ? (const void*)(wgt + (unsigned)(wrow[i] + boff)) : (const void*)sacv_zero16;
+        rb[i] = ld16(ptr);
+      }
+    };
+    auto store_tile = [&](int buf) {
+      unsigned char* dA = sA + buf * BM * LSB + r0 * LSB + kq * 16;
+      unsigned char* dB = sB + buf * BN * LSB + r0 * LSB + kq * 16;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4*>(dA + 32 * i * LSB) = ra[i];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) *reinterpret_cast<u32x4*>(dB + 32 * i * LSB) = rb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+      const bool last = kt + 1 == KT;
+      if (!last) load_tile(kt + 1);
+      const unsigned char* cA = sA + cur * BM * LSB + (wm0 + l31) * LSB + 16 * lh;
+      const unsigned char* cB = sB + cur * BN * LSB + (wn0 + l31) * LSB + 16 * lh;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(cA + i * 32 * LSB + kk * 32);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(cB + j * 32 * LSB + kk * 32);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      }
+      if (!last) store_tile(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+
+    // ---- epilogue: accumulators -> LDS [BM][BN+4] fp32 -> rows of 8 channels: + bias, (+ dst), round to the output
+    // type, 16-byte stores; CF_STATS: per-column sum / sum of squares of the ROUNDED values (what BatchNorm will read)
+    constexpr int CS = BN + 4;
+    float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stage[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CS + wn0 + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+    constexpr int CG = BN / 8, RS = 256 / CG;
+    const int c8 = tid % CG, rr = tid / CG;
+    const int n = n0 + c8 * 8;
+    const bool nok = n < a.N;  // N % 8 == 0
+    const int flags = a.flags;
+    float bv[8], ssum[8], ssq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      bv[e] = ((flags & CF_BIAS) && nok) ? a.bias[n + e] : 0.f;
+      ssum[e] = 0.f;
+      ssq[e] = 0.f;
+    }
+    const int hw = a.Hd * a.Wd;
+    for (int row = rr; row < BM; row += RS) {
+      const int m = m0 + row;
+      if (!(nok && m < a.M)) continue;
+      float v[8];
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(stage + row * CS + c8 * 8);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(stage + row * CS + c8 * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = v0[e] + bv[e];
+        v[4 + e] = v1[e] + bv[4 + e];
+      }
+      size_t orow = (size_t)m;
+      if (a.remap_s > 0) {
+        const int nn = m / hw;
+        const int rem = m - nn * hw;
+        const int hd = rem / a.Wd;
+        const int wd = rem - hd * a.Wd;
+        orow = ((size_t)nn * a.Hr + (size_t)hd * a.remap_s + a.remap_oh) * a.Wr + (size_t)wd * a.remap_s + a.remap_ow;
+      }
+      const size_t o = orow * a.N + n;
+      if (flags & CFH_OUT_F32) {
+        float* d = reinterpret_cast<float*>(a.dst) + o;
+        if (flags & CF_ACCUM) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += d[e];
+        }
+        *reinterpret_cast<f32x4*>(d) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      } else {
+        bf16* d = reinterpret_cast<bf16*>(a.dst) + o;
+        if (flags & CF_ACCUM) {
+          const bf16x8 old = *reinterpret_cast<const bf16x8*>(d);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+        }
+        bf16x8 q;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          q[e] = (bf16)v[e];
+          v[e] = (float)q[e];
+        }
+        *reinterpret_cast<bf16x8*>(d) = q;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ssum[e] += v[e];
+        ssq[e] += v[e] * v[e];
+      }
+    }
+    __syncthreads();  // the stage is dead: its memory is the reduction scratch / the next tile's buffers
+    if (flags & CF_STATS) {
+      float* red = reinterpret_cast<float*>(smem);  // [2][RS][BN]
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[(size_t)rr * BN + c8 * 8 + e] = ssum[e];
+        red[(size_t)(RS + rr) * BN + c8 * 8 + e] = ssq[e];
+      }
+      __syncthreads();
+      for (int c = tid; c < 2 * BN; c += 256) {
+        const int which = c / BN, col = c - which * BN;
+        float s = 0.f;
+        for (int l = 0; l < RS; ++l) s += red[(size_t)(which * RS + l) * BN + col];
+        if (n0 + col < a.N) a.stats[((size_t)mt * 2 + which) * a.N + n0 + col] = s;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ weight gradient
+struct WgradArgsH {
+  const bf16* dy;  // [npix][Cout]
+  const bf16* x;   // [Nb][Hx][Wx][Cin]
+  int Nb, Hx, Wx, Ho, Wo, npix;
+  int nchunks, chunk;  // pixels per split (multiple of 64)
+  float* part;         // [nchunks][Cout][N2] fp32
+  int Cin, Cout, N2;
+  int KH, KW, stride, pad;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_tn_bf16_kernel(const WgradArgsH a) {
+  // LDS images [64 pixels][BM (+32) channels] bf16: rows padded by 64 bytes so that the four pixel rows a
+  // ds_read_b64_tr_b16 touches per half-wave fall on disjoint banks
+  constexpr int RSA = BM * 2 + 64, RSB = BN * 2 + 64;  // row strides in bytes
+  constexpr int CGA = BM / 8, CGB = BN / 8;            // 16-byte chunks per pixel row
+  constexpr int PPA = 256 / CGA, PPB = 256 / CGB;      // pixel rows covered per pass
+  constexpr int RA = 64 / PPA, RB = 64 / PPB;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;                 // [2][64][RSA]
+  unsigned char* sB = smem + 2 * 64 * RSA;  // [2][64][RSB]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ntm = (a.Cout + BM - 1) / BM, ntn = (a.N2 + BN - 1) / BN;
+  int bid = blockIdx.x;
+  const int tm = bid % ntm;
+  bid /= ntm;
+  const int tn = bid % ntn;
+  const int ck = bid / ntn;
+  const int pix0 = ck * a.chunk;
+  const int pix1 = min(pix0 + a.chunk, a.npix);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const bf16* __restrict__ dy = a.dy;
+  const bf16* __restrict__ x = a.x;
+
+  const int ca = tid % CGA, pa = tid / CGA;
+  const int cb = tid % CGB, pb = tid / CGB;
+  const int co = m0 + ca * 8;
+  const bool co_ok = co < a.Cout;  // Cout % 8 == 0
+  const int n2 = n0 + cb * 8;
+  const bool n2_ok = n2 < a.N2;  // Cin % 8 == 0: a chunk never straddles two taps
+  int tap = 0, ci = 0, kh = 0, kw = 0;
+  if (n2_ok) {
+    tap = n2 / a.Cin;
+    ci = n2 - tap * a.Cin;
+    kh = tap / a.KW;
+    kw = tap - kh * a.KW;
+  }
+  const int HoWo = a.Ho * a.Wo, Wo = a.Wo, Hx = a.Hx, Wx = a.Wx;
+  const int dh = kh - a.pad, dw = kw - a.pad;
+
+  // pixel coordinates of this thread's RB gather rows, advanced incrementally by 64 pixels per K tile (no integer
+  // divisions in the loop: the MFMA block of a K tile is only 512 cycles long)
+  int pn[RB], ph[RB], pw[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int pix = pix0 + pb + i * PPB;
+    pn[i] = pix / HoWo;
+    const int rem = pix - pn[i] * HoWo;
+    ph[i] = rem / Wo;
+    pw[i] = rem - ph[i] * Wo;
+  }
+  const int Ho = a.Ho;
+  const int adv_n = 64 / HoWo;
+  const int adv_h = (64 - adv_n * HoWo) / Wo;
+  const int adv_w = 64 - adv_n * HoWo - adv_h * Wo;
+  auto advance = [&]() {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int w = pw[i] + adv_w;
+      const int cw = w >= Wo ? 1 : 0;
+      w -= cw ? Wo : 0;
+      int h = ph[i] + adv_h + cw;
+      const int chh = h >= Ho ? 1 : 0;
+      h -= chh ? Ho : 0;
+      pw[i] = w;
+      ph[i] = h;
+      pn[i] += adv_n + chh;
+    }
+  };
+  u32x4 ra[RA], rb[RB];
+  auto load_tile = [&](int p0) {  // the pixel state (pn, ph, pw) must already stand at p0
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int pix = p0 + pa + i * PPA;
+      const bool ok = co_ok & (pix < pix1);
+      const void* ptr = ok ? (const void*)(dy + (unsigned)(pix * a.Cout + co)) : (const void*)sacv_zero16;
+      ra[i] = ld16(ptr);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int pix = p0 + pb + i * PPB;
+      const int hi = ph[i] * a.stride + dh, wi = pw[i] * a.stride + dw;
+      const bool ok = n2_ok & (pix < pix1) & ((unsigned)hi < (unsigned)Hx) & ((unsigned)wi < (unsigned)Wx);
+      const void* ptr = ok ? (const void*)(x + ((unsigned)((pn[i] * Hx + hi) * Wx + wi) * (unsigned)a.Cin + (unsigned)ci))
+                           : (const void*)sacv_zero16;
+      rb[i] = ld16(ptr);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* dA = sA + buf * 64 * RSA + pa * RSA + ca * 16;
+    unsigned char* dB = sB + buf * 64 * RSB + pb * RSB + cb * 16;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4*>(dA + i * PPA * RSA) = ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<u32x4*>(dB + i * PPB * RSB) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  // transposing fragment read (MI355X_MICROARCH / cdna_hip_programming T10): per 16-lane group g a block of
+  // 4 pixel rows x 16 channels; lane 4q+p of the group addresses row q, channels 4p..4p+3, and receives channel
+  // (lane & 15) of rows 0..3.  Groups 0,1 serve k = 0..7 of the MFMA's 16-deep step, groups 2,3 k = 8..15.
+  const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+  const int tr_row = 8 * (g >> 1) + q;            // + 4 for the second read, + 16 per k step
+  const int tr_col = 16 * (g & 1) + 4 * p;        // channel inside the 32-wide MFMA block
+  const int KT = (pix1 - pix0 + 63) >> 6;
+  if (KT > 0) {
+    load_tile(pix0);
+    store_tile(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool last = kt + 1 == KT;
+    advance();
+    if (!last) load_tile(pix0 + ((kt + 1) << 6));
+    const unsigned char* cA = sA + cur * 64 * RSA + tr_row * RSA + (wm0 + tr_col) * 2;
+    const unsigned char* cB = sB + cur * 64 * RSB + tr_row * RSB + (wn0 + tr_col) * 2;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const unsigned char* pA = cA + kk * 16 * RSA + i * 64;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(pA));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(pA + 4 * RSA));
+        union { s16x4 s[2]; bf16x8 v; } u;
+        u.s[0] = lo;
+        u.s[1] = hi;
+        fa[i] = u.v;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const unsigned char* pB = cB + kk * 16 * RSB + j * 64;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(pB));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(pB + 4 * RSB));
+        union { s16x4 s[2]; bf16x8 v; } u;
+        u.s[0] = lo;
+        u.s[1] = hi;
+        fb[j] = u.v;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (!last) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  // epilogue: accumulators -> LDS [BM][BN+4] -> fp32 slab rows with 16-byte stores
+  constexpr int CS = BN + 4;
+  float* stage = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CS + wn0 + j * 32 + l31] = acc[i][j][r];
+  __syncthreads();
+  float* __restrict__ part = a.part + (size_t)ck * a.Cout * a.N2;
+  constexpr int CG = BN / 4, RS = 256 / CG;
+  const int c4 = tid % CG, rr = tid / CG;
+  const int n = n0 + c4 * 4;
+  if (n < a.N2) {
+#pragma unroll 4
+    for (int row = rr; row < BM; row += RS) {
+      const int m = m0 + row;
+      if (m < a.Cout)
+        *reinterpret_cast<f32x4*>(part + (size_t)m * a.N2 + n) =
+            *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4);
+    }
+  }
+}
+
+// fp32 -> bf16 elementwise (round to nearest even, NaN stays NaN): the per-step cast of the >=2-D section of the
+// parameter arena (channels_last k x k weights and 1x1 weights ARE their forward GEMM panels), dlogits, inputs
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out,
+                                                         size_t n) {
+  const size_t n8 = n >> 3;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(in + i * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(in + i * 8 + 4);
+    bf16x8 q;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      q[e] = (bf16)a[e];
+      q[4 + e] = (bf16)b[e];
+    }
+    *reinterpret_cast<bf16x8*>(out + i * 8) = q;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) out[n8 * 8 + threadIdx.x] = (bf16)in[n8 * 8 + threadIdx.x];
+}
+__global__ __launch_bounds__(256) void cast_f32_kernel(const bf16* __restrict__ in, float* __restrict__ out,
+                                                        size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = (float)in[i];
+}
+
+// data-gradient panels [Cin][T*Cout] bf16 of many fp32 weights in one launch (same descriptor table as the fp32
+// sacv_pack_dgrad_batched: {src fp32, dst, Cout, Cin, T, src_ohwi}, 32x32 tiles transposed through LDS)
+struct PackDescH {
+  const float* src;
+  bf16* dst;
+  int Cout, Cin, T, src_ohwi;
+};
+__global__ __launch_bounds__(256) void pack_dgrad_batched_bf16_kernel(const PackDescH* __restrict__ descs,
+                                                                       const int* __restrict__ chunk_map) {
+  __shared__ float tile[32][33];
+  const int di = chunk_map[2 * blockIdx.x], t = chunk_map[2 * blockIdx.x + 1];
+  const PackDescH d = descs[di];
+  const int nci = (d.Cin + 31) >> 5, nco = (d.Cout + 31) >> 5;
+  const int cob = t % nco;
+  const int qq = t / nco;
+  const int cib = qq % nci;
+  const int tap = qq / nci;
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int co = cob * 32 + r + 8 * rr, ci = cib * 32 + c;
+    float v = 0.f;
+    if (co < d.Cout && ci < d.Cin)
+      v = d.src[d.src_ohwi ? ((size_t)co * d.T + tap) * d.Cin + ci : ((size_t)co * d.Cin + ci) * d.T + tap];
+    tile[r + 8 * rr][c] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int ci = cib * 32 + r + 8 * rr, co = cob * 32 + c;
+    if (ci < d.Cin && co < d.Cout) d.dst[((size_t)ci * d.T + tap) * d.Cout + co] = (bf16)tile[c][r + 8 * rr];
+  }
+}
+
+// im2col of the stem for the bf16 GEMM: fp32 image (any strides) -> bf16 [M][Kpad], Kpad a multiple of 64
+__global__ void im2col_stem_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ col, int Nb, int Cin, int H,
+                                        int W, long long sN, long long sC, long long sH, long long sW, int Ho, int Wo,
+                                        int KH, int KW, int stride, int pad, int Kpad) {
+  const int G = Kpad >> 3;
+  const size_t total = (size_t)Nb * Ho * Wo * G;
+  const int K = KH * KW * Cin;
+  const float rcin = 1.0f / (float)Cin, rkw = 1.0f / (float)KW;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const int gq = (int)(t % G);
+    const size_t m = t / G;
+    const int wo = (int)(m % Wo);
+    const size_t qq = m / Wo;
+    const int ho = (int)(qq % Ho);
+    const int n = (int)(qq / Ho);
+    const float* __restrict__ src = x + n * sN;
+    const int hb = ho * stride - pad, wb = wo * stride - pad;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 8 * gq + e;
+      float f = 0.f;
+      if (k < K) {
+        const int tap = (int)(((float)k + 0.5f) * rcin);
+        const int ci = k - tap * Cin;
+        const int kh = (int)(((float)tap + 0.5f) * rkw);
+        const int kw = tap - kh * KW;
+        const int hi = hb + kh, wi = wb + kw;
+        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) f = src[ci * sC + hi * sH + wi * sW];
+      }
+      v[e] = (bf16)f;
+    }
+    *reinterpret_cast<bf16x8*>(col + t * 8) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+static int log2_exact_h(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return ((1 << l) == v) ? l : -1;
+}
+static int num_cus_h() {
+  static std::once_flag once;
+  static int cus = 256;
+  std::call_once(once, [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  });
+  return cus;
+}
+
+template <int BM, int BN, int MODE>
+static int launch_nt_h(ConvArgsH& a, hipStream_t st) {
+  size_t lds = (size_t)2 * (BM + BN) * 144;
+  const size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);
+  if (lds_epi > lds) lds = lds_epi;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [lds] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_bf16_kernel<BM, BN, MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  a.ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  int grid = num_cus_h() * 2;
+  if (grid > a.ntiles) grid = a.ntiles;
+  hipLaunchKernelGGL((conv_nt_bf16_kernel<BM, BN, MODE>), dim3(grid), dim3(256), lds, st, a);
+  SACV_CHECK_LAUNCH("conv_nt_bf16_kernel");
+  return SACV_OK;
+}
+
+template <int BM, int BN>
+static int launch_tn_h(const WgradArgsH& a, hipStream_t st) {
+  const int ntm = (a.Cout + BM - 1) / BM, ntn = (a.N2 + BN - 1) / BN;
+  size_t lds = (size_t)2 * 64 * ((BM * 2 + 64) + (BN * 2 + 64));
+  const size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);
+  if (lds_epi > lds) lds = lds_epi;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [lds] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tn_bf16_kernel<BM, BN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  hipLaunchKernelGGL((conv_tn_bf16_kernel<BM, BN>), dim3(ntm * ntn * a.nchunks), dim3(256), lds, st, a);
+  SACV_CHECK_LAUNCH("conv_tn_bf16_kernel");
+  return SACV_OK;
+}
+
+extern "C" {
+
+// bf16 convolution (forward mode 0 / data gradient mode 1) of ONE problem.  src NHWC bf16 [Nb][Hs][Ws][Cs]; w bf16
+// panel [N][KH*KW*Cs] (mode 0: the weight itself when stored channels_last or 1x1; mode 1: the [Cin][taps*Cout]
+// panel); dst [M][N] bf16, or fp32 with SACV_CFH_OUT_F32.  flags: SACV_CF_BIAS | SACV_CF_ACCUM | SACV_CF_STATS |
+// SACV_CFH_OUT_F32.  remap / ext as in sacv_conv2d_gemm.  Cs and N must be multiples of 8.
+int sacv_conv2d_gemm_bf16(const void* src, void* dst, int Nb, int Hs, int Ws, int Hd, int Wd, const void* w,
+                          const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode, int flags,
+                          int remap_s, int Hr, int Wr, const int* ext, float* stats, void* stream) {
+  SACV_CHECK_ARG(src && dst && w, "conv2d_gemm_bf16: null pointer");
+  SACV_CHECK_ARG(Cs % 8 == 0 && Cs > 0 && N % 8 == 0 && N > 0, "conv2d_gemm_bf16: Cs=%d and N=%d must be multiples of 8",
+                 Cs, N);
+  SACV_CHECK_ARG(KH > 0 && KW > 0 && (mode == 0 || mode == 1), "conv2d_gemm_bf16: bad KH/KW/mode");
+  const int sl = log2_exact_h(stride);
+  SACV_CHECK_ARG(sl >= 0, "conv2d_gemm_bf16: stride %d must be a power of two", stride);
+  SACV_CHECK_ARG(!(flags & CF_BIAS) || bias, "conv2d_gemm_bf16: bias flag without bias pointer");
+  SACV_CHECK_ARG(!(flags & CF_STATS) || stats, "conv2d_gemm_bf16: CF_STATS without a stats buffer");
+  SACV_CHECK_ARG((flags & ~(CF_BIAS | CF_ACCUM | CF_STATS | CFH_OUT_F32)) == 0, "conv2d_gemm_bf16: unknown flag bits");
+  SACV_CHECK_ARG(Nb > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0, "conv2d_gemm_bf16: bad dims");
+  const long long M = (long long)Nb * Hd * Wd;
+  SACV_CHECK_ARG(M * (long long)(N > Cs ? N : Cs) < (1LL << 31) && (long long)Nb * Hs * Ws * Cs < (1LL << 31) &&
+                     (long long)N * KH * KW * Cs < (1LL << 31),
+                 "conv2d_gemm_bf16: tensor too large for 32-bit element indexing");
+  ConvArgsH a;
+  a.src = (const bf16*)src;
+  a.dst = dst;
+  a.Nb = Nb;
+  a.Hs = Hs;
+  a.Ws = Ws;
+  a.Hd = Hd;
+  a.Wd = Wd;
+  a.M = (int)M;
+  a.remap_s = remap_s;
+  a.Hr = Hr;
+  a.Wr = Wr;
+  a.remap_oh = ext ? ext[9] : 0;
+  a.remap_ow = ext ? ext[10] : 0;
+  a.w = (const bf16*)w;
+  a.bias = bias;
+  a.Cs = Cs;
+  a.N = N;
+  a.KH = KH;
+  a.KW = KW;
+  a.stride_log2 = sl;
+  a.pad_h = pad;
+  a.pad_w = pad;
+  a.kh0 = 0;
+  a.khs = 1;
+  a.kw0 = 0;
+  a.kws = 1;
+  a.KWr = KW;
+  a.K = KH * KW * Cs;
+  if (ext) {
+    a.pad_h = ext[0];
+    a.pad_w = ext[1];
+    a.kh0 = ext[2];
+    a.khs = ext[3];
+    a.kw0 = ext[4];
+    a.kws = ext[5];
+    a.KWr = ext[7];
+    a.K = ext[6] * ext[7] * Cs;
+    SACV_CHECK_ARG(a.kh0 + a.khs * (KH - 1) < ext[6] && a.kw0 + a.kws * (KW - 1) < ext[7],
+                   "conv2d_gemm_bf16: tap subset exceeds the weight panel");
+  }
+  a.flags = flags;
+  a.stats = stats;
+  hipStream_t st = (hipStream_t)stream;
+  if (N <= 64)
+    return mode == 0 ? launch_nt_h<128, 64, 0>(a, st) : launch_nt_h<128, 64, 1>(a, st);
+  return mode == 0 ? launch_nt_h<128, 128, 0>(a, st) : launch_nt_h<128, 128, 1>(a, st);
+}
+
+long long sacv_conv2d_wgrad_bf16_workspace_bytes(int Nb, int Ho, int Wo, int Cin_pad, int Cout, int KH, int KW,
+                                                 int chunk) {
+  const long long chunks = ((long long)Nb * Ho * Wo + chunk - 1) / chunk;
+  return chunks * Cout * (long long)KH * KW * Cin_pad * (long long)sizeof(float);
+}
+
+// Weight gradient from bf16 activations into the fp32 gradient: dw (+)= x (*) dy, fp32 slabs per `chunk` pixels
+// (multiple of 64) summed in a fixed order.  Arguments as sacv_conv2d_wgrad, one segment.
+int sacv_conv2d_wgrad_bf16(const void* dy, const void* x, int Nb, int Hx, int Wx, int Ho, int Wo, float* dw,
+                           float* workspace, int Cin, int Cin_pad, int Cout, int KH, int KW, int stride, int pad,
+                           int chunk, int accumulate, int dw_taps, int dw_layout, void* stream) {
+  SACV_CHECK_ARG(dy && x && dw && workspace, "conv2d_wgrad_bf16: null pointer");
+  SACV_CHECK_ARG(dw_layout == 0 || (dw_layout == 1 && dw_taps == 0), "conv2d_wgrad_bf16: dw_layout");
+  SACV_CHECK_ARG(Cin_pad % 8 == 0 && Cout % 8 == 0, "conv2d_wgrad_bf16: channels must be multiples of 8");
+  SACV_CHECK_ARG(chunk % 64 == 0 && chunk > 0, "conv2d_wgrad_bf16: chunk must be a multiple of 64");
+  const long long np = (long long)Nb * Ho * Wo;
+  SACV_CHECK_ARG(np * (long long)(Cout > Cin_pad ? Cout : Cin_pad) < (1LL << 31) &&
+                     (long long)Nb * Hx * Wx * Cin_pad < (1LL << 32),
+                 "conv2d_wgrad_bf16: too large");
+  WgradArgsH a;
+  a.dy = (const bf16*)dy;
+  a.x = (const bf16*)x;
+  a.Nb = Nb;
+  a.Hx = Hx;
+  a.Wx = Wx;
+  a.Ho = Ho;
+  a.Wo = Wo;
+  a.npix = (int)np;
+  a.chunk = chunk;
+  a.nchunks = (int)((np + chunk - 1) / chunk);
+  a.part = workspace;
+  a.Cin = Cin_pad;
+  a.Cout = Cout;
+  a.N2 = KH * KW * Cin_pad;
+  a.KH = KH;
+  a.KW = KW;
+  a.stride = stride;
+  a.pad = pad;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (Cout <= 64)
+    rc = (a.N2 <= 64) ? launch_tn_h<64, 64>(a, st) : launch_tn_h<64, 128>(a, st);
+  else
+    rc = (a.N2 <= 64) ? launch_tn_h<128, 64>(a, st) : launch_tn_h<128, 128>(a, st);
+  if (rc != SACV_OK) return rc;
+  return sacv_internal_wgrad_reduce(workspace, dw, a.nchunks, Cout, Cin, Cin_pad, KH, KW, accumulate, dw_taps,
+                                    dw_layout, stream);
+}
+
+int sacv_cast_bf16(const float* in, void* out, long long n, void* stream) {
+  SACV_CHECK_ARG(in && out && n >= 0, "cast_bf16: bad args");
+  if (n == 0) return SACV_OK;
+  int blocks = (int)(((size_t)n / 8 + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, (bf16*)out, (size_t)n);
+  SACV_CHECK_LAUNCH("cast_bf16");
+  return SACV_OK;
+}
+
+int sacv_cast_f32(const void* in, float* out, long long n, void* stream) {
+  SACV_CHECK_ARG(in && out && n >= 0, "cast_f32: bad args");
+  if (n == 0) return SACV_OK;
+  int blocks = (int)(((size_t)n + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(cast_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, out,
+                     (size_t)n);
+  SACV_CHECK_LAUNCH("cast_f32");
+  return SACV_OK;
+}
+
+int sacv_pack_dgrad_batched_bf16(const void* descs, const int* chunk_map, int nchunks, void* stream) {
+  SACV_CHECK_ARG(descs && chunk_map && nchunks > 0, "pack_dgrad_batched_bf16: bad args");
+  static_assert(sizeof(PackDescH) == 32, "PackDescH layout is part of the ABI");
+  hipLaunchKernelGGL(pack_dgrad_batched_bf16_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
+                     (const PackDescH*)descs, chunk_map);
+  SACV_CHECK_LAUNCH("pack_dgrad_batched_bf16");
+  return SACV_OK;
+}
+
+int sacv_im2col_stem_bf16(const float* x, void* col, int Nb, int Cin, int H, int W, long long sN, long long sC,
+                          long long sH, long long sW, int Ho, int Wo, int KH, int KW, int stride, int pad, int Kpad,
+                          void* stream) {
+  SACV_CHECK_ARG(x && col, "im2col_stem_bf16: null pointer");
+  SACV_CHECK_ARG(Kpad % 64 == 0 && Kpad >= Cin * KH * KW, "im2col_stem_bf16: Kpad must be a multiple of 64 >= K");
+  const size_t total = (size_t)Nb * Ho * Wo * (Kpad / 8);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(im2col_stem_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (bf16*)col, Nb, Cin,
+                     H, W, sN, sC, sH, sW, Ho, Wo, KH, KW, stride, pad, Kpad);
+  SACV_CHECK_LAUNCH("im2col_stem_bf16");
+  return SACV_OK;
+}
+
+}  // extern "C"

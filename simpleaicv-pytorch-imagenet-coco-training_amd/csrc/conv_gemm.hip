@@ -1097,6 +1097,26 @@ static int launch_tn(const WgradArgs& a, int chunks, hipStream_t st) {
   return SACV_OK;
 }
 
+int sacv_internal_wgrad_reduce(const float* part, float* dw, int chunks, int Cout, int Cin, int Cin_pad, int KH,
+                               int KW, int accumulate, int dw_taps, int dw_layout, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int T = dw_taps > 0 ? dw_taps : KH * KW;
+  if (dw_taps > 0) {
+    // stem (KH = KW = 1, Cin_pad = Kpad): part is [Cout][Kpad] with k = tap*Cin + ci -> dw [Cout][Cin][dw_taps]
+    const int blocks = (Cout * dw_taps * Cin + 15) / 16;
+    hipLaunchKernelGGL(wgrad_reduce_stem_kernel, dim3(blocks), dim3(256), 0, st, part, dw, chunks, Cout, Cin, dw_taps,
+                       Cin_pad, accumulate);
+  } else {
+    const size_t total = (size_t)Cout * KH * KW * Cin_pad;
+    int blocks = (int)((total + 63) / 64);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, part, dw, chunks, Cout, Cin, Cin_pad, T,
+                       accumulate, dw_layout);
+  }
+  SACV_CHECK_LAUNCH("wgrad_reduce_kernel");
+  return SACV_OK;
+}
+
 extern "C" {
 
 // Grouped implicit-GEMM convolution (forward when mode==0, data-gradient when mode==1).
@@ -1263,23 +1283,8 @@ int sacv_conv2d_wgrad(int nseg, const float* const* dy, const float* const* x, c
   else
     rc = (a.N2 <= 64) ? launch_tn<128, 64>(a, chunks, st) : launch_tn<128, 128>(a, chunks, st);
   if (rc != SACV_OK) return rc;
-  int T = dw_taps > 0 ? dw_taps : KH * KW;
-  // for the stem (dw_taps = 49, KH=KW=1, Cin_pad = Kpad): part is [Cout][Kpad] with k = tap*Cin + ci
-  size_t total = (size_t)Cout * KH * KW * Cin_pad;
-  int blocks = (int)((total + 63) / 64);
-  if (blocks > 8192) blocks = 8192;
-  if (dw_taps > 0) {
-    // reinterpret: N2 = Kpad, real k < dw_taps*Cin laid out tap-major
-    // handled by the generic reduce with T=dw_taps, Cin_pad=Cin when Kpad == padded T*Cin: use stem reducer
-    blocks = (Cout * dw_taps * Cin + 15) / 16;
-    hipLaunchKernelGGL(wgrad_reduce_stem_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw, chunks, Cout, Cin,
-                       dw_taps, Cin_pad, accumulate);
-  } else {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, workspace, dw, chunks, Cout, Cin, Cin_pad,
-                       T, accumulate, dw_layout);
-  }
-  SACV_CHECK_LAUNCH("wgrad_reduce_kernel");
-  return SACV_OK;
+  return sacv_internal_wgrad_reduce(workspace, dw, chunks, Cout, Cin, Cin_pad, KH, KW, accumulate, dw_taps, dw_layout,
+                                    stream);
 }
 
 int sacv_pack_weight(const float* w_oihw, float* out, int Cout, int Cin, int KH, int KW, int kind, int Kpad,

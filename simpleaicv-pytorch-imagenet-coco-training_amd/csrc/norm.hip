@@ -107,94 +107,128 @@ __global__ __launch_bounds__(FIN_CH* FIN_PARTS) void bn_stats_finalize_kernel(
   }
 }
 
-// z = act( (y - mean) * invstd * gamma + beta [+ residual] );  stat_is_var: invstd holds a variance
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ y, const float* __restrict__ mean,
+// z = act( (y - mean) * invstd * gamma + beta [+ residual] );  stat_is_var: invstd holds a variance.
+// T = storage type of y / residual / z (fp32: 4 elements per thread and pass, bf16: 8); arithmetic in fp32.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ mean,
                                                         const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta,
-                                                        const float* __restrict__ residual, float* __restrict__ z,
-                                                        size_t n4, int C, int relu, int stat_is_var, float eps) {
-  const int cg = C >> 2;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    int c4 = (int)(i % cg) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
-    f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4);
-    f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4);
-    f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c4);
-    f32x4 b = *reinterpret_cast<const f32x4*>(beta + c4);
-    f32x4 o;
+                                                        const float* __restrict__ beta, const T* __restrict__ residual,
+                                                        T* __restrict__ z, size_t nv, int C, int relu, int stat_is_var,
+                                                        float eps) {
+  constexpr int V = VecIO<T>::N;
+  const int cg = C / V;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cg) * V;
+    float v[V], mu[V], is[V], g[V], b[V], o[V];
+    VecIO<T>::load(y + i * V, v);
+    ld_param<V>(mean + c0, mu);
+    ld_param<V>(invstd + c0, is);
+    ld_param<V>(gamma + c0, g);
+    ld_param<V>(beta + c0, b);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < V; ++k) {
       float inv = stat_is_var ? (1.0f / sqrtf(is[k] + eps)) : is[k];
       o[k] = (v[k] - mu[k]) * inv * g[k] + b[k];
     }
-    if (residual) o += *reinterpret_cast<const f32x4*>(residual + i * 4);
+    if (residual) {
+      float r[V];
+      VecIO<T>::load(residual + i * V, r);
+#pragma unroll
+      for (int k = 0; k < V; ++k) o[k] += r[k];
+    }
     if (relu) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.f);
+      for (int k = 0; k < V; ++k) o[k] = fmaxf(o[k], 0.f);
     }
-    *reinterpret_cast<f32x4*>(z + i * 4) = o;
+    VecIO<T>::store(z + i * V, o);
   }
 }
 
 // backward partials: partial[b][0][c] = sum g, partial[b][1][c] = sum g*xhat,  g = dz * (z > 0).
 // The ReLU mask comes from `zmask` (the stored block output) or, when rc_beta is given, is recomputed from y
 // with the forward's own expression ((y - mean) * invstd) * gamma + beta (bit-identical: -ffp-contract=off),
-// which saves reading z (layers without a residual input).
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float* __restrict__ dz,
-                                                                     const float* __restrict__ zmask,
-                                                                     const float* __restrict__ y,
+// which saves reading z (layers without a residual input).  With bf16 storage the recomputed value is rounded to
+// bf16 first, exactly like the forward pass stored it.
+template <typename T>
+__device__ __forceinline__ float storage_round(float v);
+template <>
+__device__ __forceinline__ float storage_round<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float storage_round<sacv_bf16>(float v) { return (float)(sacv_bf16)v; }
+
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const T* __restrict__ dz,
+                                                                     const T* __restrict__ zmask,
+                                                                     const T* __restrict__ y,
                                                                      const float* __restrict__ mean,
                                                                      const float* __restrict__ invstd,
                                                                      const float* __restrict__ rc_gamma,
                                                                      const float* __restrict__ rc_beta,
                                                                      float* __restrict__ partial, int R, int C,
                                                                      int rows_per_block) {
+  constexpr int V = VecIO<T>::N;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int cg = C >> 2;
+  const int cg = C / V;
   const int tid = threadIdx.x;
   const int r_begin = blockIdx.x * rows_per_block;
   const int r_end = min(R, r_begin + rows_per_block);
   float* out = partial + (size_t)blockIdx.x * 2 * C;
-  auto accum = [&](int r, int c4, const f32x4& mu, const f32x4& is, f32x4& s, f32x4& q) {
-    size_t o = (size_t)r * C + c4 * 4;
-    f32x4 g = *reinterpret_cast<const f32x4*>(dz + o);
-    f32x4 v = *reinterpret_cast<const f32x4*>(y + o);
-    const f32x4 xhat = (v - mu) * is;
+  auto accum = [&](int r, int cv, const float (&mu)[V], const float (&is)[V], float (&s)[V], float (&q)[V]) {
+    const size_t o = (size_t)r * C + cv * V;
+    float g[V], v[V], xhat[V];
+    VecIO<T>::load(dz + o, g);
+    VecIO<T>::load(y + o, v);
+#pragma unroll
+    for (int k = 0; k < V; ++k) xhat[k] = (v[k] - mu[k]) * is[k];
     if (zmask) {
-      f32x4 zz = *reinterpret_cast<const f32x4*>(zmask + o);
+      float zz[V];
+      VecIO<T>::load(zmask + o, zz);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
+      for (int k = 0; k < V; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
     } else if (rc_beta) {
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(rc_gamma + c4 * 4);
-      const f32x4 be = *reinterpret_cast<const f32x4*>(rc_beta + c4 * 4);
-      const f32x4 zz = xhat * ga + be;
+      float ga[V], be[V];
+      ld_param<V>(rc_gamma + cv * V, ga);
+      ld_param<V>(rc_beta + cv * V, be);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
+      for (int k = 0; k < V; ++k) g[k] = storage_round<T>(xhat[k] * ga[k] + be[k]) > 0.f ? g[k] : 0.f;
     }
-    s += g;
-    q += g * xhat;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      s[k] += g[k];
+      q[k] += g[k] * xhat[k];
+    }
   };
   if (cg >= BN_THREADS) {
-    for (int c4 = tid; c4 < cg; c4 += BN_THREADS) {
-      f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
-      f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
-      f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
-      for (int r = r_begin; r < r_end; ++r) accum(r, c4, mu, is, s, q);
-      *reinterpret_cast<f32x4*>(out + c4 * 4) = s;
-      *reinterpret_cast<f32x4*>(out + C + c4 * 4) = q;
+    for (int cv = tid; cv < cg; cv += BN_THREADS) {
+      float mu[V], is[V], s[V], q[V];
+      ld_param<V>(mean + cv * V, mu);
+      ld_param<V>(invstd + cv * V, is);
+#pragma unroll
+      for (int k = 0; k < V; ++k) s[k] = q[k] = 0.f;
+      for (int r = r_begin; r < r_end; ++r) accum(r, cv, mu, is, s, q);
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        out[cv * V + k] = s[k];
+        out[C + cv * V + k] = q[k];
+      }
     }
     return;
   }
   const int rl = BN_THREADS / cg;
-  const int c4 = tid % cg, rlane = tid / cg;
-  f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+  const int cv = tid % cg, rlane = tid / cg;
   if (rlane < rl) {
-    f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
-    f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
-    for (int r = r_begin + rlane; r < r_end; r += rl) accum(r, c4, mu, is, s, q);
-    *reinterpret_cast<f32x4*>(sm + (size_t)rlane * 2 * C + c4 * 4) = s;
-    *reinterpret_cast<f32x4*>(sm + (size_t)rlane * 2 * C + C + c4 * 4) = q;
+    float mu[V], is[V], s[V], q[V];
+    ld_param<V>(mean + cv * V, mu);
+    ld_param<V>(invstd + cv * V, is);
+#pragma unroll
+    for (int k = 0; k < V; ++k) s[k] = q[k] = 0.f;
+    for (int r = r_begin + rlane; r < r_end; r += rl) accum(r, cv, mu, is, s, q);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      sm[(size_t)rlane * 2 * C + cv * V + k] = s[k];
+      sm[(size_t)rlane * 2 * C + C + cv * V + k] = q[k];
+    }
   }
   __syncthreads();
   for (int i = tid; i < 2 * C; i += BN_THREADS) {
@@ -230,38 +264,43 @@ __global__ __launch_bounds__(FIN_CH* FIN_PARTS) void bn_bwd_finalize_kernel(cons
 }
 
 // dy = gamma*invstd * (g - mean_g - xhat*mean_gx);  optional g_out = g (masked upstream grad)
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz,
-                                                            const float* __restrict__ zmask,
-                                                            const float* __restrict__ y,
-                                                            const float* __restrict__ mean,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ zmask,
+                                                            const T* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ rc_beta,
-                                                            const float* __restrict__ coef, float* __restrict__ dy,
-                                                            float* __restrict__ g_out, size_t n4, int C) {
-  const int cg = C >> 2;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    int c4 = (int)(i % cg) * 4;
-    f32x4 g = *reinterpret_cast<const f32x4*>(dz + i * 4);
-    f32x4 v = *reinterpret_cast<const f32x4*>(y + i * 4);
-    f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4);
-    f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4);
-    f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c4);
-    f32x4 mg = *reinterpret_cast<const f32x4*>(coef + c4);
-    f32x4 mgx = *reinterpret_cast<const f32x4*>(coef + C + c4);
-    f32x4 xhat = (v - mu) * is;
+                                                            const float* __restrict__ coef, T* __restrict__ dy,
+                                                            T* __restrict__ g_out, size_t nv, int C) {
+  constexpr int V = VecIO<T>::N;
+  const int cg = C / V;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % cg) * V;
+    float g[V], v[V], mu[V], is[V], ga[V], mg[V], mgx[V], xhat[V], o[V];
+    VecIO<T>::load(dz + i * V, g);
+    VecIO<T>::load(y + i * V, v);
+    ld_param<V>(mean + c0, mu);
+    ld_param<V>(invstd + c0, is);
+    ld_param<V>(gamma + c0, ga);
+    ld_param<V>(coef + c0, mg);
+    ld_param<V>(coef + C + c0, mgx);
+#pragma unroll
+    for (int k = 0; k < V; ++k) xhat[k] = (v[k] - mu[k]) * is[k];
     if (zmask) {
-      f32x4 zz = *reinterpret_cast<const f32x4*>(zmask + i * 4);
+      float zz[V];
+      VecIO<T>::load(zmask + i * V, zz);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
+      for (int k = 0; k < V; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
     } else if (rc_beta) {
-      const f32x4 zz = xhat * ga + *reinterpret_cast<const f32x4*>(rc_beta + c4);
+      float be[V];
+      ld_param<V>(rc_beta + c0, be);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
+      for (int k = 0; k < V; ++k) g[k] = storage_round<T>(xhat[k] * ga[k] + be[k]) > 0.f ? g[k] : 0.f;
     }
-    f32x4 o = (g - mg - xhat * mgx) * (ga * is);
-    *reinterpret_cast<f32x4*>(dy + i * 4) = o;
-    if (g_out) *reinterpret_cast<f32x4*>(g_out + i * 4) = g;
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = (g[k] - mg[k] - xhat[k] * mgx[k]) * (ga[k] * is[k]);
+    VecIO<T>::store(dy + i * V, o);
+    if (g_out) VecIO<T>::store(g_out + i * V, g);
   }
 }
 
@@ -274,11 +313,57 @@ static int pick_blocks(int R, int* rows_per_block) {
   return nb;
 }
 
-static size_t lds_for(int C) {
-  int cg = C / 4;
+static size_t lds_for(int C, int V = 4) {
+  int cg = C / V;
   if (cg >= BN_THREADS) return 0;
   int rl = BN_THREADS / cg;
   return (size_t)rl * 2 * C * sizeof(float);
+}
+
+template <typename T>
+static int bn_apply_impl(const T* y, const float* mean, const float* invstd_or_var, const float* gamma,
+                         const float* beta, const T* residual, T* z, long long numel, int C, int relu, int stat_is_var,
+                         float eps, void* stream) {
+  constexpr int V = VecIO<T>::N;
+  SACV_CHECK_ARG(y && mean && invstd_or_var && gamma && beta && z, "bn_apply: null pointer");
+  SACV_CHECK_ARG(C % V == 0 && numel % C == 0, "bn_apply: bad shape (C=%d must be a multiple of %d)", C, V);
+  size_t nv = (size_t)numel / V;
+  int blocks = (int)((nv + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, mean, invstd_or_var, gamma,
+                     beta, residual, z, nv, C, relu, stat_is_var, eps);
+  SACV_CHECK_LAUNCH("bn_apply");
+  return SACV_OK;
+}
+
+// dz: upstream grad; y: conv output (pre-BN).  ReLU mask: zmask = the block output (or null); with zmask null and
+// beta non-null the mask is recomputed from y (layers whose output is relu(bn(y)), no residual).
+template <typename T>
+static int bn_train_bwd_impl(const T* dz, const T* zmask, const T* y, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, T* dy, T* g_out, float* dgamma, float* dbeta,
+                             int R, int C, int accumulate, float* workspace, void* stream) {
+  constexpr int V = VecIO<T>::N;
+  SACV_CHECK_ARG(dz && y && mean && invstd && gamma && dy && dgamma && dbeta && workspace, "bn_train_bwd: null");
+  SACV_CHECK_ARG(C % V == 0 && C > 0 && R > 0, "bn_train_bwd: bad shape (C=%d must be a multiple of %d)", C, V);
+  SACV_CHECK_ARG(lds_for(C, V) <= 64 * 1024, "bn_train_bwd: C=%d unsupported", C);
+  int rpb;
+  int nb = pick_blocks(R, &rpb);
+  hipStream_t st = (hipStream_t)stream;
+  float* coef = workspace + (size_t)nb * 2 * C;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(nb), dim3(BN_THREADS), lds_for(C, V), st, dz, zmask, y, mean,
+                     invstd, gamma, zmask ? nullptr : beta, workspace, R, C, rpb);
+  SACV_CHECK_LAUNCH("bn_bwd_partial");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, st,
+                     workspace, nb, R, C, dgamma,
+                     dbeta, coef, accumulate);
+  SACV_CHECK_LAUNCH("bn_bwd_finalize");
+  size_t nv = (size_t)R * C / V;
+  int blocks = (int)((nv + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, dz, zmask, y, mean, invstd, gamma,
+                     zmask ? nullptr : beta, coef, dy, g_out, nv, C);
+  SACV_CHECK_LAUNCH("bn_bwd_apply");
+  return SACV_OK;
 }
 
 extern "C" {
@@ -324,42 +409,29 @@ int sacv_bn_finalize_stats(const float* partial, int nblocks, int R, int C, floa
 int sacv_bn_apply(const float* y, const float* mean, const float* invstd_or_var, const float* gamma,
                   const float* beta, const float* residual, float* z, long long numel, int C, int relu,
                   int stat_is_var, float eps, void* stream) {
-  SACV_CHECK_ARG(y && mean && invstd_or_var && gamma && beta && z, "bn_apply: null pointer");
-  SACV_CHECK_ARG(C % 4 == 0 && numel % C == 0, "bn_apply: bad shape");
-  size_t n4 = (size_t)numel / 4;
-  int blocks = (int)((n4 + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, mean, invstd_or_var, gamma,
-                     beta, residual, z, n4, C, relu, stat_is_var, eps);
-  SACV_CHECK_LAUNCH("bn_apply");
-  return SACV_OK;
+  return bn_apply_impl<float>(y, mean, invstd_or_var, gamma, beta, residual, z, numel, C, relu, stat_is_var, eps,
+                              stream);
+}
+// bf16 activations (y, residual, z), fp32 statistics and affine parameters
+int sacv_bn_apply_bf16(const void* y, const float* mean, const float* invstd_or_var, const float* gamma,
+                       const float* beta, const void* residual, void* z, long long numel, int C, int relu,
+                       int stat_is_var, float eps, void* stream) {
+  return bn_apply_impl<sacv_bf16>((const sacv_bf16*)y, mean, invstd_or_var, gamma, beta, (const sacv_bf16*)residual,
+                                  (sacv_bf16*)z, numel, C, relu, stat_is_var, eps, stream);
 }
 
-// dz: upstream grad; y: conv output (pre-BN).  ReLU mask: zmask = the block output (or null); with zmask null and
-// beta non-null the mask is recomputed from y (layers whose output is relu(bn(y)), no residual).
 int sacv_bn_train_bwd(const float* dz, const float* zmask, const float* y, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, float* dy, float* g_out, float* dgamma, float* dbeta,
                       int R, int C, int accumulate, float* workspace, void* stream) {
-  SACV_CHECK_ARG(dz && y && mean && invstd && gamma && dy && dgamma && dbeta && workspace, "bn_train_bwd: null");
-  SACV_CHECK_ARG(C % 4 == 0 && C > 0 && R > 0, "bn_train_bwd: bad shape");
-  int rpb;
-  int nb = pick_blocks(R, &rpb);
-  hipStream_t st = (hipStream_t)stream;
-  float* coef = workspace + (size_t)nb * 2 * C;
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(BN_THREADS), lds_for(C), st, dz, zmask, y, mean, invstd,
-                     gamma, zmask ? nullptr : beta, workspace, R, C, rpb);
-  SACV_CHECK_LAUNCH("bn_bwd_partial");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, st,
-                     workspace, nb, R, C, dgamma,
-                     dbeta, coef, accumulate);
-  SACV_CHECK_LAUNCH("bn_bwd_finalize");
-  size_t n4 = (size_t)R * C / 4;
-  int blocks = (int)((n4 + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, st, dz, zmask, y, mean, invstd, gamma,
-                     zmask ? nullptr : beta, coef, dy, g_out, n4, C);
-  SACV_CHECK_LAUNCH("bn_bwd_apply");
-  return SACV_OK;
+  return bn_train_bwd_impl<float>(dz, zmask, y, mean, invstd, gamma, beta, dy, g_out, dgamma, dbeta, R, C, accumulate,
+                                  workspace, stream);
+}
+int sacv_bn_train_bwd_bf16(const void* dz, const void* zmask, const void* y, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, void* dy, void* g_out, float* dgamma, float* dbeta,
+                           int R, int C, int accumulate, float* workspace, void* stream) {
+  return bn_train_bwd_impl<sacv_bf16>((const sacv_bf16*)dz, (const sacv_bf16*)zmask, (const sacv_bf16*)y, mean, invstd,
+                                      gamma, beta, (sacv_bf16*)dy, (sacv_bf16*)g_out, dgamma, dbeta, R, C, accumulate,
+                                      workspace, stream);
 }
 
 }  // extern "C"

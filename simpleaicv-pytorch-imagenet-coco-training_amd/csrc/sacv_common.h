@@ -28,10 +28,58 @@ void sacv_set_error(const char* fmt, ...);
     }                                                                      \
   } while (0)
 
+// internal (not part of the C ABI): fixed-order sum of the weight-gradient slabs part[chunks][Cout][KH*KW*Cin_pad]
+// into dw (conv_gemm.hip); shared by the fp32 and the bf16 weight-gradient kernels
+int sacv_internal_wgrad_reduce(const float* part, float* dw, int chunks, int Cout, int Cin, int Cin_pad, int KH,
+                               int KW, int accumulate, int dw_taps, int dw_layout, void* stream);
+
 static inline int sacv_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// 16-byte vector I/O on activations stored as fp32 (4 elements) or bf16 (8 elements); arithmetic is always fp32
+typedef __bf16 sacv_bf16;
+typedef __bf16 sacv_bf16x8 __attribute__((ext_vector_type(8)));
+template <typename T>
+struct VecIO;
+template <>
+struct VecIO<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = t[e];
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+};
+template <>
+struct VecIO<sacv_bf16> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const sacv_bf16* p, float (&v)[8]) {
+    const sacv_bf16x8 t = *reinterpret_cast<const sacv_bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+  }
+  static __device__ __forceinline__ void store(sacv_bf16* p, const float (&v)[8]) {
+    sacv_bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (sacv_bf16)v[e];
+    *reinterpret_cast<sacv_bf16x8*>(p) = t;
+  }
+};
+// V consecutive fp32 per-channel parameters (V = 4 or 8; 16-byte aligned)
+template <int V>
+__device__ __forceinline__ void ld_param(const float* p, float (&v)[V]) {
+#pragma unroll
+  for (int q = 0; q < V / 4; ++q) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[4 * q + e] = t[e];
+  }
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -2,7 +2,7 @@
 
 All trainable tensors of a detector live in ONE contiguous buffer (and their gradients in a
 second one of the same layout), ordered [1-D tensors | >=2-D tensors], every tensor padded
-to a multiple of 4 floats.  This is what makes the optimizer a single fused AdamW launch
+to a multiple of 8 floats.  This is what makes the optimizer a single fused AdamW launch
 (two weight-decay groups = one split index, tools/utils.py:484-509) and a gradient bucket a
 zero-copy slice for the RCCL all-reduce.  nn.Parameter objects keep their reference names
 and shapes: their .data are views into the arena, so state_dict()/load_state_dict() work.
@@ -11,7 +11,9 @@ import torch
 
 
 def _pad4(n):
-    return (n + 3) // 4 * 4
+    """Every tensor starts on a 32-byte boundary of the fp32 arenas (= a 16-byte boundary of the bf16 cast of the
+    arena, whose slices the bf16 kernels read with 16-byte loads)."""
+    return (n + 7) // 8 * 8
 
 
 class ParamArena:

@@ -153,6 +153,16 @@ class HipDetector(nn.Module):
                                       self.planes, fcos=self._fcos)
         return self
 
+    def _apply(self, fn, recurse=True):
+        """.cuda() / .to(device): build the flat arenas at once, so that whatever wraps the model next
+        (nn.parallel.DistributedDataParallel records parameter strides at construction, tools/utils.py:178-180)
+        sees the parameters' final storage: k x k conv weights are channels_last views into the arena."""
+        out = super()._apply(fn, recurse)
+        p = next(self.parameters(), None)
+        if p is not None and p.device.type == 'cuda':
+            self.prepare()
+        return out
+
     def _ready(self):
         if self._arena is None or not self._arena.is_current():
             self.prepare()

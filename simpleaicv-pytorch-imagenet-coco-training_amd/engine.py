@@ -45,6 +45,11 @@ class DetectorEngine:
         # resnetforcifar.py:38-45)
         assert block in ('Bottleneck', 'BasicBlock') and stem in ('imagenet', 'cifar')
         self.block, self.layers, self.stem = block, tuple(layers), stem
+        # autocast mode: bf16 activations and weight panels on v_mfma_f32_32x32x16_bf16, fp32
+        # accumulation / statistics / master weights / gradients.  Needs the flat arena (set by the model).
+        self.amp = False
+        self.arena = None
+        self._hpanels = None
         self.num_classes, self.num_anchors, self.planes, self.fcos = num_classes, num_anchors, planes, fcos
         self.ctx = None
         self.bp = 'backbone.'  # key prefix of the trunk in the state_dict ('' for the bare classifier)
@@ -56,9 +61,28 @@ class DetectorEngine:
     def _wgrad(self, dys, xs, dw, cin, kh, kw, stride, pad, **kw_args):
         ops.conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, **kw_args)
 
+    def set_amp(self, enabled, arena=None):
+        """Switch the bf16 matrix-core path on/off (the reference's config.use_amp / autocast)."""
+        if enabled and (arena or self.arena) is None:
+            raise ValueError('amp needs the flat parameter arena')
+        self.arena = arena or self.arena
+        self.amp = bool(enabled)
+        return self
+
+    def _fwd_panel(self, w):
+        """Forward GEMM panel [Cout][taps*Cin] of a conv / fc weight in the compute dtype."""
+        if self.amp:
+            return self._hpanels.fwd(w)
+        return ops.fwd_panel(w if w.ndim == 4 else w.view(w.shape[0], w.shape[1], 1, 1))
+
     def _dgrad_panel(self, w):
         """[Cin][KH*KW*Cout] panel of a weight: from the batched per-step refresh when the weight is one of the
         model's parameters, packed on the spot otherwise (composite weights, unit tests)."""
+        if self.amp:
+            pnl = self._hpanels.dgrad(w)
+            if pnl is None:
+                raise ValueError('amp: no bf16 data-gradient panel for this weight')
+            return pnl
         if self._panels is not None:
             pnl = self._panels.get(w)
             if pnl is not None:
@@ -66,6 +90,14 @@ class DetectorEngine:
         return ops.pack_weight(w, PACK_DGRAD)
 
     def _refresh_dgrad_panels(self):
+        if self.amp:
+            if self._hpanels is None or not self._hpanels.is_current():
+                stem = self.bp + 'conv1.layer.0.weight'
+                ws = [t for k, t in self.p.items() if k.endswith('.weight') and t.ndim in (2, 4) and k != stem
+                      and t.dtype == torch.float32]
+                self._hpanels = ops.HalfPanels(self.arena, ws, stem_weight=self.p[stem])
+            self._hpanels.refresh()
+            return
         if self._panels is None or not self._panels.is_current():
             stem = self.bp + 'conv1.layer.0.weight'
             ws = [t for k, t in self.p.items() if k.endswith('.weight') and t.ndim == 4 and k != stem
@@ -79,7 +111,7 @@ class DetectorEngine:
         p = self.p
         w = p[prefix + '.layer.0.weight']
         cout = w.shape[0]
-        wp = ops.fwd_panel(w)
+        wp = self._fwd_panel(w)
         hw = _out_hw(x.shape[1], x.shape[2], k, stride, pad)
         if training:  # batch statistics come out of the conv epilogue (no extra pass over y)
             (y,), st = ops.conv_gemm([x], wp, cout, k, k, stride, pad, 0, [hw], stats=True)
@@ -137,7 +169,7 @@ class DetectorEngine:
             # 1x1 strided conv: only every stride-th input pixel receives gradient -> GEMM over the
             # dy pixels scattered (accumulated) into dx
             if out is None:
-                out = torch.zeros(x_shape, device=dy.device, dtype=torch.float32)
+                out = torch.zeros(x_shape, device=dy.device, dtype=dy.dtype)
                 flags |= CF_ACCUM
             elif not accumulate:
                 raise ValueError('strided 1x1 dgrad writes a sparse pattern: out must be accumulated into')
@@ -156,7 +188,7 @@ class DetectorEngine:
         for kw, so the four launches together execute exactly the forward's MACs instead of 4x."""
         n, h, w, _ = x_shape
         if out is None:
-            out = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+            out = torch.empty(x_shape, device=dy.device, dtype=dy.dtype)
         for ph in (0, 1):
             for pw in (0, 1):
                 hc, wc = (h - ph + 1) // 2, (w - pw + 1) // 2
@@ -192,10 +224,13 @@ class DetectorEngine:
         b, _, h, w = images.shape
         # stem: explicit im2col (Cin=3) + GEMM, BN, ReLU (+ 3x3/s2 max pool for the ImageNet stem)
         sk, ss, sp = (7, 2, 3) if self.stem == 'imagenet' else (3, 1, 1)
-        kpad = ops.stem_kpad(sk)
         ho, wo = _out_hw(h, w, sk, ss, sp)
-        col = ops.im2col_stem(images, ho, wo, sk, sk, ss, sp)
-        wst = ops.pack_weight(p[bp + 'conv1.layer.0.weight'], PACK_STEM)
+        if self.amp:
+            col = ops.im2col_stem(images, ho, wo, sk, sk, ss, sp, dtype=ops.BF16)
+            wst = self._hpanels.stem_panel
+        else:
+            col = ops.im2col_stem(images, ho, wo, sk, sk, ss, sp)
+            wst = ops.pack_weight(p[bp + 'conv1.layer.0.weight'], PACK_STEM)
         if training:
             (y,), st = ops.conv_gemm([col], wst, 64, 1, 1, 1, 0, 0, [(ho, wo)], stats=True)
         else:
@@ -518,7 +553,7 @@ class DetectorEngine:
         dy, _ = ops.bn_train_bwd(dpool, None, st.y, st.mean, st.invstd, self.p[bn + 'weight'], self.g[bn + 'weight'],
                                  self.g[bn + 'bias'], relu_beta=self.p[bn + 'bias'])
         self._wgrad([dy], [st.x], self.g[bp + 'conv1.layer.0.weight'], 3, 1, 1, 1, 0,
-                    cin_pad=ops.stem_kpad(st.k), dw_taps=st.k * st.k)
+                    cin_pad=st.x.shape[-1], dw_taps=st.k * st.k)
 
     def _bottleneck_bwd(self, saved, dout, accum_target):
         c1, c2, c3, cd = saved
@@ -581,8 +616,13 @@ class ClassifierEngine(DetectorEngine):
         pooled = ops.avgpool_fwd(c5)
         w, bias = self._fc_padded()
         nout = self.p['fc.weight'].shape[0]
-        wp = ops.fwd_panel(w.view(w.shape[0], w.shape[1], 1, 1))
-        logits = ops.conv_gemm([pooled], wp, w.shape[0], 1, 1, 1, 0, 0, [(1, 1)], bias=bias)[0]
+        if self.amp:
+            wp = self._hpanels.fwd(w) if w is self.p['fc.weight'] else ops.cast_bf16(w)
+            logits = ops.conv_gemm([pooled], wp, w.shape[0], 1, 1, 1, 0, 0, [(1, 1)], bias=bias,
+                                   flags=ops.CFH_OUT_F32)[0]
+        else:
+            wp = ops.fwd_panel(w.view(w.shape[0], w.shape[1], 1, 1))
+            logits = ops.conv_gemm([pooled], wp, w.shape[0], 1, 1, 1, 0, 0, [(1, 1)], bias=bias)[0]
         logits = logits.view(logits.shape[0], w.shape[0])
         if w.shape[0] != nout:
             logits = logits[:, :nout].contiguous()
@@ -598,7 +638,8 @@ class ClassifierEngine(DetectorEngine):
         e.g. the 10 classes of CIFAR-10.  Plain views when num_classes % 4 == 0."""
         w, b = self.p['fc.weight'], self.p['fc.bias']
         nout = w.shape[0]
-        npad = -(-nout // 4) * 4
+        gran = 8 if self.amp else 4
+        npad = -(-nout // gran) * gran
         if npad == nout:
             return w, b
         wp = torch.zeros((npad, w.shape[1]), device=w.device, dtype=torch.float32)
@@ -622,13 +663,20 @@ class ClassifierEngine(DetectorEngine):
             dbp = torch.empty(npad, device=dl.device, dtype=torch.float32)
         else:
             dy, dwp, dbp = dl, self.g['fc.weight'].view(nout, nin, 1, 1), self.g['fc.bias']
+        ops.colsum(dy.view(-1, npad), npad, dbp)
+        if self.amp:
+            dy = ops.cast_bf16(dy)
         dy = dy.view(dy.shape[0], 1, 1, npad)
         self._wgrad([dy], [ctx['pooled']], dwp, nin, 1, 1, 1, 0)
-        ops.colsum(dy.view(-1, npad), npad, dbp)
         if npad != nout:
             self.g['fc.weight'].copy_(dwp.view(npad, nin)[:nout])
             self.g['fc.bias'].copy_(dbp[:nout])
-        dpooled = self._dgrad(dy, w.view(npad, nin, 1, 1), ctx['pooled'].shape, 1, 1, 0)
+        if self.amp:
+            wd = self._hpanels.dgrad(w) if w is self.p['fc.weight'] else \
+                ops.cast_bf16(w.t().contiguous())  # [nin][npad]
+            dpooled = ops.conv_gemm([dy], wd, nin, 1, 1, 1, 0, 1, [(1, 1)])[0]
+        else:
+            dpooled = self._dgrad(dy, w.view(npad, nin, 1, 1), ctx['pooled'].shape, 1, 1, 0)
         dc5 = ops.avgpool_bwd(dpooled, ctx['c5_shape'])
         if on_stage:
             on_stage('heads')

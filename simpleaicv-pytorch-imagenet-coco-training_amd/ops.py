@@ -12,13 +12,16 @@ from . import _lib
 from ._lib import lib, check, iarr, farr, parr
 
 CF_BIAS, CF_RELU, CF_SIGMOID, CF_ACCUM, CF_MASK, CF_STATS = 1, 2, 4, 8, 16, 32
+CFH_OUT_F32 = 64  # bf16 convolution with an fp32 destination (the classifier's logits)
+BF16 = torch.bfloat16
 PACK_FWD, PACK_DGRAD, PACK_STEM = 0, 1, 2
 STEM_KPAD = 160  # 7*7*3 = 147 padded to a multiple of 32
 
 
-def stem_kpad(k, cin=3):
-    """GEMM-K of the im2col'ed stem convolution (k x k taps x cin), padded to a multiple of 32."""
-    return -(-(k * k * cin) // 32) * 32
+def stem_kpad(k, cin=3, granule=32):
+    """GEMM-K of the im2col'ed stem convolution (k x k taps x cin), padded to a multiple of the K tile (32 fp32
+    elements; 64 for the bf16 kernels)."""
+    return -(-(k * k * cin) // granule) * granule
 
 
 def _stream():
@@ -31,24 +34,28 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []
+        self.bytes = []
 
-    def time(self, key, flops, launch):
+    def time(self, key, flops, launch, nbytes=0.0):
+        """flops / nbytes: ALGORITHMIC work of the launch (conv MACs x 2; input + output + weights touched once)."""
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         out = launch()
         e1.record()
         self.records.append((key, flops, e0, e1))
+        self.bytes.append(nbytes)
         return out
 
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for key, flops, e0, e1 in self.records:
-            a = agg.setdefault(key, dict(launches=0, flops=0.0, ms=0.0))
+        for (key, flops, e0, e1), nb in zip(self.records, self.bytes):
+            a = agg.setdefault(key, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0))
             a['launches'] += 1
             a['flops'] += flops
             a['ms'] += e0.elapsed_time(e1)
+            a['bytes'] += nb
         return agg
 
 
@@ -56,11 +63,26 @@ TIMER = None
 _GEMM_WS_BYTES = None
 
 
-def _chk(t, name='tensor'):
-    if t.device.type != 'cuda' or t.dtype != torch.float32 or not t.is_contiguous():
-        raise ValueError(f'{name}: expected a contiguous fp32 CUDA(HIP) tensor, got {t.dtype} {t.device} '
+def _chk(t, name='tensor', dtype=torch.float32):
+    if t.device.type != 'cuda' or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError(f'{name}: expected a contiguous {dtype} CUDA(HIP) tensor, got {t.dtype} {t.device} '
                          f'contiguous={t.is_contiguous()}')
     return t
+
+
+def cast_bf16(t, out=None):
+    """fp32 -> bf16 (round to nearest even) on the device."""
+    _chk(t, 'cast_bf16 input')
+    out = out if out is not None else torch.empty(t.shape, device=t.device, dtype=BF16)
+    check(lib.sacv_cast_bf16(_ptr(t), _ptr(out), t.numel(), _stream()), 'cast_bf16')
+    return out
+
+
+def cast_f32(t):
+    _chk(t, 'cast_f32 input', BF16)
+    out = torch.empty(t.shape, device=t.device, dtype=torch.float32)
+    check(lib.sacv_cast_f32(_ptr(t), _ptr(out), t.numel(), _stream()), 'cast_f32')
+    return out
 
 
 def _ptr(t):
@@ -91,7 +113,7 @@ def fwd_panel(w):
     return pack_weight(w, PACK_FWD)
 
 
-def pack_weight(w_oihw, kind, out=None):
+def pack_weight(w_oihw, kind, out=None, kpad=None):
     layout = weight_layout(w_oihw)
     if layout == 1:
         if kind == PACK_FWD:
@@ -104,7 +126,7 @@ def pack_weight(w_oihw, kind, out=None):
         check(lib.sacv_pack_weight(_ptr(w_oihw), _ptr(out), co, ci, kh, kw, 3, 0, _stream()), 'pack_weight')
         return out
     if kind == PACK_STEM:
-        kpad = stem_kpad(kh, ci)
+        kpad = kpad or stem_kpad(kh, ci)
         shape = (co, kpad)
     elif kind == PACK_FWD:
         shape, kpad = (co, kh * kw * ci), 0
@@ -133,6 +155,10 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
     """
     n = len(srcs)
     cs = srcs[0].shape[3]
+    half = srcs[0].dtype == BF16
+    if half:
+        return _conv_gemm_bf16(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias, flags, masks, outs,
+                               remap, stats, ext)
     if outs is None:
         outs = [torch.empty((s.shape[0], hw[0], hw[1], n_out), device=s.device, dtype=torch.float32)
                 for s, hw in zip(srcs, out_hw)]
@@ -165,7 +191,49 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
         else:
             pix = sum(s.shape[0] * s.shape[1] * s.shape[2] for s in srcs)
         TIMER.time(('conv_nt_128x128' if n_out > 64 else 'conv_nt_128x64') + f'|m{mode} k{kh} s{stride} cs{cs} n{n_out} np{n} pix{pix} f{flags}',
-                   2.0 * pix * n_out * kh * kw * cs, launch)
+                   2.0 * pix * n_out * kh * kw * cs, launch,
+                   nbytes=4.0 * (sum(t.numel() for t in srcs) + sum(o.numel() for o in outs) + w_packed.numel()))
+    else:
+        launch()
+    if stats:
+        return outs, stats_buf
+    return outs
+
+
+def _conv_gemm_bf16(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias, flags, masks, outs, remap, stats,
+                    ext):
+    """bf16 activations: one problem per launch, epilogue flags BIAS / ACCUM / STATS / OUT_F32."""
+    if len(srcs) != 1 or masks:
+        raise ValueError('bf16 conv_gemm: one problem per launch, no mask epilogue')
+    if flags & ~(CF_BIAS | CF_ACCUM | CF_STATS | CFH_OUT_F32):
+        raise ValueError(f'bf16 conv_gemm: unsupported epilogue flags {flags}')
+    s, hw = _chk(srcs[0], 'conv src', BF16), out_hw[0]
+    _chk(w_packed, 'bf16 weight panel', BF16)
+    cs = s.shape[3]
+    odt = torch.float32 if (flags & CFH_OUT_F32) else BF16
+    if outs is None:
+        outs = [torch.empty((s.shape[0], hw[0], hw[1], n_out), device=s.device, dtype=odt)]
+    _chk(outs[0], 'conv dst', odt)
+    if bias is not None:
+        flags |= CF_BIAS
+    rs, hr, wr = remap if remap else (0, 0, 0)
+    stats_buf = None
+    if stats:
+        rows = -(-(s.shape[0] * hw[0] * hw[1]) // 128)
+        stats_buf = torch.empty((rows, 2, n_out), device=s.device, dtype=torch.float32)
+        flags |= CF_STATS
+
+    def launch():
+        check(lib.sacv_conv2d_gemm_bf16(s.data_ptr(), outs[0].data_ptr(), s.shape[0], s.shape[1], s.shape[2], hw[0],
+                                        hw[1], _ptr(w_packed), _ptr(bias), cs, n_out, kh, kw, stride, pad, mode, flags,
+                                        rs, hr, wr, iarr(ext) if ext is not None else None, _ptr(stats_buf),
+                                        _stream()), 'conv2d_gemm_bf16')
+
+    if TIMER is not None:
+        pix = s.shape[0] * (hw[0] * hw[1] if mode == 0 else s.shape[1] * s.shape[2])
+        TIMER.time(f'conv_nt_bf16|m{mode} k{kh} s{stride} cs{cs} n{n_out} pix{pix} f{flags}',
+                   2.0 * pix * n_out * kh * kw * cs, launch,
+                   nbytes=2.0 * (s.numel() + outs[0].numel() * (2 if odt == torch.float32 else 1) + w_packed.numel()))
     else:
         launch()
     if stats:
@@ -213,6 +281,8 @@ def conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, accumulate=False, cin_pad=
     dw_layout = weight_layout(dw) if dw.ndim == 4 else 0
     cin_pad = cin_pad or cin
     cout = dys[0].shape[3]
+    if dys[0].dtype == BF16:
+        return _conv_wgrad_bf16(dys, xs, dw, cin, cin_pad, cout, kh, kw, stride, pad, accumulate, dw_taps, dw_layout)
     nb = [d.shape[0] for d in dys]
     ho = [d.shape[1] for d in dys]
     wo = [d.shape[2] for d in dys]
@@ -235,15 +305,45 @@ def conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, accumulate=False, cin_pad=
     return dw
 
 
-def im2col_stem(x_nchw_logical, ho, wo, kh=7, kw=7, stride=2, pad=3):
+def _conv_wgrad_bf16(dys, xs, dw, cin, cin_pad, cout, kh, kw, stride, pad, accumulate, dw_taps, dw_layout):
+    if len(dys) != 1:
+        raise ValueError('bf16 conv_wgrad: one segment per launch')
+    dy, x = _chk(dys[0], 'dy', BF16), _chk(xs[0], 'x', BF16)
+    nb, ho, wo = dy.shape[0], dy.shape[1], dy.shape[2]
+    chunk = _wgrad_chunk([nb * ho * wo], cout, kh * kw * cin_pad)
+    chunk = max(64, -(-chunk // 64) * 64)
+    nbytes = lib.sacv_conv2d_wgrad_bf16_workspace_bytes(nb, ho, wo, cin_pad, cout, kh, kw, chunk)
+    ws = workspace(nbytes, dy.device, 'wgrad')
+
+    def launch():
+        check(lib.sacv_conv2d_wgrad_bf16(dy.data_ptr(), x.data_ptr(), nb, x.shape[1], x.shape[2], ho, wo, _ptr(dw),
+                                         ws.data_ptr(), cin, cin_pad, cout, kh, kw, stride, pad, chunk,
+                                         int(accumulate), dw_taps, dw_layout, _stream()), 'conv2d_wgrad_bf16')
+
+    if TIMER is not None:
+        taps = dw_taps if dw_taps else kh * kw
+        TIMER.time(f'conv_tn_bf16|k{kh} s{stride} ci{cin} co{cout}', 2.0 * nb * ho * wo * cout * cin * taps, launch,
+                   nbytes=2.0 * (dy.numel() + x.numel()) + 4.0 * dw.numel())
+    else:
+        launch()
+    return dw
+
+
+def im2col_stem(x_nchw_logical, ho, wo, kh=7, kw=7, stride=2, pad=3, dtype=torch.float32):
     """x: logical [N,3,H,W] in ANY strides (NCHW-contiguous or channels_last) -> [N,ho,wo,STEM_KPAD]."""
     x = x_nchw_logical
     if x.device.type != 'cuda' or x.dtype != torch.float32:
         raise ValueError('im2col_stem: expected an fp32 CUDA(HIP) tensor')
     n, c, h, w = x.shape
+    sn, sc, sh, sw = x.stride()
+    if dtype == BF16:
+        kpad = stem_kpad(kh, c, 64)
+        col = torch.empty((n, ho, wo, kpad), device=x.device, dtype=BF16)
+        check(lib.sacv_im2col_stem_bf16(_ptr(x), _ptr(col), n, c, h, w, sn, sc, sh, sw, ho, wo, kh, kw, stride, pad,
+                                        kpad, _stream()), 'im2col_stem_bf16')
+        return col
     kpad = stem_kpad(kh, c)
     col = torch.empty((n, ho, wo, kpad), device=x.device, dtype=torch.float32)
-    sn, sc, sh, sw = x.stride()
     check(lib.sacv_im2col_stem(_ptr(x), _ptr(col), n, c, h, w, sn, sc, sh, sw, ho, wo, kh, kw, stride, pad,
                                kpad, _stream()), 'im2col_stem')
     return col
@@ -287,6 +387,11 @@ def colsum_finalize(stats_buf, out, accumulate=False):
 def bn_apply(y, mean, invstd_or_var, gamma, beta, residual=None, relu=False, stat_is_var=False, eps=1e-5,
              out=None):
     z = out if out is not None else torch.empty_like(y)
+    if y.dtype == BF16:
+        check(lib.sacv_bn_apply_bf16(_ptr(y), _ptr(mean), _ptr(invstd_or_var), _ptr(gamma), _ptr(beta), _ptr(residual),
+                                     _ptr(z), y.numel(), y.shape[-1], int(relu), int(stat_is_var), eps, _stream()),
+              'bn_apply_bf16')
+        return z
     check(lib.sacv_bn_apply(_ptr(y), _ptr(mean), _ptr(invstd_or_var), _ptr(gamma), _ptr(beta), _ptr(residual),
                             _ptr(z), y.numel(), y.shape[-1], int(relu), int(stat_is_var), eps, _stream()), 'bn_apply')
     return z
@@ -299,6 +404,12 @@ def bn_train_bwd(dz, zmask, y, mean, invstd, gamma, dgamma, dbeta, want_g=False,
     r = y.numel() // c
     dy = dy_out if dy_out is not None else torch.empty_like(y)
     g = torch.empty_like(y) if want_g else None
+    if y.dtype == BF16:
+        check(lib.sacv_bn_train_bwd_bf16(_ptr(dz), _ptr(zmask), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                         _ptr(relu_beta), _ptr(dy), _ptr(g), _ptr(dgamma), _ptr(dbeta), r, c,
+                                         int(accumulate), _bn_ws(r, c, y.device).data_ptr(), _stream()),
+              'bn_train_bwd_bf16')
+        return dy, g
     check(lib.sacv_bn_train_bwd(_ptr(dz), _ptr(zmask), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma),
                                 _ptr(relu_beta), _ptr(dy), _ptr(g), _ptr(dgamma), _ptr(dbeta), r, c, int(accumulate),
                                 _bn_ws(r, c, y.device).data_ptr(), _stream()), 'bn_train_bwd')
@@ -330,15 +441,23 @@ def groupnorm_bwd(x, dz, zmask, stats, gamma, dgamma, dbeta, groups=32, accumula
 def maxpool_fwd(x, k=3, s=2, p=1, want_idx=True):
     n, h, w, c = x.shape
     ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
-    y = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float32)
+    y = torch.empty((n, ho, wo, c), device=x.device, dtype=x.dtype)
     idx = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.uint8) if want_idx else None
+    if x.dtype == BF16:
+        check(lib.sacv_maxpool_fwd_bf16(_ptr(x), _ptr(y), _ptr(idx), n, h, w, c, ho, wo, k, s, p, _stream()),
+              'maxpool_fwd_bf16')
+        return y, idx
     check(lib.sacv_maxpool_fwd(_ptr(x), _ptr(y), _ptr(idx), n, h, w, c, ho, wo, k, s, p, _stream()), 'maxpool_fwd')
     return y, idx
 
 
 def maxpool_bwd(dy, idx, in_shape, k=3, s=2, p=1):
     n, h, w, c = in_shape
-    dx = torch.empty(in_shape, device=dy.device, dtype=torch.float32)
+    dx = torch.empty(in_shape, device=dy.device, dtype=dy.dtype)
+    if dy.dtype == BF16:
+        check(lib.sacv_maxpool_bwd_bf16(_ptr(dy), _ptr(idx), _ptr(dx), n, h, w, c, dy.shape[1], dy.shape[2], k, s, p,
+                                        _stream()), 'maxpool_bwd_bf16')
+        return dx
     check(lib.sacv_maxpool_bwd(_ptr(dy), _ptr(idx), _ptr(dx), n, h, w, c, dy.shape[1], dy.shape[2], k, s, p,
                                _stream()), 'maxpool_bwd')
     return dx
@@ -557,14 +676,20 @@ def eval_postprocess(boxes, scales, sizes):
 # ------------------------------------------------------------------------------------------ classification
 def avgpool_fwd(x):
     n, h, w, c = x.shape
-    out = torch.empty((n, 1, 1, c), device=x.device, dtype=torch.float32)
+    out = torch.empty((n, 1, 1, c), device=x.device, dtype=x.dtype)
+    if x.dtype == BF16:
+        check(lib.sacv_avgpool_fwd_bf16(_ptr(x), _ptr(out), n, h * w, c, _stream()), 'avgpool_fwd_bf16')
+        return out
     check(lib.sacv_avgpool_fwd(_ptr(x), _ptr(out), n, h * w, c, _stream()), 'avgpool_fwd')
     return out
 
 
 def avgpool_bwd(dy, x_shape):
     n, h, w, c = x_shape
-    dx = torch.empty(tuple(x_shape), device=dy.device, dtype=torch.float32)
+    dx = torch.empty(tuple(x_shape), device=dy.device, dtype=dy.dtype)
+    if dy.dtype == BF16:
+        check(lib.sacv_avgpool_bwd_bf16(_ptr(dy), _ptr(dx), n, h * w, c, _stream()), 'avgpool_bwd_bf16')
+        return dx
     check(lib.sacv_avgpool_bwd(_ptr(dy), _ptr(dx), n, h * w, c, _stream()), 'avgpool_bwd')
     return dx
 
@@ -624,6 +749,64 @@ class DgradPanels:
 
     def get(self, w):
         return self.panels.get(w.data_ptr())
+
+
+class HalfPanels:
+    """bf16 GEMM panels of the fp32 master weights, refreshed by TWO launches per step: the forward panels are ONE
+    elementwise cast of the >=2-D section of the parameter arena (k x k weights are stored channels_last there and 1x1 /
+    FC weights are their own panels, so a weight's forward panel is a view at the same offset), the data-gradient
+    panels [Cin][taps*Cout] one batched transpose-cast.  The stem (Cin = 3, OIHW) is packed separately."""
+
+    def __init__(self, arena, weights, stem_weight=None):
+        import numpy as np
+        self.arena = arena
+        dev = arena.params.device
+        self.base = arena.params.data_ptr()
+        self.flat = torch.empty(arena.numel - arena.split, device=dev, dtype=BF16)
+        self.stem_weight = stem_weight
+        self.stem_panel = None
+        self.dpanels = {}
+        recs = np.zeros(len(weights), dtype=np.dtype([('src', '<u8'), ('dst', '<u8'), ('co', '<i4'), ('ci', '<i4'),
+                                                      ('t', '<i4'), ('ohwi', '<i4')]))
+        cmap = []
+        self._keep = list(weights)
+        for i, w in enumerate(weights):
+            w4 = w if w.ndim == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
+            co, ci, kh, kw = w4.shape
+            out = torch.empty((ci, kh * kw * co), device=dev, dtype=BF16)
+            self.dpanels[w.data_ptr()] = out
+            recs[i] = (w.data_ptr(), out.data_ptr(), co, ci, kh * kw, weight_layout(w4))
+            nchunk = kh * kw * ((ci + 31) // 32) * ((co + 31) // 32)
+            cmap.append(np.stack([np.full(nchunk, i, dtype=np.int32), np.arange(nchunk, dtype=np.int32)], axis=1))
+        cmap = np.concatenate(cmap)
+        self.nchunks = int(cmap.shape[0])
+        self.descs = torch.from_numpy(recs.view(np.uint8).copy()).to(dev)
+        self.cmap = torch.from_numpy(cmap.copy()).to(dev)
+        self.ptrs = [w.data_ptr() for w in weights]
+
+    def is_current(self):
+        return self.arena.params.data_ptr() == self.base and all(w.data_ptr() == p for w, p in zip(self._keep, self.ptrs))
+
+    def refresh(self):
+        a = self.arena
+        cast_bf16(a.params[a.split:], self.flat)
+        check(lib.sacv_pack_dgrad_batched_bf16(self.descs.data_ptr(), self.cmap.data_ptr(), self.nchunks, _stream()),
+              'pack_dgrad_batched_bf16')
+        if self.stem_weight is not None:
+            w = self.stem_weight
+            kpad = stem_kpad(w.shape[2], w.shape[1], 64)
+            self.stem_panel = cast_bf16(pack_weight(w, PACK_STEM, kpad=kpad))
+
+    def fwd(self, w):
+        """bf16 forward panel [Cout][taps*Cin] of a master weight that is stored as its own panel."""
+        off = (w.data_ptr() - self.base) // 4 - self.arena.split
+        n = w.numel()
+        if off < 0 or off + n > self.flat.numel():
+            raise ValueError('HalfPanels.fwd: not a >=2-D tensor of this arena')
+        return self.flat[off:off + n].view(w.shape[0], n // w.shape[0])
+
+    def dgrad(self, w):
+        return self.dpanels.get(w.data_ptr())
 
 
 # ------------------------------------------------------------------------------------------ step gate

@@ -290,7 +290,9 @@ class ClassificationTrainer(_StepDriver):
 
     def __init__(self, model, criterion, lr=0.1, momentum=0.9, weight_decay=1e-4, accumulation_steps=1,
                  process_group=None, nesterov=False, clip_grad_value=0.0, clip_max_norm=0.0, skip_inf_nan_grad=False,
-                 transport='torch'):
+                 transport='torch', use_amp=None):
+        if use_amp is not None:  # config.use_amp: bf16 matrix-core path (no GradScaler: bf16 has fp32's exponent)
+            model.set_amp(use_amp)
         self.criterion = criterion
         self.momentum, self.nesterov = momentum, nesterov
         self._init_driver(model, lr, weight_decay, accumulation_steps, clip_grad_value, clip_max_norm,

@@ -42,7 +42,7 @@ def test_full_size_step_against_reference_fixture(golden_dir, kind, tag):
             d = gi.digest(o.detach().cpu().numpy(), 256)
             ref = arrs[f'{name}_out{g_}_l{l}_samples']
             if fcos:  # GroupNorm over few values amplifies fp32 rounding (tests/test_gpu_fcos.py): abs vs the scale
-                assert float(np.abs(d['samples'] - ref).max()) <= 2e-4 * max(1.0, float(np.abs(ref).max())), (g_, l)
+                assert float(np.abs(d['samples'] - ref).max()) <= 5e-4 * max(1.0, float(np.abs(ref).max())), (g_, l)
             else:
                 np.testing.assert_allclose(d['samples'], ref, rtol=2e-4, atol=5e-6)
     sum(ld.values()).backward()

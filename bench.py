@@ -19,6 +19,7 @@ sys.path.insert(0, ROOT)
 
 H, W, BATCH = 800, 1333, 2
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, fp32 matrix
+PEAK_HBM_GBS = 8000.0          # same guide: HBM3E 8 TB/s spec (6.3 TB/s measured with a float4 copy)
 
 
 def cpu_baseline(max_steps=2):
@@ -84,9 +85,10 @@ def bench_classification(args, rank, world, group, ops, synth):
     from sacv_amd.classification import backbones, losses
     from sacv_amd.train import ClassificationTrainer
     CB, R = 256, 224
+    amp = args.dtype == 'bf16'
     net = backbones.__dict__['resnet50'](num_classes=1000).cuda().train()
     trainer = ClassificationTrainer(net, losses.__dict__['CELoss'](), lr=0.1, momentum=0.9, weight_decay=1e-4,
-                                    process_group=group)
+                                    process_group=group, use_amp=amp)
     images = torch.cat([torch.tensor(synth.images(rank * 64 + i, CB // 8, R, R)) for i in range(8)]).cuda()
     labels = torch.tensor((synth.uniform(rank + 99, (CB,)) * 1000).astype(np.int64) % 1000).cuda()
 
@@ -114,18 +116,39 @@ def bench_classification(args, rank, world, group, ops, synth):
         elapsed = float(t)
     roofline = None
     if timer is not None:
-        k = dict(launches=0, flops=0.0, ms=0.0)
-        for name, v in timer.summary().items():
+        agg = timer.summary()
+        k = dict(launches=0, flops=0.0, ms=0.0, bytes=0.0)
+        for name, v in agg.items():
             if name.startswith('conv_nt_'):
                 for f_ in k:
                     k[f_] += v[f_]
-        if k['launches']:
+        if k['launches'] and not amp:
             ach = k['flops'] / (k['ms'] * 1e-3) / 1e12
             roofline = dict(kernel='conv_nt_kernel (implicit-GEMM conv forward + data gradient, fp32 MFMA 32x32x2)',
                             bound='mfma', achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                             frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
                             launches_per_step=k['launches'] // args.steps,
                             share_of_step_ms=round(k['ms'] / args.steps, 2))
+        elif k['launches']:
+            # bf16: these convolutions sit at or below the HBM ridge -> algorithmic bytes (input +
+            # output + weights, each once) / HIP-event time against 8 TB/s; the matrix-core rate rides along
+            gbs = k['bytes'] / (k['ms'] * 1e-3) / 1e9
+            cls3 = dict(launches=0, flops=0.0, ms=0.0, bytes=0.0)
+            for name, v in agg.items():  # layer1 3x3 (64 -> 64 @ 56x56), forward + data gradient
+                if name.startswith('conv_nt_bf16|') and ' k3 s1 cs64 n64 ' in name:
+                    for f_ in cls3:
+                        cls3[f_] += v[f_]
+            roofline = dict(kernel='conv_nt_bf16_kernel (implicit-GEMM conv forward + data gradient, bf16 MFMA 32x32x16)',
+                            bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                            frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None,
+                            launches_per_step=k['launches'] // args.steps,
+                            share_of_step_ms=round(k['ms'] / args.steps, 2),
+                            matrix_tflops=round(k['flops'] / (k['ms'] * 1e-3) / 1e12, 1))
+            if cls3['launches']:
+                g3 = cls3['bytes'] / (cls3['ms'] * 1e-3) / 1e9
+                roofline['layer1_3x3'] = dict(achieved=round(g3, 1), frac=round(g3 / PEAK_HBM_GBS, 4), unit='GB/s',
+                                              avg_launch_us=round(cls3['ms'] / cls3['launches'] * 1e3, 1),
+                                              matrix_tflops=round(cls3['flops'] / (cls3['ms'] * 1e-3) / 1e12, 1))
         if os.environ.get('SACV_BENCH_DUMP') and rank == 0:
             recs = timer.records[-(len(timer.records) // args.steps):]
             with open(os.environ['SACV_BENCH_DUMP'], 'w') as f:
@@ -137,9 +160,10 @@ def bench_classification(args, rank, world, group, ops, synth):
             'metric': 'images/sec/node ResNet50 ImageNet 224x224 bs=256/GPU (secondary, SURVEY 8f-1)',
             'value': round(world * CB * args.steps / elapsed, 2), 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'ResNet50 ImageNet training step (fwd + CELoss + bwd + grad all-reduce + SGD '
-                                   'momentum), images [256,3,224,224]/GPU, random init',
+                                   'momentum), images [256,3,224,224]/GPU, random init'
+                                   + (', bf16 activations / fp32 accumulate+master weights (autocast)' if amp else ''),
                        'global_batch': world * CB, 'parallelism': f'dp{world}'},
             'loss': loss, 'roofline': roofline}), flush=True)
     if world > 1:
@@ -157,7 +181,12 @@ def main():
                     help='retinanet = the headline metric; fcos = secondary workload (BASELINE config 4); '
                          'resnet50_cls = ResNet50 ImageNet classification, bs 256/GPU, 224x224 (SURVEY.md 8f-1)')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help='bf16: the autocast recipe of resnet50_cls (BASELINE config #2); the detection recipes run '
+                         'fp32 (use_amp=False in their train_config.py)')
     args = ap.parse_args()
+    if args.dtype == 'bf16' and args.model != 'resnet50_cls':
+        raise SystemExit('--dtype bf16 is the resnet50_cls recipe; the detection recipes are fp32 (use_amp=False)')
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and 'RANK' not in os.environ:

@@ -22,14 +22,18 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, fp32 ma
 PEAK_HBM_GBS = 8000.0          # same guide: HBM3E 8 TB/s spec (6.3 TB/s measured with a float4 copy)
 
 
-def cpu_baseline(max_steps=2):
-    """The CPU oracle's training step (torch-CPU fp32 restatement of the reference step, pinned to the
-    reference by tests/golden) timed on this host's cores: 1 warm-up + `max_steps` timed steps of the
-    SAME workload (B=2, 800x1333)."""
+def cpu_baseline(warmup=3, steps=5):
+    """The CPU oracle's training step (torch-CPU fp32 restatement of the reference step, pinned to the reference by
+    tests/golden) timed on this host's cores: `warmup` + `steps` steps of the SAME workload (B=2, 800x1333), median,
+    with the forward / loss / backward / optimizer split."""
+    import statistics
     import torch
     from oracle import losses as olosses, model as omodel, synth
-    # a 1-GPU box shares its host: 16 cores are this job's share (more threads only oversubscribe)
-    torch.set_num_threads(min(16, os.cpu_count() or 16))
+    try:  # every core this process may run on (a 1-GPU box hands out a share of the host: 16)
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
     sd = omodel.init_retinanet_state(0)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
               if v.dtype.is_floating_point and 'running_' not in k}
@@ -41,18 +45,43 @@ def cpu_baseline(max_steps=2):
     crit = olosses.RetinaLossOracle()
     images = torch.tensor(synth.images(0, BATCH, H, W))
     annots = torch.tensor(synth.annotations(0, BATCH, H, W, boxes_per_image=8))
-    times = []
-    for it in range(1 + max_steps):
+    rows = []
+    for it in range(warmup + steps):
         t0 = time.perf_counter()
-        ld = crit(omodel.retinanet_forward(state, images, training=True), annots)
+        outs = omodel.retinanet_forward(state, images, training=True)
+        t1 = time.perf_counter()
+        ld = crit(outs, annots)
+        t2 = time.perf_counter()
         opt.zero_grad()
         sum(ld.values()).backward()
+        t3 = time.perf_counter()
         opt.step()
-        times.append(time.perf_counter() - t0)
-    t = sum(times[1:]) / max_steps
-    return dict(value=BATCH / t, unit='images/sec', cores=torch.get_num_threads(), kind='port',
-                sample=f'{max_steps} timed steps (after 1 warm-up) of the same workload: B=2, 800x1333, '
-                       f'RetinaNet-R50 fwd+RetinaLoss+bwd+AdamW, torch-CPU fp32 oracle, {t:.2f} s/step')
+        t4 = time.perf_counter()
+        rows.append((t4 - t0, t1 - t0, t2 - t1, t3 - t2, t4 - t3))
+    timed = rows[warmup:]
+    med = [statistics.median(r[i] for r in timed) for i in range(5)]
+    return dict(value=BATCH / med[0], unit='images/sec', cores=torch.get_num_threads(), kind='port',
+                seconds_per_step=round(med[0], 3),
+                split_seconds=dict(forward=round(med[1], 3), loss=round(med[2], 3), backward=round(med[3], 3),
+                                   optimizer=round(med[4], 3)),
+                sample=f'median of {steps} timed steps (after {warmup} warm-up) of the same workload: B=2, 800x1333, '
+                       f'RetinaNet-R50 fwd+RetinaLoss+bwd+AdamW, torch-CPU fp32 oracle, {med[0]:.2f} s/step')
+
+
+def class_table(agg, steps):
+    """Per conv class (kernel family, mode, kernel size, stride, channels): launches per step, time, matrix-core
+    TFLOP/s and its fraction of the dtype's dense MFMA peak, algorithmic GB/s (input + output + weights once) and its
+    fraction of the 8 TB/s HBM peak -- the bound that applies is the larger fraction's."""
+    rows = []
+    for key, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
+        half = '_bf16' in key.split('|')[0]
+        peak = 2500.0 if half else PEAK_FP32_MFMA_TFLOPS
+        tf = v['flops'] / (v['ms'] * 1e-3) / 1e12 if v['ms'] else 0.0
+        gbs = v.get('bytes', 0.0) / (v['ms'] * 1e-3) / 1e9 if v['ms'] else 0.0
+        rows.append(dict(cls=key, launches_per_step=v['launches'] / steps, ms_per_step=round(v['ms'] / steps, 4),
+                         tflops=round(tf, 1), mfma_frac=round(tf / peak, 4), gbs=round(gbs, 1),
+                         hbm_frac=round(gbs / PEAK_HBM_GBS, 4)))
+    return rows
 
 
 def launch_ranks(n):
@@ -155,6 +184,11 @@ def bench_classification(args, rank, world, group, ops, synth):
                 for key, flops, e0, e1 in recs:
                     ms = e0.elapsed_time(e1)
                     f.write(f'{key} {flops/1e9:.3f} GFLOP {ms*1e3:.1f} us {flops/(ms*1e-3)/1e12:.1f} TF\n')
+        if args.class_table and rank == 0:
+            with open(args.class_table, 'w') as f:
+                json.dump(dict(model='resnet50_cls', dtype=args.dtype, batch=CB, steps=args.steps,
+                               peak_tflops_bf16_mfma=2500.0, peak_tflops_fp32_mfma=PEAK_FP32_MFMA_TFLOPS,
+                               peak_hbm_gbs=PEAK_HBM_GBS, classes=class_table(agg, args.steps)), f, indent=1)
     if rank == 0:
         print(json.dumps({
             'metric': 'images/sec/node ResNet50 ImageNet 224x224 bs=256/GPU (secondary, SURVEY 8f-1)',
@@ -181,6 +215,11 @@ def main():
                     help='retinanet = the headline metric; fcos = secondary workload (BASELINE config 4); '
                          'resnet50_cls = ResNet50 ImageNet classification, bs 256/GPU, 224x224 (SURVEY.md 8f-1)')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--image-size', default='800x1333',
+                    help='HxW of the synthetic batch: 800x1333 = the headline shape S1, 1333x1333 = the collater\'s '
+                         'padded square S2 (SURVEY.md 8d)')
+    ap.add_argument('--class-table', default='',
+                    help='write the per-conv-class roofline table (MFMA and HBM fractions) to this JSON file')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help='bf16: the autocast recipe of resnet50_cls (BASELINE config #2); the detection recipes run '
                          'fp32 (use_amp=False in their train_config.py)')
@@ -188,6 +227,8 @@ def main():
     if args.dtype == 'bf16' and args.model != 'resnet50_cls':
         raise SystemExit('--dtype bf16 is the resnet50_cls recipe; the detection recipes are fp32 (use_amp=False)')
 
+    global H, W
+    H, W = (int(v) for v in args.image_size.lower().split('x'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and 'RANK' not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet (no torch.cuda
@@ -245,12 +286,18 @@ def main():
     if not args.no_kernel_timer:
         timer = ops.TIMER = ops.KernelTimer()
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         out = trainer.step(images, annots)
+        marks[i + 1].record()  # an event on the launch stream: no synchronisation inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    ms_median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] +
+                                                                                per_step[len(per_step) // 2])
     losses_host = trainer.finish_step(out)
     if world > 1:
         t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
@@ -282,9 +329,11 @@ def main():
             # HBM traffic per launch of the same kernel family from the PMC passes committed under profiles/
             # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read-doubling applied there)
             traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-            if os.path.exists(tpath):
-                traffic = round(json.load(open(tpath))['hbm_bytes_per_launch'])
+            for tname in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+                tpath = os.path.join(ROOT, 'profiles', tname)
+                if os.path.exists(tpath) and args.model == 'retinanet' and (H, W) == (800, 1333):
+                    traffic = round(json.load(open(tpath))['hbm_bytes_per_launch'])
+                    break
             tn = dict(launches=0, flops=0.0, ms=0.0)
             for name, v in agg.items():
                 if name.startswith('conv_tn'):
@@ -307,22 +356,32 @@ def main():
                             share_of_step_ms=round(k['ms'] / args.steps, 2))
             if secondary:
                 roofline['second_kernel'] = secondary
+        if args.class_table and rank == 0:
+            with open(args.class_table, 'w') as f:
+                json.dump(dict(model=args.model, image_size=[H, W], batch=BATCH, steps=args.steps,
+                               peak_tflops_fp32_mfma=PEAK_FP32_MFMA_TFLOPS, peak_hbm_gbs=PEAK_HBM_GBS,
+                               classes=class_table(agg, args.steps)), f, indent=1)
     if rank == 0:
         line = {
             'metric': 'images/sec/node RetinaNet-R50 COCO 1333x800 bs=2/GPU',
             'value': round(value, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+            'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'ms_per_step_median': round(ms_median, 3),
+            'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'RetinaNet-ResNet50 COCO training step (fwd + RetinaLoss SmoothL1 + bwd + '
-                                   'grad all-reduce + AdamW), images [2,3,800,1333]/GPU, 8 GT boxes/image, '
+                                   f'grad all-reduce + AdamW), images [2,3,{H},{W}]/GPU, 8 GT boxes/image, '
                                    'random init', 'global_batch': world * BATCH, 'parallelism': f'dp{world}'},
             'loss': losses_host,
             'roofline': roofline,
         }
+        headline = args.model == 'retinanet' and (H, W) == (800, 1333)
+        if not headline:
+            name = 'FCOS-R50' if args.model == 'fcos' else 'RetinaNet-R50'
+            line['metric'] = f'images/sec/node {name} COCO {W}x{H} bs=2/GPU (secondary)'
         if args.model == 'fcos':
-            line['metric'] = 'images/sec/node FCOS-R50 COCO 1333x800 bs=2/GPU (secondary)'
-            line['config']['workload'] = line['config']['workload'].replace('RetinaNet-ResNet50', 'FCOS-ResNet50').replace('RetinaLoss SmoothL1', 'FCOSLoss GIoU')
-        if world == 1 and not args.no_cpu_baseline and args.model == 'retinanet':
+            line['config']['workload'] = line['config']['workload'].replace('RetinaNet-ResNet50', 'FCOS-ResNet50') \
+                .replace('RetinaLoss SmoothL1', 'FCOSLoss GIoU')
+        if world == 1 and not args.no_cpu_baseline and args.model == 'retinanet' and (H, W) == (800, 1333):
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
     if world > 1:

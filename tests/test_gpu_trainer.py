@@ -151,7 +151,8 @@ def test_checkpoint_state_roundtrip_and_torch_optim_layout():
                    for n in g['param_names']] for g in tr.param_groups]
     opt = torch.optim.AdamW([{'params': cpu_params[0], 'weight_decay': 0.0},
                              {'params': cpu_params[1], 'weight_decay': 1e-3}], lr=1e-4)
-    opt.load_state_dict({'state': sd['state'], 'param_groups': sd['param_groups']})
+    import copy
+    opt.load_state_dict(copy.deepcopy({'state': sd['state'], 'param_groups': sd['param_groups']}))  # torch steps 'step' in place
     assert opt.param_groups[0]['lr'] == 1e-5
     tr.step(*batches[2])
     for plist, g in zip(cpu_params, tr.param_groups):

@@ -73,7 +73,13 @@ __global__ __launch_bounds__(256, 2) void conv_nt_bf16_kernel(const ConvArgsH a)
   const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+  // XCD-aware raster (cdna_hip_programming T1): workgroups are dealt round-robin over the 8 XCDs, so work item `it`
+  // runs on XCD it % 8; giving each XCD a CONTIGUOUS range of tiles keeps the N tiles of one M tile (which share the
+  // A rows) and neighbouring M tiles (which share 3x3 halo rows) in one XCD's L2.  These kernels are L2/HBM-bound.
+  const int per = (a.ntiles + 7) >> 3;
+  for (int it = blockIdx.x; it < per * 8; it += gridDim.x) {
+    const int tile = (it & 7) * per + (it >> 3);
+    if (tile >= a.ntiles) continue;
     const int nt = tile % ntn, mt = tile / ntn;
     const int m0 = mt * BM, n0 = nt * BN;
     int hb[RA], wb[RA], rowoff[RA], wrow[RB];
@@ -613,7 +619,8 @@ static int launch_nt_h(ConvArgsH& a, hipStream_t st) {
   });
   a.ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   int grid = num_cus_h() * 2;
-  if (grid > a.ntiles) grid = a.ntiles;
+  const int items = ((a.ntiles + 7) / 8) * 8;
+  if (grid > items) grid = items;
   hipLaunchKernelGGL((conv_nt_bf16_kernel<BM, BN, MODE>), dim3(grid), dim3(256), lds, st, a);
   SACV_CHECK_LAUNCH("conv_nt_bf16_kernel");
   return SACV_OK;

@@ -118,19 +118,29 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
                                                         float eps) {
   constexpr int V = VecIO<T>::N;
   const int cg = C / V;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+  // when the grid's thread count is a multiple of the channel-group count, a thread keeps its channel group for the
+  // whole grid-stride loop: the four per-channel parameter vectors are loaded once instead of once per 16-byte access
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const bool fixed = (stride % (size_t)cg) == 0;
+  float mu[V], is[V], g[V], b[V];
+  int cprev = -1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
     const int c0 = (int)(i % cg) * V;
-    float v[V], mu[V], is[V], g[V], b[V], o[V];
+    float v[V], o[V];
     VecIO<T>::load(y + i * V, v);
-    ld_param<V>(mean + c0, mu);
-    ld_param<V>(invstd + c0, is);
-    ld_param<V>(gamma + c0, g);
-    ld_param<V>(beta + c0, b);
+    if (!fixed || cprev < 0) {
+      ld_param<V>(mean + c0, mu);
+      ld_param<V>(invstd + c0, is);
+      ld_param<V>(gamma + c0, g);
+      ld_param<V>(beta + c0, b);
+      if (stat_is_var) {
 #pragma unroll
-    for (int k = 0; k < V; ++k) {
-      float inv = stat_is_var ? (1.0f / sqrtf(is[k] + eps)) : is[k];
-      o[k] = (v[k] - mu[k]) * inv * g[k] + b[k];
+        for (int k = 0; k < V; ++k) is[k] = 1.0f / sqrtf(is[k] + eps);
+      }
+      cprev = c0;
     }
+#pragma unroll
+    for (int k = 0; k < V; ++k) o[k] = (v[k] - mu[k]) * is[k] * g[k] + b[k];
     if (residual) {
       float r[V];
       VecIO<T>::load(residual + i * V, r);
@@ -174,6 +184,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const T* __r
   const int r_begin = blockIdx.x * rows_per_block;
   const int r_end = min(R, r_begin + rows_per_block);
   float* out = partial + (size_t)blockIdx.x * 2 * C;
+  float ga[V], be[V];  // recompute path: the thread's channel group is fixed in both branches below
   auto accum = [&](int r, int cv, const float (&mu)[V], const float (&is)[V], float (&s)[V], float (&q)[V]) {
     const size_t o = (size_t)r * C + cv * V;
     float g[V], v[V], xhat[V];
@@ -187,9 +198,6 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const T* __r
 #pragma unroll
       for (int k = 0; k < V; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
     } else if (rc_beta) {
-      float ga[V], be[V];
-      ld_param<V>(rc_gamma + cv * V, ga);
-      ld_param<V>(rc_beta + cv * V, be);
 #pragma unroll
       for (int k = 0; k < V; ++k) g[k] = storage_round<T>(xhat[k] * ga[k] + be[k]) > 0.f ? g[k] : 0.f;
     }
@@ -204,6 +212,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const T* __r
       float mu[V], is[V], s[V], q[V];
       ld_param<V>(mean + cv * V, mu);
       ld_param<V>(invstd + cv * V, is);
+      if (rc_beta && !zmask) {
+        ld_param<V>(rc_gamma + cv * V, ga);
+        ld_param<V>(rc_beta + cv * V, be);
+      }
 #pragma unroll
       for (int k = 0; k < V; ++k) s[k] = q[k] = 0.f;
       for (int r = r_begin; r < r_end; ++r) accum(r, cv, mu, is, s, q);
@@ -221,6 +233,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const T* __r
     float mu[V], is[V], s[V], q[V];
     ld_param<V>(mean + cv * V, mu);
     ld_param<V>(invstd + cv * V, is);
+    if (rc_beta && !zmask) {
+      ld_param<V>(rc_gamma + cv * V, ga);
+      ld_param<V>(rc_beta + cv * V, be);
+    }
 #pragma unroll
     for (int k = 0; k < V; ++k) s[k] = q[k] = 0.f;
     for (int r = r_begin + rlane; r < r_end; r += rl) accum(r, cv, mu, is, s, q);
@@ -274,16 +290,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                             T* __restrict__ g_out, size_t nv, int C) {
   constexpr int V = VecIO<T>::N;
   const int cg = C / V;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (size_t)gridDim.x * blockDim.x) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const bool fixed = (stride % (size_t)cg) == 0;  // see bn_apply_kernel
+  float mu[V], is[V], ga[V], mg[V], mgx[V], be[V];
+  int cprev = -1;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
     const int c0 = (int)(i % cg) * V;
-    float g[V], v[V], mu[V], is[V], ga[V], mg[V], mgx[V], xhat[V], o[V];
+    float g[V], v[V], xhat[V], o[V];
     VecIO<T>::load(dz + i * V, g);
     VecIO<T>::load(y + i * V, v);
-    ld_param<V>(mean + c0, mu);
-    ld_param<V>(invstd + c0, is);
-    ld_param<V>(gamma + c0, ga);
-    ld_param<V>(coef + c0, mg);
-    ld_param<V>(coef + C + c0, mgx);
+    if (!fixed || cprev < 0) {
+      ld_param<V>(mean + c0, mu);
+      ld_param<V>(invstd + c0, is);
+      ld_param<V>(gamma + c0, ga);
+      ld_param<V>(coef + c0, mg);
+      ld_param<V>(coef + C + c0, mgx);
+      if (rc_beta) ld_param<V>(rc_beta + c0, be);
+      cprev = c0;
+    }
 #pragma unroll
     for (int k = 0; k < V; ++k) xhat[k] = (v[k] - mu[k]) * is[k];
     if (zmask) {
@@ -292,8 +316,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
       for (int k = 0; k < V; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
     } else if (rc_beta) {
-      float be[V];
-      ld_param<V>(rc_beta + c0, be);
 #pragma unroll
       for (int k = 0; k < V; ++k) g[k] = storage_round<T>(xhat[k] * ga[k] + be[k]) > 0.f ? g[k] : 0.f;
     }

@@ -291,6 +291,55 @@ int sacv_maxpool_bwd_bf16(const void* dy, const unsigned char* idx, void* dx, in
 int sacv_avgpool_fwd_bf16(const void* x, void* out, int N, int HW, int C, void* stream);
 int sacv_avgpool_bwd_bf16(const void* dy, void* dx, int N, int HW, int C, void* stream);
 
+/* ---- ViT-B/16 MAE pre-training step (BASELINE config #5).  simpleAICV/masked_image_modeling/models/
+ *      vit_mae.py:25-461, simpleAICV/classification/backbones/vit.py:20-160, masked_image_modeling/losses.py:11-23.
+ *      The Linear layers (patch embedding, qkv, proj, fc1, fc2, encoder_to_decoder, pred) run as 1x1 problems of
+ *      sacv_conv2d_gemm_bf16 / sacv_conv2d_wgrad_bf16; these are the kernels around them.  Index tensors are int64
+ *      (torch.argsort / torch.gather), the residual stream is fp32, GEMM operands bf16. --------------------------- */
+/* random_masking (vit_mae.py:187-215): shuffle = argsort(noise[b]), restore = argsort(shuffle), keep = shuffle[:keep],
+ * mask = restore >= keep.  noise [B][n] fp32 (torch.rand in the reference), n <= 1024. */
+int sacv_mae_random_masking(const float* noise, int B, int n, int keep_len, long long* shuffle_ids,
+                            long long* restore_ids, long long* keep_ids, float* mask, void* stream);
+/* rows[b*keep + j][(c*P + py)*P + px] bf16 = patch ids[b][j] of image b (ids NULL: every patch in order); the
+ * P x P / stride-P PatchEmbeddingBlock convolution is a GEMM over these rows, only the KEPT patches are embedded */
+int sacv_mae_patchify(const float* img, const long long* ids, void* rows, int B, int C, int H, int W, int P, int keep,
+                      long long sN, long long sC, long long sH, long long sW, void* stream);
+/* images_to_patch (vit_mae.py:421-433) [+ the collater's per-patch normalisation when norm != 0] -> fp32 [B][L][P*P*C] */
+int sacv_mae_patch_labels(const float* img, float* out, int B, int C, int H, int W, int P, int norm, long long sN,
+                          long long sC, long long sH, long long sW, void* stream);
+/* encoder input: x[b][0] = cls + pos[0]; x[b][1+j] = emb[b*keep+j] + pos[1 + keep_ids[b][j]]  (fp32 out) */
+int sacv_mae_encoder_tokens(const void* emb, const float* cls, const float* pos, const long long* keep_ids, float* x,
+                            int B, int keep, int E, void* stream);
+int sacv_mae_encoder_tokens_bwd(const float* dx, void* demb, int B, int keep, int E, void* stream);
+/* decoder input (vit_mae.py:343-360): mask tokens appended, un-shuffled by restore_ids, + pos */
+int sacv_mae_decoder_tokens(const void* y, const float* mask_token, const float* pos, const long long* restore_ids,
+                            float* x, int B, int keep, int n, int D, void* stream);
+/* dy bf16 [B][keep+1][D]; gmask fp32 [B*(n-keep)][D]: the rows whose column sum is d mask_token */
+int sacv_mae_decoder_tokens_bwd(const float* dx, const long long* shuffle_ids, void* dy, float* gmask, int B, int keep,
+                                int n, int D, void* stream);
+/* nn.LayerNorm over the last dim: x fp32 [R][C] -> y bf16; mean / rstd fp32 [R] saved for the backward */
+int sacv_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int R,
+                       int C, float eps, void* stream);
+long long sacv_layernorm_bwd_workspace_floats(int R, int C);
+int sacv_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       float* dx, float* dgamma, float* dbeta, int R, int C, int accumulate_dx, int accumulate_params,
+                       float* workspace, void* stream);
+/* nn.GELU() (exact erf form) on bf16 tensors */
+int sacv_gelu_fwd(const void* x, void* y, long long n, void* stream);
+int sacv_gelu_bwd(const void* dy, const void* x, void* dx, long long n, void* stream);
+long long sacv_colsum_bf16_workspace_floats(int R, int C);
+int sacv_colsum_bf16(const void* x, float* out, int R, int C, int accumulate, float* workspace, void* stream);
+/* MultiHeadAttention core (vit.py:73-86): qkv bf16 [B][n][3][H][d] -> out bf16 [B][n][H*d];
+ * softmax(bf16(QK^T) * scale) in fp32, probabilities cast to bf16 for the product with V (autocast's dtypes) */
+int sacv_attention_fwd(const void* qkv, void* out, int B, int n, int H, int d, float scale, void* stream);
+int sacv_attention_bwd(const void* qkv, const void* dout, void* dqkv, int B, int n, int H, int d, float scale,
+                       void* stream);
+long long sacv_mae_mse_workspace_floats(int B, int n);
+/* MSELoss(pred[:, 1:], label, mask) (losses.py:11-23); pred bf16 [B][n+1][K] (row 0 = cls token, dropped),
+ * label fp32 [B][n][K], mask fp32 [B][n]; dpred (nullable) bf16 = d loss / d pred * grad_scale */
+int sacv_mae_mse_loss(const void* pred, const float* label, const float* mask, void* dpred, float* loss_out, int B,
+                      int n, int K, float grad_scale, float* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

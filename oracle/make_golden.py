@@ -763,9 +763,95 @@ def sec_cls_bf16(ref):
 
 
 
+MAE_CFGS = {
+    # name: (cfg of oracle.mae, batch)
+    'tiny': (dict(patch=16, image=64, E=128, Le=2, He=4, D=64, Ld=1, Hd=4), 4),
+    'base_d2': (dict(patch=16, image=224, E=768, Le=2, He=12, D=512, Ld=1, Hd=16), 4),
+    'base': (dict(patch=16, image=224, E=768, Le=12, He=12, D=512, Ld=8, Hd=16), 2),
+}
+
+
+def sec_mae(ref):
+    """the reference VITMAEPretrainModel + MSELoss + collater labels on seeded inputs, fp32 and under
+    torch.autocast('cpu', bfloat16) (the recipe's use_amp).  The masking noise is the reference's own torch.rand draw
+    after torch.manual_seed(s) (recorded: the first RNG use of forward is random_masking, dropout is 0)."""
+    load_reference()
+    import importlib
+    mm = importlib.import_module('simpleAICV.masked_image_modeling.models.vit_mae')
+    ml = importlib.import_module('simpleAICV.masked_image_modeling.losses')
+    mc = importlib.import_module('simpleAICV.masked_image_modeling.common')
+    from oracle import mae as omae
+    meta, arrs = {}, {}
+    for name, (cfg, B) in MAE_CFGS.items():
+        def build():
+            net = mm.VITMAEPretrainModel(patch_size=cfg['patch'], image_size=cfg['image'], mask_ratio=0.75,
+                                         encoder_embedding_planes=cfg['E'], encoder_block_nums=cfg['Le'],
+                                         encoder_head_nums=cfg['He'], decoder_embedding_planes=cfg['D'],
+                                         decoder_block_nums=cfg['Ld'], decoder_head_nums=cfg['Hd'])
+            net.load_state_dict(omae.init_mae_state(0, cfg), strict=True)
+            return net.train()
+        net = build()
+        if name == 'tiny':
+            meta['contract_tiny'] = dict(
+                keys=[[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in net.state_dict().items()],
+                params=[[k, list(v.shape), bool(v.requires_grad)] for k, v in net.named_parameters()])
+        if name == 'base':
+            full = mm.vit_base_patch16_224_mae_pretrain_model()
+            meta['contract_base'] = dict(
+                keys=[[k, list(v.shape)] for k, v in full.state_dict().items()],
+                n_params=int(sum(p.numel() for p in full.parameters())),
+                pos_embed_sha=sha(full.encoder.pos_embed.detach().numpy()),
+                dec_pos_embed_sha=sha(full.decoder.pos_embed.detach().numpy()))
+        S = cfg['image']
+        hwc = np.transpose(synth.images(71, B, S, S), (0, 2, 3, 1)) * 4.0 - 2.0   # ~ mean/std-normalised pixels
+        batch = mc.MAESelfSupervisedPretrainCollater(image_size=S, patch_size=cfg['patch'], norm_label=True)(
+            [dict(image=hwc[i]) for i in range(B)])
+        images, labels = batch['image'], batch['label']
+        crit = ml.MSELoss()
+        n = (S // cfg['patch'])**2
+        torch.manual_seed(1234 + len(name))
+        noise = torch.rand(B, n)
+        m = dict(cfg=cfg, B=B, noise_seed=1234 + len(name))
+        arrs[f'{name}_noise'] = noise.numpy()
+        arrs[f'{name}_labels_samples'] = labels.numpy().reshape(-1)[::997].copy()
+        m['labels_sha'] = sha(labels.numpy())
+        for tag, ctx in (('fp32', None), ('bf16', torch.autocast('cpu', dtype=torch.bfloat16))):
+            net = build()
+            torch.manual_seed(1234 + len(name))
+            if ctx is None:
+                out, mask = net(images)
+                loss = crit(out, labels, mask)
+            else:
+                with ctx:
+                    out, mask = net(images)
+                    loss = crit(out, labels, mask)
+            loss.backward()
+            m[f'loss_{tag}'] = float(loss.detach())
+            m[f'grad_norm_{tag}'] = {k: float(p.grad.double().norm()) for k, p in net.named_parameters()
+                                     if p.grad is not None}
+            arrs[f'{name}_pred_{tag}'] = out.detach().float().numpy().reshape(-1)[::211].copy()
+            if tag == 'fp32':
+                arrs[f'{name}_mask'] = mask.numpy()
+                # restore ids and mask from the reference encoder itself (same seed => same noise draw)
+                probe = build()  # (construction consumes RNG: seed AFTER it)
+                torch.manual_seed(1234 + len(name))
+                with torch.no_grad():
+                    _, mask_e, restore_e = probe.encoder(images)
+                assert torch.equal(mask_e, mask)
+                arrs[f'{name}_restore'] = restore_e.numpy()
+                for k in ('encoder.cls_token', 'decoder.mask_token', 'encoder.norm.weight', 'decoder.fc.bias',
+                          'encoder.blocks.0.attn.qkv.bias', 'encoder.patch_embed.proj.bias'):
+                    arrs[f'{name}_grad_{k}'] = dict(net.named_parameters())[k].grad.numpy().copy()
+        meta[name] = m
+        print(name, m['loss_fp32'], m['loss_bf16'])
+    np.savez_compressed(os.path.join(GOLD, 'mae.npz'), **arrs)
+    json.dump(meta, open(os.path.join(GOLD, 'mae.json'), 'w'), indent=0)
+
+
+
 SECTIONS = dict(cls=sec_cls, contract=sec_contract, anchors=sec_anchors, assign=sec_assign, losses=sec_losses,
                 decode=sec_decode, e2e=sec_e2e, e2e_s1=sec_e2e_s1, e2e_s2=sec_e2e_s2, scheduler=sec_scheduler,
-                trainer=sec_trainer, collate=sec_collate, evalpost=sec_evalpost, cifar=sec_cifar, cls_bf16=sec_cls_bf16)
+                trainer=sec_trainer, collate=sec_collate, evalpost=sec_evalpost, cifar=sec_cifar, cls_bf16=sec_cls_bf16, mae=sec_mae)
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)

@@ -80,6 +80,24 @@ SIGNATURES = {
     'sacv_maxpool_bwd_bf16': (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     'sacv_avgpool_fwd_bf16': (I, [P, P, I, I, I, P]),
     'sacv_avgpool_bwd_bf16': (I, [P, P, I, I, I, P]),
+    'sacv_mae_random_masking': (I, [P, I, I, I, P, P, P, P, P]),
+    'sacv_mae_patchify': (I, [P, P, P, I, I, I, I, I, I, LL, LL, LL, LL, P]),
+    'sacv_mae_patch_labels': (I, [P, P, I, I, I, I, I, I, LL, LL, LL, LL, P]),
+    'sacv_mae_encoder_tokens': (I, [P, P, P, P, P, I, I, I, P]),
+    'sacv_mae_encoder_tokens_bwd': (I, [P, P, I, I, I, P]),
+    'sacv_mae_decoder_tokens': (I, [P, P, P, P, P, I, I, I, I, P]),
+    'sacv_mae_decoder_tokens_bwd': (I, [P, P, P, P, I, I, I, I, P]),
+    'sacv_layernorm_fwd': (I, [P, P, P, P, P, P, I, I, F, P]),
+    'sacv_layernorm_bwd_workspace_floats': (LL, [I, I]),
+    'sacv_layernorm_bwd': (I, [P, P, P, P, P, P, P, P, I, I, I, I, P, P]),
+    'sacv_gelu_fwd': (I, [P, P, LL, P]),
+    'sacv_gelu_bwd': (I, [P, P, P, LL, P]),
+    'sacv_colsum_bf16_workspace_floats': (LL, [I, I]),
+    'sacv_colsum_bf16': (I, [P, P, I, I, I, P, P]),
+    'sacv_attention_fwd': (I, [P, P, I, I, I, I, F, P]),
+    'sacv_attention_bwd': (I, [P, P, P, I, I, I, I, F, P]),
+    'sacv_mae_mse_workspace_floats': (LL, [I, I]),
+    'sacv_mae_mse_loss': (I, [P, P, P, P, P, I, I, I, F, P, P]),
     'sacv_comm_unique_id_bytes': (I, []),
     'sacv_comm_unique_id': (I, [P]),
     'sacv_comm_init': (I, [P, I, I, P]),

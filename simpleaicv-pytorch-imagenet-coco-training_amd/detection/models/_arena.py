@@ -19,7 +19,9 @@ def _pad4(n):
 class ParamArena:
 
     def __init__(self, module):
-        named = [(n, p) for n, p in module.named_parameters()]
+        # frozen parameters (the MAE position tables, requires_grad=False) stay outside the arenas: build_optimizer
+        # skips them too (tools/utils.py:320-322, :483-485)
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         if not named:
             raise ValueError('module has no parameters')
         dev = named[0][1].device

@@ -32,7 +32,7 @@ def stage_ranges(arena_order, offsets, numel, split):
                 return o
         return numel
 
-    heads_begin = first(('cls_head.', 'reg_head.', 'clsregcnt_head.', 'fc.'))
+    heads_begin = first(('cls_head.', 'reg_head.', 'clsregcnt_head.', 'fc.', 'decoder.'))
     neck_begin = min(first(('backbone.layer4.', 'layer4.')), first(('fpn.',)))
     neck_begin = min(neck_begin, heads_begin)
     mid_begin = min(first(('backbone.layer3.', 'layer3.')), neck_begin)

@@ -283,6 +283,54 @@ class DetectionTrainer(_StepDriver):
         return out
 
 
+class MAETrainer(DetectionTrainer):
+    """One iteration of tools/scripts.py::train_mae_self_supervised_learning (:1748-1900) with the recipe's optimizer
+    (2.masked_image_modeling_training/imagenet/mae_vit_base_patch16_224/train_config.py: AdamW lr 6e-4, betas
+    (0.9, 0.95), weight decay 5e-2 on ndim>1 tensors, CosineLR with 40 warm-up epochs, use_amp).  The labels of the
+    reference come from its collater (per-patch normalised pixels, masked_image_modeling/common.py:8-44); when the
+    caller passes none they are computed from the images on the device."""
+
+    def __init__(self, model, criterion, lr=6e-4, betas=(0.9, 0.95), eps=1e-8, weight_decay=5e-2, norm_label=True,
+                 **kw):
+        super().__init__(model, criterion, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kw)
+        self.norm_label = norm_label
+
+    def step(self, images, labels=None, noise=None):
+        from . import vit_ops as V
+        model = self.model
+        self._begin(*([images] if labels is None else [images, labels]))
+        engine, arena = model.engine, self._arena
+        images = images.float()
+        if labels is None:
+            labels = V.patch_labels(images, model.patch_size, norm=self.norm_label)
+        pred, mask = engine.forward(images, noise=noise, keep=True)
+        inv = 1.0 / self.accumulation_steps
+        loss, dpred = self.criterion.fused(pred, labels.contiguous().float(), mask, grad_scale=inv)
+        ops.loss_skip_flag(loss, self.flag)
+        self._vote_begin()
+        engine.backward(dpred, on_stage=self._on_stage)
+        if inv != 1.0:
+            loss = ops.eltwise(ops.EW_SCALE, loss, scalar=inv)
+        out = {'loss': loss[0]}
+        if self._after_backward():
+            return out
+        if self.boundary:
+            self._gate_and_clip(self.betas[0], self.betas[1])
+            g1, g2 = self.param_groups
+            ops.adamw_step_gated(arena.params, arena.grads, self.exp_avg, self.exp_avg_sq, arena.split, g1['lr'],
+                                 self.betas[0], self.betas[1], self.eps, g1['weight_decay'], g2['weight_decay'],
+                                 self.state, grad_scale=1.0 / self.world, clip_value=self.clip_grad_value,
+                                 lr_hi=g2['lr'])
+            self.micro = 0
+        self.iter_index += 1
+        return out
+
+    def finish_step(self, loss_dict):
+        v = torch.cat([loss_dict['loss'].reshape(1).float(), self.state[0:2]])
+        v = vote_and_reduce_scalars(v, self.group).tolist()
+        return {'loss': v[0] / self.world, 'optimizer_steps': int(round(v[1] / self.world)), 'skipped': v[2] > 0}
+
+
 class ClassificationTrainer(_StepDriver):
     """One ImageNet training iteration of tools/scripts.py::train_classification with the ResNet50 recipe's
     optimizer (0.classification_training/imagenet/resnet50/train_config.py:68-79: SGD lr 0.1, momentum 0.9,

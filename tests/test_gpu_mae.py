@@ -1,0 +1,200 @@
+"""ViT MAE pre-training on the GPU: the kernels of csrc/vit.hip against torch references, the
+random-masking indices bit-exact against the reference's own draw, and the whole forward / loss / backward against the
+reference model run in fp32 and under torch.autocast('cpu', bfloat16) (tests/golden/mae.*; the recipe uses use_amp).
+
+Tolerances: index tensors and the mask bit-exact; fp32-in/fp32-out kernels 1e-5; bf16 tensors 2^-8 relative + 2e-3 of the
+tensor's max (rounding + summation order); end to end: loss within max(2e-3, 3x the reference's own bf16-vs-fp32 gap),
+gradient norms as close to the fp32 run as the reference's bf16 run is (factor 2.5, floor 2e-2 median)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import mae as omae, synth
+from tests.test_mae_cpu import mae_inputs
+
+BF = torch.bfloat16
+
+
+def rnd(seed, *shape, std=1.0):
+    return torch.tensor(synth.normal(seed, shape, std=std))
+
+
+def q(t):
+    return t.to(BF).float()
+
+
+def close_bf16(got, ref, what, extra=2e-3):
+    got, ref = got.float().cpu(), ref.float()
+    tol = (2.0**-8) * ref.abs() + extra * ref.abs().max()
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), (what, int(bad.sum()), float((got - ref).abs().max()), float(ref.abs().max()))
+
+
+def test_random_masking_indices_bit_exact(golden_dir):
+    from sacv_amd import vit_ops as V
+    arrs = np.load(os.path.join(golden_dir, 'mae.npz'))
+    for name, n in (('tiny', 16), ('base', 196)):
+        noise = torch.tensor(arrs[f'{name}_noise'])
+        keep = int(n * 0.25)
+        shuffle, restore, keep_ids, mask = V.random_masking(noise.cuda(), keep)
+        assert np.array_equal(restore.cpu().numpy(), arrs[f'{name}_restore'])       # the reference encoder's own ids
+        assert np.array_equal(mask.cpu().numpy(), arrs[f'{name}_mask'])
+        assert torch.equal(shuffle.cpu(), torch.argsort(noise, dim=1)) and torch.equal(keep_ids, shuffle[:, :keep])
+    noise = torch.rand(37, 1000)
+    s, r, k, m = V.random_masking(noise.cuda(), 250)
+    assert torch.equal(s.cpu(), torch.argsort(noise, dim=1)) and torch.equal(r.cpu(), torch.argsort(s.cpu(), dim=1))
+
+
+def test_patch_layernorm_gelu_tokens_loss_kernels():
+    from sacv_amd import vit_ops as V
+    B, S, P = 3, 64, 16
+    img = rnd(1, B, S, S, 3).permute(0, 3, 1, 2)                       # channels_last strides like the collater's
+    n = (S // P)**2
+    ids = torch.stack([torch.randperm(n)[:5] for _ in range(B)])
+    rows = V.patchify(img.cuda(), P, ids.cuda())
+    unf = F.unfold(img.contiguous(), P, stride=P).transpose(1, 2)      # [B, n, 3*P*P] in (c, py, px) order
+    want = torch.gather(unf, 1, ids.unsqueeze(-1).repeat(1, 1, unf.shape[-1])).reshape(-1, unf.shape[-1])
+    assert torch.equal(rows.cpu(), want.to(BF))
+    lab = V.patch_labels(img.cuda(), P, norm=True).cpu()
+    torch.testing.assert_close(lab, omae.patch_labels(img, P, True), rtol=1e-5, atol=1e-5)
+    assert torch.equal(V.patch_labels(img.cuda(), P, norm=False).cpu(), omae.patch_labels(img, P, False))
+    # LayerNorm
+    R, C = 50, 768
+    x = rnd(2, R, C) * 2 + 0.5
+    ga, be = 1 + 0.2 * rnd(3, C), 0.1 * rnd(4, C)
+    xr, gr, br = x.clone().requires_grad_(True), ga.clone().requires_grad_(True), be.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (C,), gr, br, 1e-6)
+    dy = q(rnd(5, R, C))
+    y.backward(dy)
+    yh, mean, rstd = V.layernorm_fwd(x.cuda(), ga.cuda(), be.cuda())
+    close_bf16(yh, y.detach(), 'layernorm fwd', extra=1e-5)
+    dga, dbe = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    dx = V.layernorm_bwd(dy.cuda().to(BF), x.cuda(), mean, rstd, ga.cuda(), dga, dbe)
+    torch.testing.assert_close(dx.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dga.cpu(), gr.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dbe.cpu(), br.grad, rtol=1e-4, atol=1e-4)
+    base = rnd(6, R, C).cuda()
+    dx2 = V.layernorm_bwd(dy.cuda().to(BF), x.cuda(), mean, rstd, ga.cuda(), dga, dbe, dx=base.clone(),
+                          accumulate_params=True)
+    torch.testing.assert_close(dx2, base + dx, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(dga.cpu(), 2 * gr.grad, rtol=1e-4, atol=2e-4)
+    # GELU
+    f = q(rnd(7, 33, 3072) * 2)
+    fr = f.clone().requires_grad_(True)
+    gl = F.gelu(fr)
+    dg = q(rnd(8, 33, 3072))
+    gl.backward(dg)
+    close_bf16(V.gelu_fwd(f.cuda().to(BF)), gl.detach(), 'gelu fwd', extra=1e-5)
+    close_bf16(V.gelu_bwd(dg.cuda().to(BF), f.cuda().to(BF)), fr.grad, 'gelu bwd', extra=1e-5)
+    # column sums
+    out = torch.zeros(3072, device='cuda')
+    V.colsum_bf16(f.cuda().to(BF), out)
+    torch.testing.assert_close(out.cpu(), f.sum(0), rtol=1e-5, atol=1e-4)
+    # masked MSE
+    Bm, nm, K = 4, 16, 768
+    pred = q(rnd(9, Bm, nm + 1, K))
+    label = rnd(10, Bm, nm, K)
+    mask = (torch.tensor(synth.uniform(11, (Bm, nm))) > 0.25).float()
+    pr = pred.clone().requires_grad_(True)
+    ref = omae.mse_loss(pr[:, 1:, :], label, mask)
+    ref.backward()
+    loss, dpred = V.mse_loss(pred.view(-1, K).cuda().to(BF), label.cuda(), mask.cuda())
+    assert abs(float(loss) - float(ref)) <= 1e-5 * float(ref)
+    close_bf16(dpred.view(Bm, nm + 1, K), pr.grad, 'mse grad', extra=1e-5)
+
+
+@pytest.mark.parametrize('b,n,heads,d', [(2, 50, 12, 64), (2, 197, 16, 32), (3, 17, 4, 32)])
+def test_attention_core_fwd_bwd(b, n, heads, d):
+    """softmax(bf16(QK^T) * scale) V with autocast's rounding points against torch on the same bf16 inputs."""
+    from sacv_amd import vit_ops as V
+    c = heads * d
+    qkv = q(rnd(12, b * n, 3 * c) * 0.8)
+    t = qkv.clone().requires_grad_(True)
+    x = t.view(b, n, 3, heads, d).permute(2, 0, 3, 1, 4)
+    qq, kk, vv = torch.unbind(x, dim=0)
+    attn = ((qq @ kk.transpose(-2, -1)) * d**-0.5).softmax(dim=-1)
+    o = (attn @ vv).transpose(1, 2).reshape(b * n, c)
+    do = q(rnd(13, b * n, c))
+    o.backward(do)
+    got = V.attention_fwd(qkv.cuda().to(BF), b, n, heads)
+    close_bf16(got, o.detach(), 'attention fwd', extra=6e-3)   # + bf16 rounding of S and P inside
+    dqkv = V.attention_bwd(qkv.cuda().to(BF), do.cuda().to(BF), b, n, heads)
+    ref = t.grad
+    err = float((dqkv.float().cpu() - ref).norm() / ref.norm())
+    assert err <= 1.5e-2, err                                   # rel-L2 with bf16 S / P / dP / dS inside
+
+
+@pytest.mark.parametrize('name', ['tiny', 'base_d2', 'base'])
+def test_mae_step_against_reference(golden_dir, name):
+    from sacv_amd.masked_image_modeling import models, losses
+    meta = json.load(open(os.path.join(golden_dir, 'mae.json')))[name]
+    arrs = np.load(os.path.join(golden_dir, 'mae.npz'))
+    cfg, B = meta['cfg'], meta['B']
+    images = mae_inputs(cfg, B)
+    labels = omae.patch_labels(images, cfg['patch'], norm=True)
+    net = models.VITMAEPretrainModel(patch_size=cfg['patch'], image_size=cfg['image'], mask_ratio=0.75,
+                                     encoder_embedding_planes=cfg['E'], encoder_block_nums=cfg['Le'],
+                                     encoder_head_nums=cfg['He'], decoder_embedding_planes=cfg['D'],
+                                     decoder_block_nums=cfg['Ld'], decoder_head_nums=cfg['Hd'])
+    net.load_state_dict(omae.init_mae_state(0, cfg), strict=True)
+    net = net.cuda().train()
+    crit = losses.__dict__['MSELoss']()
+    net.set_noise(torch.tensor(arrs[f'{name}_noise']).cuda())
+    out, mask = net(images.cuda())
+    assert tuple(out.shape) == (B, (cfg['image'] // cfg['patch'])**2, cfg['patch']**2 * 3)
+    assert np.array_equal(mask.cpu().numpy(), arrs[f'{name}_mask'])
+    loss = crit(out, labels.cuda(), mask)
+    l32, lbf = meta['loss_fp32'], meta['loss_bf16']
+    print(f'{name}: loss gpu-bf16 {float(loss):.6f} ref-bf16 {lbf:.6f} ref-fp32 {l32:.6f}')
+    assert abs(float(loss) - l32) <= max(2e-3, 3 * abs(lbf - l32)) * max(1.0, l32)
+    p32, pbf = arrs[f'{name}_pred_fp32'], arrs[f'{name}_pred_bf16']
+    got = out.detach().float().cpu().numpy().reshape(-1)[::211]
+    err, ref_err = np.abs(got - p32).max() / np.abs(p32).max(), np.abs(pbf - p32).max() / np.abs(p32).max()
+    print(f'  pred vs fp32: gpu-bf16 {err:.3e}, reference-bf16 {ref_err:.3e}')
+    assert err <= max(2e-2, 2.5 * ref_err)
+    loss.backward()
+    rel_g, rel_r = [], []
+    for k, p in net.named_parameters():
+        if not p.requires_grad:
+            continue
+        n32 = meta['grad_norm_fp32'][k]
+        rel_g.append(abs(float(p.grad.double().norm()) - n32) / (n32 + 1e-12))
+        rel_r.append(abs(meta['grad_norm_bf16'][k] - n32) / (n32 + 1e-12))
+    print(f'  grad norms vs fp32: gpu-bf16 median {np.median(rel_g):.3e} max {max(rel_g):.3e}; '
+          f'reference-bf16 median {np.median(rel_r):.3e} max {max(rel_r):.3e}')
+    assert float(np.median(rel_g)) <= max(2e-2, 2.5 * float(np.median(rel_r)))
+    assert max(rel_g) <= max(0.15, 2.5 * max(rel_r))
+    for k in ('encoder.cls_token', 'decoder.mask_token', 'encoder.norm.weight', 'decoder.fc.bias',
+              'encoder.blocks.0.attn.qkv.bias', 'encoder.patch_embed.proj.bias'):
+        want = arrs[f'{name}_grad_{k}'].astype(np.float64)
+        gotg = dict(net.named_parameters())[k].grad.detach().cpu().numpy().astype(np.float64).reshape(want.shape)
+        l2 = np.linalg.norm(gotg - want) / (np.linalg.norm(want) + 1e-30)
+        assert l2 <= 6e-2, (k, l2)
+
+
+def test_mae_trainer_recipe_batch():
+    """128 images per GPU (the recipe's 1024 over 8 GPUs) of ViT-B/16 MAE: three AdamW steps at a linear-regime rate
+    lower the loss; fp32 master weights move; the frozen position tables do not."""
+    from sacv_amd.masked_image_modeling import models, losses
+    from sacv_amd.train import MAETrainer
+    net = models.__dict__['vit_base_patch16_224_mae_pretrain_model']()
+    cfg = dict(patch=16, image=224, E=768, Le=12, He=12, D=512, Ld=8, Hd=16)
+    net.load_state_dict(omae.init_mae_state(0, cfg), strict=True)
+    net = net.cuda().train()
+    tr = MAETrainer(net, losses.__dict__['MSELoss'](), lr=1e-4)
+    x = (torch.cat([torch.tensor(synth.images(400 + i, 32, 224, 224)) for i in range(4)]) * 4 - 2).cuda()
+    pos0 = net.encoder.pos_embed.clone()
+    p0 = net.arena.params.clone()
+    noise = torch.tensor(synth.uniform(5, (128, 196))).cuda()
+    ls = [tr.finish_step(tr.step(x, noise=noise))['loss'] for _ in range(3)]
+    print('MAE bs128 losses', ls)
+    assert all(np.isfinite(ls)) and ls[2] < ls[0]
+    assert torch.equal(net.encoder.pos_embed, pos0) and float((net.arena.params - p0).abs().max()) > 0
+    assert len(tr.param_groups[0]['param_names']) + len(tr.param_groups[1]['param_names']) == \
+        sum(1 for p in net.parameters() if p.requires_grad)

@@ -29,10 +29,13 @@ def cpu_baseline(warmup=3, steps=5):
     import statistics
     import torch
     from oracle import losses as olosses, model as omodel, synth
-    try:  # every core this process may run on (a 1-GPU box hands out a share of the host: 16)
+    try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    # a 1-GPU box is a 16-core SHARE of a large host: the affinity mask shows every host core, but threads beyond the
+    # share only time-slice against the other tenants (192 threads here: >50 s per step instead of ~6)
+    cores = min(16, cores)
     torch.set_num_threads(cores)
     sd = omodel.init_retinanet_state(0)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
@@ -205,13 +208,86 @@ def bench_classification(args, rank, world, group, ops, synth):
         dist.destroy_process_group()
 
 
+def bench_mae(args, rank, world, group, ops, synth):
+    """Secondary workload (BASELINE config #5): ViT-B/16 MAE pre-training step of
+    2.masked_image_modeling_training/imagenet/mae_vit_base_patch16_224/train_config.py -- total batch 1024 over 8 GPUs =
+    128 images/GPU, 224x224, mask ratio 0.75, MSELoss on per-patch-normalised pixels, AdamW(6e-4, (0.9, 0.95), wd 0.05),
+    autocast: bf16 matrix-core GEMMs, fp32 residual stream / statistics / master weights."""
+    import torch
+    import torch.distributed as dist
+    from sacv_amd.masked_image_modeling import models, losses
+    from sacv_amd.train import MAETrainer
+    MB, R = 128, 224
+    net = models.__dict__['vit_base_patch16_224_mae_pretrain_model']().cuda().train()
+    trainer = MAETrainer(net, losses.__dict__['MSELoss'](), lr=6e-4, betas=(0.9, 0.95), weight_decay=5e-2,
+                         process_group=group)
+    images = (torch.cat([torch.tensor(synth.images(rank * 64 + i, MB // 8, R, R)) for i in range(8)]) * 4 - 2).cuda()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = trainer.step(images)
+    timer = None
+    if not args.no_kernel_timer:
+        timer = ops.TIMER = ops.KernelTimer()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(images)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.TIMER = None
+    loss = trainer.finish_step(out)
+    if world > 1:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    roofline = None
+    if timer is not None:
+        agg = timer.summary()
+        k = dict(launches=0, flops=0.0, ms=0.0, bytes=0.0)
+        for name, v in agg.items():
+            if name.startswith('conv_nt_bf16') or name.startswith('conv_tn_bf16'):
+                for f_ in k:
+                    k[f_] += v[f_]
+        if k['launches']:
+            tf = k['flops'] / (k['ms'] * 1e-3) / 1e12
+            roofline = dict(kernel='conv_nt_bf16 / conv_tn_bf16 as Linear GEMMs (bf16 MFMA 32x32x16: forward, data and '
+                                   'weight gradients of patch-embed / qkv / proj / fc1 / fc2 / pred)',
+                            bound='mfma', achieved=round(tf, 1), peak=2500.0, unit='TFLOP/s', frac=round(tf / 2500.0, 4),
+                            traffic=None, launches_per_step=k['launches'] // args.steps,
+                            share_of_step_ms=round(k['ms'] / args.steps, 2),
+                            algorithmic_gbs=round(k['bytes'] / (k['ms'] * 1e-3) / 1e9, 1))
+        if args.class_table and rank == 0:
+            with open(args.class_table, 'w') as f:
+                json.dump(dict(model='vit_mae', dtype='bf16', batch=MB, steps=args.steps, peak_tflops_bf16_mfma=2500.0,
+                               peak_hbm_gbs=PEAK_HBM_GBS, classes=class_table(agg, args.steps)), f, indent=1)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'images/sec/node ViT-B/16 MAE pre-training 224x224 bs=128/GPU (secondary, SURVEY 8f-4)',
+            'value': round(world * MB * args.steps / elapsed, 2), 'unit': 'images/sec', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'ViT-B/16 MAE pre-training step (random masking 0.75, encoder 12x768 on 50 tokens, '
+                                   'decoder 8x512 on 197 tokens, masked MSE on normalised patches, bwd, grad all-reduce, '
+                                   'AdamW), images [128,3,224,224]/GPU, random init, autocast dtypes',
+                       'global_batch': world * MB, 'parallelism': f'dp{world}'},
+            'loss': loss, 'roofline': roofline}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--model', default='retinanet', choices=['retinanet', 'fcos', 'resnet50_cls'],
+    ap.add_argument('--model', default='retinanet', choices=['retinanet', 'fcos', 'resnet50_cls', 'vit_mae'],
                     help='retinanet = the headline metric; fcos = secondary workload (BASELINE config 4); '
                          'resnet50_cls = ResNet50 ImageNet classification, bs 256/GPU, 224x224 (SURVEY.md 8f-1)')
     ap.add_argument('--no-kernel-timer', action='store_true')
@@ -224,8 +300,11 @@ def main():
                     help='bf16: the autocast recipe of resnet50_cls (BASELINE config #2); the detection recipes run '
                          'fp32 (use_amp=False in their train_config.py)')
     args = ap.parse_args()
-    if args.dtype == 'bf16' and args.model != 'resnet50_cls':
-        raise SystemExit('--dtype bf16 is the resnet50_cls recipe; the detection recipes are fp32 (use_amp=False)')
+    if args.model == 'vit_mae':
+        args.dtype = 'bf16'  # the MAE recipe runs under autocast (use_amp=True); there is no fp32 engine for it
+    if args.dtype == 'bf16' and args.model not in ('resnet50_cls', 'vit_mae'):
+        raise SystemExit('--dtype bf16 is the resnet50_cls / vit_mae recipe; the detection recipes are fp32 '
+                         '(use_amp=False)')
 
     global H, W
     H, W = (int(v) for v in args.image_size.lower().split('x'))
@@ -265,6 +344,8 @@ def main():
     torch.manual_seed(0)
     if args.model == 'resnet50_cls':
         return bench_classification(args, rank, world, group, ops, synth)
+    if args.model == 'vit_mae':
+        return bench_mae(args, rank, world, group, ops, synth)
     if args.model == 'fcos':
         net = models.__dict__['resnet50_fcos'](backbone_pretrained_path='', num_classes=80).cuda().train()
         crit = losses.__dict__['FCOSLoss']()

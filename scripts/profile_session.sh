@@ -7,13 +7,13 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-echo "[1] headline bench (un-profiled, CPU baseline, per-class table)"
+echo "[1] headline bench (un-profiled, CPU baseline, per-class table)"; date
 python3 bench.py --steps 20 --warmup 5 --class-table $OUT/classes_retina.json > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json; echo
-echo "[2] kernel trace of the headline bench"
+date; echo "[2] kernel trace of the headline bench"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/kt.log 2>&1
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
-echo "[3] PMC passes (separate runs): FETCH_SIZE, WRITE_SIZE, MFMA busy"
+date; echo "[3] PMC passes (separate runs): FETCH_SIZE, WRITE_SIZE, MFMA busy"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer > $OUT/pmc_fetch.log 2>&1
 cp $(find $OUT/pmc_fetch -name "*counter_collection.csv" | head -1) $OUT/pmc_fetch.csv
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer > $OUT/pmc_write.log 2>&1
@@ -21,7 +21,7 @@ cp $(find $OUT/pmc_write -name "*counter_collection.csv" | head -1) $OUT/pmc_wri
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_mfma -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer > $OUT/pmc_mfma.log 2>&1
 cp $(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1) $OUT/pmc_mfma.csv
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/kt
-echo "[4] secondary lines: FCOS, S2, classification fp32 / bf16"
+date; echo "[4] secondary lines: FCOS, S2, classification fp32 / bf16"
 python3 bench.py --model fcos --steps 20 --warmup 5 --no-cpu-baseline --class-table $OUT/classes_fcos.json | tail -1 > $OUT/fcos.json
 python3 bench.py --image-size 1333x1333 --steps 10 --warmup 3 --no-cpu-baseline | tail -1 > $OUT/s2.json
 python3 bench.py --model resnet50_cls --steps 10 --warmup 3 | tail -1 > $OUT/cls_f32.json

@@ -52,9 +52,9 @@ def resnet50_bn_layers(B, H, W):
     return layers
 
 
-def hbm_table(stats_by_name, steps, B, H, W, extra):
+def hbm_table(stats_by_name, steps, B, H, W, extra, elem_bytes=4):
     L = resnet50_bn_layers(B, H, W)
-    gb = lambda f: sum(f(e, relu, res) for e, relu, res in L) * 4 / 1e9
+    gb = lambda f: sum(f(e, relu, res) for e, relu, res in L) * elem_bytes / 1e9
     rows = [
         ('bn_apply_kernel', gb(lambda e, r, s: e * (3 if s else 2)), 'read y, write z (+ the residual input of the 16 block outputs)'),
         ('bn_bwd_partial_kernel', gb(lambda e, r, s: e * (3 if s else 2)), 'read dz, y (+ z where the ReLU follows a residual add; elsewhere the mask is recomputed from y)'),
@@ -62,7 +62,7 @@ def hbm_table(stats_by_name, steps, B, H, W, extra):
     ] + extra
     out = []
     for name, g, what in rows:
-        hit = [v for k, v in stats_by_name.items() if k.startswith(name)]
+        hit = [v for k, v in stats_by_name.items() if name in k]  # templated kernels: 'void bn_apply_kernel<float>(...'
         if not hit:
             continue
         ms = sum(h[1] for h in hit) / steps / 1e6
@@ -159,20 +159,25 @@ def main():
         crow = read_stats(sys.argv[6])
         cb = json.loads([l for l in open(sys.argv[7]) if l.startswith('{')][-1])
         cby = {r[0]: (r[1], r[2]) for r in crow}
+        half = cb.get('dtype') == 'bf16'
         with open(os.path.join(prof, f'{tag}_cls_kernel_stats.csv'), 'w') as f:
             f.write(open(sys.argv[6]).read())
         json.dump(cb, open(os.path.join(prof, f'{tag}_cls_bench.json'), 'w'))
         ctot = sum(r[2] for r in crow) / steps / 1e6
-        md += ['', '## Secondary workload: ResNet50 ImageNet classification, bs 256, 224x224, fp32 (SURVEY 8f-1)', '',
-               f'`bench.py --model resnet50_cls`: {cb["value"]} images/s, {cb["ms_per_step"]} ms/step (un-profiled; `{tag}_cls_bench.json`); '
-               f'kernel time {ctot:.2f} ms/step (`{tag}_cls_kernel_stats.csv`). conv_nt family {cb["roofline"]["achieved"]} TFLOP/s '
-               f'({cb["roofline"]["frac"]} of the fp32 MFMA peak).', '',
+        rf = cb['roofline']
+        md += ['', f'## Secondary workload: ResNet50 ImageNet classification, bs 256, 224x224, {cb.get("dtype", "f32")} (SURVEY 8f-1)', '',
+               f'`bench.py --model resnet50_cls{" --dtype bf16" if half else ""}`: {cb["value"]} images/s, {cb["ms_per_step"]} ms/step '
+               f'(un-profiled; `{tag}_cls_bench.json`); kernel time {ctot:.2f} ms/step (`{tag}_cls_kernel_stats.csv`). '
+               f'conv_nt family: {rf["achieved"]} {rf["unit"]} = {rf["frac"]} of the {rf["bound"]} peak {rf["peak"]}'
+               + (f' (matrix cores at {rf.get("matrix_tflops")} TFLOP/s; layer1 3x3: {rf.get("layer1_3x3")})' if half else '') + '.', '',
                '| kernel | calls/step | ms/step | avg us | % |', '|---|---|---|---|---|']
-        for name, calls, tot, avg, pct in crow[:14]:
+        for name, calls, tot, avg, pct in crow[:16]:
             md.append(f'| `{name[:60]}` | {calls / steps:.1f} | {tot / steps / 1e6:.3f} | {avg / 1e3:.1f} | {pct:.2f} |')
         md += ['', '| kernel | algorithmic GB/step | ms/step | achieved TB/s | frac of 8 TB/s | bytes counted |', '|---|---|---|---|---|---|']
+        eb = 2 if half else 4
+        kp = 192 if half else 160
         md += hbm_table(cby, steps, 256, 224, 224, [
-            ('im2col_stem_kernel', (256 * 3 * 224 * 224 + 256 * 112 * 112 * 160) * 4 / 1e9, 'read image, write im2col matrix')])
+            ('im2col_stem', (256 * 3 * 224 * 224 * 4 + 256 * 112 * 112 * kp * eb) / 1e9, 'read image (fp32), write im2col matrix')], eb)
     open(os.path.join(prof, f'{tag}_summary.md'), 'w').write('\n'.join(md) + '\n')
     print('\n'.join(md[:20]))
 

@@ -334,6 +334,14 @@ int sacv_colsum_bf16(const void* x, float* out, int R, int C, int accumulate, fl
 int sacv_attention_fwd(const void* qkv, void* out, int B, int n, int H, int d, float scale, void* stream);
 int sacv_attention_bwd(const void* qkv, const void* dout, void* dqkv, int B, int n, int H, int d, float scale,
                        void* stream);
+/* the same block on the bf16 matrix cores (csrc/attention.hip: S^T = K Q^T, the probability tile in the accumulator
+ * registers is the next MFMA's operand; two-phase deterministic backward from the saved log-sum-exp lse [B][H][n]);
+ * covers head dims 32 / 64 and up to 224 tokens -- the VALU kernels above are the general form */
+int sacv_attention_mfma_supported(int n, int d);
+int sacv_attention_fwd_mfma(const void* qkv, void* out, float* lse, int B, int n, int H, int d, float scale,
+                            void* stream);
+int sacv_attention_bwd_mfma(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B,
+                            int n, int H, int d, float scale, void* stream);
 long long sacv_mae_mse_workspace_floats(int B, int n);
 /* MSELoss(pred[:, 1:], label, mask) (losses.py:11-23); pred bf16 [B][n+1][K] (row 0 = cls token, dropped),
  * label fp32 [B][n][K], mask fp32 [B][n]; dpred (nullable) bf16 = d loss / d pred * grad_scale */

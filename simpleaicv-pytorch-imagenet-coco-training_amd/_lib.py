@@ -96,6 +96,9 @@ SIGNATURES = {
     'sacv_colsum_bf16': (I, [P, P, I, I, I, P, P]),
     'sacv_attention_fwd': (I, [P, P, I, I, I, I, F, P]),
     'sacv_attention_bwd': (I, [P, P, P, I, I, I, I, F, P]),
+    'sacv_attention_mfma_supported': (I, [I, I]),
+    'sacv_attention_fwd_mfma': (I, [P, P, P, I, I, I, I, F, P]),
+    'sacv_attention_bwd_mfma': (I, [P, P, P, P, P, I, I, I, I, F, P]),
     'sacv_mae_mse_workspace_floats': (LL, [I, I]),
     'sacv_mae_mse_loss': (I, [P, P, P, P, P, I, I, I, F, P, P]),
     'sacv_comm_unique_id_bytes': (I, []),

@@ -442,16 +442,23 @@ __device__ __forceinline__ void lds_gemm(float* C, int ldc, const float* A, int 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    for (int k = 0; k < K; ++k) {
-      float a[4], b[4];
+    // K % 4 == 0 (head dim, ATT_QC and the padded sequence length are multiples of 4): four k steps of LDS reads are
+    // in flight before their FMAs -- with one or two waves per SIMD the loop is bound by LDS latency, not bandwidth
+    for (int k0 = 0; k0 < K; k0 += 4) {
+      float a[4][4], b[4][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = A[(m0 + i) * am + k * ak];
+      for (int u = 0; u < 4; ++u) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = B[k * bk + (c + j * tn) * bn];
+        for (int i = 0; i < 4; ++i) a[u][i] = A[(m0 + i) * am + (k0 + u) * ak];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) b[u][j] = B[(k0 + u) * bk + (c + j * tn) * bn];
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] += a[u][i] * b[u][j];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -506,7 +513,7 @@ __device__ __forceinline__ void att_softmax_rows(float* S, int ld, int rows, int
   }
 }
 
-__global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int n,
+__global__ __launch_bounds__(512) void attention_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out, int n,
                                                              int H, int d, float scale) {
   extern __shared__ float sm[];
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -555,7 +562,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(const bf16* __restri
 // backward of the same block: recomputes S / P per query chunk; dqkv bf16 [B][n][3][H][d]
 //   dV = bf16(P_b^T dO); dP = bf16(dO V^T); dS = P (dP - sum_k dP P) (fp32 softmax backward); d(QK^T) = bf16(bf16(dS) *
 //   scale); dQ = bf16(d(QK^T) K); dK = bf16(d(QK^T)^T Q)
-__global__ __launch_bounds__(256) void attention_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+__global__ __launch_bounds__(512) void attention_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                              bf16* __restrict__ dqkv, int n, int H, int d, float scale) {
   extern __shared__ float sm[];
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -594,7 +601,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(const bf16* __restri
     // softmax backward needs the fp32 P and dP: dS = P * (dP - rowsum(dP * P))
     {
       const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-      for (int r = w; r < ATT_QC; r += 4) {
+      for (int r = w; r < ATT_QC; r += (int)(blockDim.x >> 6)) {
         float* p = Ps + r * lds;
         float* g = Gs + r * lds;
         float dot = 0.f;
@@ -852,7 +859,7 @@ int sacv_attention_fwd(const void* qkv, void* out, int B, int n, int H, int d, f
   SACV_CHECK_ARG(lds <= 160 * 1024, "attention_fwd: sequence %d x head dim %d does not fit the LDS", n, d);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_fwd_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const bf16*)qkv,
+  hipLaunchKernelGGL(attention_fwd_kernel, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
                      (bf16*)out, n, H, d, scale);
   SACV_CHECK_LAUNCH("attention_fwd");
   return SACV_OK;
@@ -865,7 +872,7 @@ int sacv_attention_bwd(const void* qkv, const void* dout, void* dqkv, int B, int
   SACV_CHECK_ARG(lds <= 160 * 1024, "attention_bwd: sequence %d x head dim %d does not fit the LDS", n, d);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(256), lds, (hipStream_t)stream, (const bf16*)qkv,
+  hipLaunchKernelGGL(attention_bwd_kernel, dim3(B * H), dim3(512), lds, (hipStream_t)stream, (const bf16*)qkv,
                      (const bf16*)dout, (bf16*)dqkv, n, H, d, scale);
   SACV_CHECK_LAUNCH("attention_bwd");
   return SACV_OK;

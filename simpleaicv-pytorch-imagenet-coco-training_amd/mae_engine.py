@@ -14,7 +14,7 @@ LN_EPS = 1e-6
 
 
 class _Block:
-    __slots__ = ('x0', 'm1', 'r1', 'h', 'qkv', 'a', 'x1', 'm2', 'r2', 'h2', 'f', 'g')
+    __slots__ = ('x0', 'm1', 'r1', 'h', 'qkv', 'a', 'lse', 'x1', 'm2', 'r2', 'h2', 'f', 'g')
 
 
 class MAEEngine:
@@ -51,7 +51,7 @@ class MAEEngine:
         s = _Block() if keep else None
         h, m1, r1 = V.layernorm_fwd(x, p[pre + '.norm1.weight'], p[pre + '.norm1.bias'], LN_EPS)
         qkv = V.linear_fwd(h, self._wf(pre + '.attn.qkv.weight'), p[pre + '.attn.qkv.bias'])
-        a = V.attention_fwd(qkv, b, n, heads)
+        a, lse = V.attention_fwd(qkv, b, n, heads)
         x1 = x.clone()
         V.linear_fwd(a, self._wf(pre + '.attn.proj.weight'), p[pre + '.attn.proj.bias'], out=x1, accumulate=True,
                      out_f32=True)
@@ -62,7 +62,7 @@ class MAEEngine:
         V.linear_fwd(gl, self._wf(pre + '.mlp.fc2.weight'), p[pre + '.mlp.fc2.bias'], out=x2, accumulate=True,
                      out_f32=True)
         if keep:
-            s.x0, s.m1, s.r1, s.h, s.qkv, s.a = x, m1, r1, h, qkv, a
+            s.x0, s.m1, s.r1, s.h, s.qkv, s.a, s.lse = x, m1, r1, h, qkv, a, lse
             s.x1, s.m2, s.r2, s.h2, s.f, s.g = x1, m2, r2, h2, f, gl
         return x2, s
 
@@ -81,7 +81,7 @@ class MAEEngine:
         dxb = ops.cast_bf16(dx)
         V.linear_wgrad(dxb, s.a, g[pre + '.attn.proj.weight'], g[pre + '.attn.proj.bias'])
         da = V.linear_dgrad(dxb, self._wd(pre + '.attn.proj.weight'), c)
-        dqkv = V.attention_bwd(s.qkv, da, b, n, heads)
+        dqkv = V.attention_bwd(s.qkv, s.a, da, s.lse, b, n, heads)
         V.linear_wgrad(dqkv, s.h, g[pre + '.attn.qkv.weight'], g[pre + '.attn.qkv.bias'])
         dh = V.linear_dgrad(dqkv, self._wd(pre + '.attn.qkv.weight'), c)
         V.layernorm_bwd(dh, s.x0, s.m1, s.r1, p[pre + '.norm1.weight'], g[pre + '.norm1.weight'],

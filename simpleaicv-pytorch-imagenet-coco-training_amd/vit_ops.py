@@ -123,22 +123,36 @@ def colsum_bf16(x, out, accumulate=False):
     return out
 
 
-def attention_fwd(qkv, b, n, heads):
-    """qkv bf16 [B*n, 3*C] (= [B][n][3][H][d]) -> bf16 [B*n, C]."""
+def attention_fwd(qkv, b, n, heads, mfma=None):
+    """qkv bf16 [B*n, 3*C] (= [B][n][3][H][d]) -> (out bf16 [B*n, C], lse fp32 [B,H,n] or None).
+    mfma: None = the matrix-core kernel whenever it covers (n, d); False = the general VALU kernel."""
     c = qkv.shape[1] // 3
     d = c // heads
     out = torch.empty((b * n, c), device=qkv.device, dtype=BF16)
-    check(lib.sacv_attention_fwd(_ptr(_chk(qkv, 'qkv', BF16)), _ptr(out), b, n, heads, d, float(d)**-0.5, _stream()),
-          'attention_fwd')
-    return out
+    _chk(qkv, 'qkv', BF16)
+    if mfma is None:
+        mfma = bool(lib.sacv_attention_mfma_supported(n, d))
+    if mfma:
+        lse = torch.empty((b, heads, n), device=qkv.device, dtype=torch.float32)
+        check(lib.sacv_attention_fwd_mfma(_ptr(qkv), _ptr(out), _ptr(lse), b, n, heads, d, float(d)**-0.5, _stream()),
+              'attention_fwd_mfma')
+        return out, lse
+    check(lib.sacv_attention_fwd(_ptr(qkv), _ptr(out), b, n, heads, d, float(d)**-0.5, _stream()), 'attention_fwd')
+    return out, None
 
 
-def attention_bwd(qkv, dout, b, n, heads):
+def attention_bwd(qkv, out, dout, lse, b, n, heads):
+    """lse None: the VALU kernel (recomputes the softmax itself); else the matrix-core kernel."""
     c = qkv.shape[1] // 3
     d = c // heads
     dqkv = torch.empty_like(qkv)
-    check(lib.sacv_attention_bwd(_ptr(qkv), _ptr(_chk(dout, 'dout', BF16)), _ptr(dqkv), b, n, heads, d, float(d)**-0.5,
-                                 _stream()), 'attention_bwd')
+    _chk(dout, 'dout', BF16)
+    if lse is not None:
+        check(lib.sacv_attention_bwd_mfma(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), b, n, heads, d,
+                                          float(d)**-0.5, _stream()), 'attention_bwd_mfma')
+    else:
+        check(lib.sacv_attention_bwd(_ptr(qkv), _ptr(dout), _ptr(dqkv), b, n, heads, d, float(d)**-0.5, _stream()),
+              'attention_bwd')
     return dqkv
 
 

@@ -46,7 +46,8 @@ def test_random_masking_indices_bit_exact(golden_dir):
         assert np.array_equal(restore.cpu().numpy(), arrs[f'{name}_restore'])       # the reference encoder's own ids
         assert np.array_equal(mask.cpu().numpy(), arrs[f'{name}_mask'])
         assert torch.equal(shuffle.cpu(), torch.argsort(noise, dim=1)) and torch.equal(keep_ids, shuffle[:, :keep])
-    noise = torch.rand(37, 1000)
+    # distinct values per row (ties are unpinned: torch.argsort is not stable; torch.rand has only 2^24 values)
+    noise = torch.stack([(torch.randperm(1000).float() + 0.5) / 1000 for _ in range(37)])
     s, r, k, m = V.random_masking(noise.cuda(), 250)
     assert torch.equal(s.cpu(), torch.argsort(noise, dim=1)) and torch.equal(r.cpu(), torch.argsort(s.cpu(), dim=1))
 
@@ -109,22 +110,28 @@ def test_patch_layernorm_gelu_tokens_loss_kernels():
     close_bf16(dpred.view(Bm, nm + 1, K), pr.grad, 'mse grad', extra=1e-5)
 
 
-@pytest.mark.parametrize('b,n,heads,d', [(2, 50, 12, 64), (2, 197, 16, 32), (3, 17, 4, 32)])
-def test_attention_core_fwd_bwd(b, n, heads, d):
-    """softmax(bf16(QK^T) * scale) V with autocast's rounding points against torch on the same bf16 inputs."""
+@pytest.mark.parametrize('mfma', [True, False])
+@pytest.mark.parametrize('b,n,heads,d', [(2, 50, 12, 64), (2, 197, 16, 32), (3, 17, 4, 32), (2, 33, 3, 64)])
+def test_attention_core_fwd_bwd(b, n, heads, d, mfma):
+    """softmax(bf16(QK^T) * scale) V with autocast's rounding points against torch on the same bf16 inputs: the matrix-core
+    kernels (csrc/attention.hip) and the general VALU kernels (csrc/vit.hip)."""
     from sacv_amd import vit_ops as V
     c = heads * d
     qkv = q(rnd(12, b * n, 3 * c) * 0.8)
     t = qkv.clone().requires_grad_(True)
     x = t.view(b, n, 3, heads, d).permute(2, 0, 3, 1, 4)
     qq, kk, vv = torch.unbind(x, dim=0)
-    attn = ((qq @ kk.transpose(-2, -1)) * d**-0.5).softmax(dim=-1)
+    sc = (qq @ kk.transpose(-2, -1)) * d**-0.5
+    attn = sc.softmax(dim=-1)
     o = (attn @ vv).transpose(1, 2).reshape(b * n, c)
     do = q(rnd(13, b * n, c))
     o.backward(do)
-    got = V.attention_fwd(qkv.cuda().to(BF), b, n, heads)
+    got, lse = V.attention_fwd(qkv.cuda().to(BF), b, n, heads, mfma=mfma)
+    assert (lse is not None) == mfma
     close_bf16(got, o.detach(), 'attention fwd', extra=6e-3)   # + bf16 rounding of S and P inside
-    dqkv = V.attention_bwd(qkv.cuda().to(BF), do.cuda().to(BF), b, n, heads)
+    if mfma:
+        torch.testing.assert_close(lse.cpu(), torch.logsumexp(sc.detach(), dim=-1), rtol=0, atol=2e-2)
+    dqkv = V.attention_bwd(qkv.cuda().to(BF), got, do.cuda().to(BF), lse, b, n, heads)
     ref = t.grad
     err = float((dqkv.float().cpu() - ref).norm() / ref.norm())
     assert err <= 1.5e-2, err                                   # rel-L2 with bf16 S / P / dP / dS inside

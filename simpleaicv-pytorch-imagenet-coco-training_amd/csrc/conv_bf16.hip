@@ -50,16 +50,11 @@ struct ConvArgsH {
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 
-#ifndef SACV_BF16_NT
-#define SACV_BF16_NT 512  // threads per workgroup of the bf16 conv kernel: 8 waves (4 x 2), 2 workgroups per CU
-#endif
-template <int BM, int BN, int MODE, int NT>
-__global__ __launch_bounds__(NT, NT / 128) void conv_nt_bf16_kernel(const ConvArgsH a) {
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_nt_bf16_kernel(const ConvArgsH a) {
   constexpr int LSB = 144;                      // LDS row stride in bytes: 64 bf16 + 16 bytes of padding
-  constexpr int RPP = NT / 8;                   // tile rows fetched per pass (8 threads x 16 B per row)
-  constexpr int RA = BM / RPP, RB = BN / RPP;   // 16-byte gathers per thread per K tile
-  constexpr int WM = NT / 128;                  // waves along M (x 2 along N)
-  constexpr int WTM = BM / WM, WTN = BN / 2;
+  constexpr int RA = BM / 32, RB = BN / 32;     // 16-byte gathers per thread per K tile
+  constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;
@@ -91,7 +86,7 @@ __global__ __launch_bounds__(NT, NT / 128) void conv_nt_bf16_kernel(const ConvAr
     bool wok[RB];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int m = m0 + r0 + RPP * i;
+      const int m = m0 + r0 + 32 * i;
       if (m < a.M) {
         const int hw = a.Hd * a.Wd;
         const int n = m / hw;
@@ -115,16 +110,13 @@ __global__ __launch_bounds__(NT, NT / 128) void conv_nt_bf16_kernel(const ConvAr
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      const int n = n0 + r0 + RPP * i;
+      const int n = n0 + r0 + 32 * i;
       wok[i] = n < a.N;
       wrow[i] = n * a.K + kq * 8;
     }
 
-    // TWO register staging sets: the gathers of K tile k+2 are issued while tile k is multiplied, so two tiles
-    // (2 x 32 KB per workgroup) are in flight -- with the ~1.5 us L2/HBM latency of a loaded chip one tile in flight
-    // kept the matrix cores at 14 % (Little's law: 64 KB per CU in flight = 18 B/clk, the L2 can deliver ~30)
-    u32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
-    auto load_tile = [&](int kt, u32x4 (&ra)[RA], u32x4 (&rb)[RB]) {
+    u32x4 ra[RA], rb[RB];
+    auto load_tile = [&](int kt) {
       const int tap = kt / cpt;
       const int c0 = (kt - tap * cpt) << 6;
       const int kh = tap / a.KW;
@@ -163,13 +155,13 @@ __global__ __launch_bounds__(NT, NT / 128) void conv_nt_bf16_kernel(const ConvAr
         rb[i] = ld16(ptr);
       }
     };
-    auto store_tile = [&](int buf, const u32x4 (&ra)[RA], const u32x4 (&rb)[RB]) {
+    auto store_tile = [&](int buf) {
       unsigned char* dA = sA + buf * BM * LSB + r0 * LSB + kq * 16;
       unsigned char* dB = sB + buf * BN * LSB + r0 * LSB + kq * 16;
 #pragma unroll
-      for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4*>(dA + RPP * i * LSB) = ra[i];
+      for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4*>(dA + 32 * i * LSB) = ra[i];
 #pragma unroll
-      for (int i = 0; i < RB; ++i) *reinterpret_cast<u32x4*>(dB + RPP * i * LSB) = rb[i];
+      for (int i = 0; i < RB; ++i) *reinterpret_cast<u32x4*>(dB + 32 * i * LSB) = rb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -180,9 +172,15 @@ __global__ __launch_bounds__(NT, NT / 128) void conv_nt_bf16_kernel(const ConvAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto compute = [&](int buf) {
-      const unsigned char* cA = sA + buf * BM * LSB + (wm0 + l31) * LSB + 16 * lh;
-      const unsigned char* cB = sB + buf * BN * LSB + (wn0 + l31) * LSB + 16 * lh;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+      const bool last = kt + 1 == KT;
+      if (!last) load_tile(kt + 1);
+      const unsigned char* cA = sA + cur * BM * LSB + (wm0 + l31) * LSB + 16 * lh;
+      const unsigned char* cB = sB + cur * BN * LSB + (wn0 + l31) * LSB + 16 * lh;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         bf16x8 fa[TM], fb[TN];
@@ -196,23 +194,9 @@ __global__ __launch_bounds__(NT, NT / 128) void conv_nt_bf16_kernel(const ConvAr
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
       }
-    };
-    load_tile(0, ra0, rb0);
-    if (KT > 1) load_tile(1, ra1, rb1);
-    store_tile(0, ra0, rb0);
-    __syncthreads();
-    for (int kt = 0; kt < KT; kt += 2) {
-      // even step: LDS buffer 0 holds tile kt; set 1 holds tile kt+1 (in flight); set 0 is free for tile kt+2
-      if (kt + 2 < KT) load_tile(kt + 2, ra0, rb0);
-      compute(0);
-      if (kt + 1 < KT) store_tile(1, ra1, rb1);
+      if (!last) store_tile(cur ^ 1);
       __syncthreads();
-      if (kt + 1 >= KT) break;
-      // odd step: buffer 1 holds tile kt+1; set 0 holds tile kt+2 (in flight); set 1 is free for tile kt+3
-      if (kt + 3 < KT) load_tile(kt + 3, ra1, rb1);
-      compute(1);
-      if (kt + 2 < KT) store_tile(0, ra0, rb0);
-      __syncthreads();
+      cur ^= 1;
     }
 
     // ---- epilogue: accumulators -> LDS [BM][BN+4] fp32 -> rows of 8 channels: + bias, (+ dst), round to the output
@@ -227,7 +211,7 @@ __global__ __launch_bounds__(NT, NT / 128) void conv_nt_bf16_kernel(const ConvAr
         for (int r = 0; r < 16; ++r)
           stage[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CS + wn0 + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
-    constexpr int CG = BN / 8, RS = NT / CG;
+    constexpr int CG = BN / 8, RS = 256 / CG;
     const int c8 = tid % CG, rr = tid / CG;
     const int n = n0 + c8 * 8;
     const bool nok = n < a.N;  // N % 8 == 0
@@ -298,7 +282,7 @@ __global__ __launch_bounds__(NT, NT / 128) void conv_nt_bf16_kernel(const ConvAr
         red[(size_t)(RS + rr) * BN + c8 * 8 + e] = ssq[e];
       }
       __syncthreads();
-      for (int c = tid; c < 2 * BN; c += NT) {
+      for (int c = tid; c < 2 * BN; c += 256) {
         const int which = c / BN, col = c - which * BN;
         float s = 0.f;
         for (int l = 0; l < RS; ++l) s += red[(size_t)(which * RS + l) * BN + col];
@@ -630,14 +614,14 @@ static int launch_nt_h(ConvArgsH& a, hipStream_t st) {
   if (lds_epi > lds) lds = lds_epi;
   static std::once_flag attr_once;
   std::call_once(attr_once, [lds] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_bf16_kernel<BM, BN, MODE, SACV_BF16_NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_bf16_kernel<BM, BN, MODE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   a.ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   int grid = num_cus_h() * 2;
   const int items = ((a.ntiles + 7) / 8) * 8;
   if (grid > items) grid = items;
-  hipLaunchKernelGGL((conv_nt_bf16_kernel<BM, BN, MODE, SACV_BF16_NT>), dim3(grid), dim3(SACV_BF16_NT), lds, st, a);
+  hipLaunchKernelGGL((conv_nt_bf16_kernel<BM, BN, MODE>), dim3(grid), dim3(256), lds, st, a);
   SACV_CHECK_LAUNCH("conv_nt_bf16_kernel");
   return SACV_OK;
 }

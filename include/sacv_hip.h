@@ -59,6 +59,27 @@ int sacv_conv2d_gemm(int nprob, const float* const* src /*host array*/, float* c
 long long sacv_conv2d_gemm_workspace_bytes(void);
 int sacv_conv2d_gemm_stats_rows(int nprob, const int* Nb, const int* Hd, const int* Wd);
 
+/* ---- Winograd F(2x2,3x3) path of the stride-1 3x3 head convolutions (head.py:20-36, 55-70, 103-141: nn.Conv2d
+ *      3x3 / pad 1 over the 5 pyramid levels).  Three steps: weights -> U (once per optimizer step), input -> V,
+ *      16 chained GEMMs + output transform + the sacv_conv2d_gemm epilogue in one kernel.  2.25x fewer
+ *      matrix-core flops than sacv_conv2d_gemm; same results up to fp32 rounding. ----------------------------- */
+/* tiles of 2x2 output pixels over the pyramid: sum_l Nb * ceil(H[l]/2) * ceil(W[l]/2) */
+int sacv_wino_tiles(int nlev, int Nb, const int* H, const int* W /*host arrays*/);
+/* U[16][N][K] = G w G^T from a GEMM panel [N][9][K] (forward panel; data-gradient panel with flip = 1) */
+int sacv_wino_weights(const float* panel, float* U, int N, int K, int flip, void* stream);
+/* V[16][Tpad][C] = B^T d B of every 4x4 input patch; Tpad = tiles rounded up to a multiple of 64 */
+int sacv_wino_input(int nlev, const float* const* src /*host array*/, int Nb, const int* H, const int* W, int C,
+                    float* V, int Tpad, void* stream);
+int sacv_wino_stats_rows(int tiles);
+/* nprob (1 or 2) independent convolutions over the same pyramid geometry (e.g. layer i of both head towers):
+ * dst[p*5 + l] = [Nb][H[l]][W[l]][N[p]]; flags[p] = SACV_CF_* bits; mask[p*5 + l] with SACV_CF_MASK;
+ * stats[p] = [sacv_wino_stats_rows][2][N[p]] with SACV_CF_STATS */
+int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, const float* const* V /*host array*/,
+                   const float* const* U /*host array*/, const int* Tpad, const int* K, const int* N,
+                   const float* const* bias /*host array or NULL*/, float* const* dst /*host array [nprob*5]*/,
+                   const float* const* mask /*host array [nprob*5] or NULL*/, float* const* stats /*host array or NULL*/,
+                   const int* flags, void* stream);
+
 long long sacv_conv2d_wgrad_workspace_bytes(int nseg, const int* Nb, const int* Ho, const int* Wo, int Cin_pad,
                                             int Cout, int KH, int KW, int chunk);
 

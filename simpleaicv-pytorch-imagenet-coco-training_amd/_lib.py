@@ -21,6 +21,11 @@ SIGNATURES = {
     'sacv_bn_finalize_stats': (I, [P, I, I, I, F, F, P, P, P, P, P, P]),
     'sacv_colsum_finalize': (I, [P, I, I, I, P, I, P]),
     'sacv_conv2d_gemm_workspace_bytes': (LL, []),
+    'sacv_wino_tiles': (I, [I, I, P, P]),
+    'sacv_wino_weights': (I, [P, P, I, I, I, P]),
+    'sacv_wino_input': (I, [I, P, I, P, P, I, P, I, P]),
+    'sacv_wino_stats_rows': (I, [I]),
+    'sacv_wino_gemm': (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     'sacv_conv2d_wgrad_workspace_bytes': (LL, [I, P, P, P, I, I, I, I, I]),
     'sacv_conv2d_wgrad': (I, [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     'sacv_pack_dgrad_batched': (I, [P, P, I, P]),

@@ -1,0 +1,737 @@
+// Winograd F(2x2, 3x3) path for the stride-1 3x3 convolutions of the detection heads (fp32, NHWC, gfx950).
+//
+// Y = A^T [ (G g G^T) .* (B^T d B) ] A per 2x2 output tile: 16 multiplies per output pair of pixels instead of 36,
+// i.e. 2.25x fewer matrix-core flops than the implicit GEMM of conv_gemm.hip.  The reference computes these layers
+// with nn.Conv2d (simpleAICV/detection/models/head.py:20-36, 55-70 RetinaClsHead/RetinaRegHead, :103-141 FCOS
+// towers); the transforms only use the coefficients 0, +-1, +-1/2, so the result differs from the direct fp32
+// sum by ordinary fp32 rounding (tests/test_gpu_winograd.py bounds it against the direct kernel and fp64).
+//
+//   wino_weight_kernel   U[g][n][k] = (G w[n] G^T)[g]        from a GEMM panel [N][9][K] (forward panel, or the
+//                                                             data-gradient panel with the taps flipped)
+//   wino_input_kernel    V[g][t][c] = (B^T d_t B)[g]          4x4 input patch of tile t (all levels of a head in one
+//                                                             launch; t runs over level, image, tile row, tile col)
+//   wino_gemm_kernel     M_g = V[g] U[g]^T for g = 0..15 back to back in ONE workgroup per (64 tiles x 128 channels)
+//                        item, each M_g folded into the four output accumulators Y[a][b] += A^T[a][i] A^T[b][j] M_g
+//                        (VALU adds once per g), so M never goes to memory and the inner loop sees one long K
+//                        (16 x Cin) with no epilogue in between; the epilogue writes the 2x2 pixels of every tile with
+//                        the fused bias / ReLU / sigmoid / accumulate / ReLU-mask / column-sum options of the direct
+//                        kernel (conv_gemm.hip vec_epilogue).
+//
+// Deterministic (no atomics, fixed summation order).
+#include "sacv_common.h"
+#include <mutex>
+
+#define WCF_BIAS 1
+#define WCF_RELU 2
+#define WCF_SIGMOID 4
+#define WCF_ACCUM 8
+#define WCF_MASK 16
+#define WCF_STATS 32
+
+#ifndef WINO_ABL
+#define WINO_ABL 0  // tuning builds only (scripts/): bit mask of ablations, never set in the shipped library
+#endif
+#define WINO_MAXL 5  // pyramid levels per problem
+#define WINO_MAXP 2  // problems (e.g. the two towers of a head) per GEMM launch
+
+static __device__ __attribute__((aligned(16))) float wino_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// -------------------------------------------------------------------------------------------- weights
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ panel, float* __restrict__ U,
+                                                          int N, int K, int Np, int Kp, int flip) {
+  const int k4n = Kp >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Np * k4n) return;
+  const int n = idx / k4n, k4 = idx - n * k4n;
+  const size_t gs = (size_t)Np * Kp;
+  float* o = U + (size_t)n * Kp + k4 * 4;
+  if (n >= N || k4 * 4 >= K) {  // zero padding: the GEMM reads whole 128 x 32 operand tiles without masks
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 16; ++g) *reinterpret_cast<f32x4*>(o + g * gs) = z;
+    return;
+  }
+  const float* p = panel + (size_t)n * 9 * K + k4 * 4;
+  f32x4 g[3][3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int tap = flip ? (2 - kh) * 3 + (2 - kw) : kh * 3 + kw;
+      g[kh][kw] = *reinterpret_cast<const f32x4*>(p + (size_t)tap * K);
+    }
+  f32x4 t[4][3];  // G g
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    t[0][kw] = g[0][kw];
+    t[1][kw] = 0.5f * (g[0][kw] + g[1][kw] + g[2][kw]);
+    t[2][kw] = 0.5f * (g[0][kw] - g[1][kw] + g[2][kw]);
+    t[3][kw] = g[2][kw];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 0) * gs) = t[i][0];
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 1) * gs) = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 2) * gs) = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 3) * gs) = t[i][2];
+  }
+}
+
+// -------------------------------------------------------------------------------------------- geometry
+struct WinoGeom {
+  int nlev;
+  int tile_begin[WINO_MAXL + 1];  // first tile row of each level; [nlev] = T
+  int th[WINO_MAXL], tw[WINO_MAXL], H[WINO_MAXL], W[WINO_MAXL];
+  int Nb;
+};
+
+struct WinoTile {
+  int lev, n, ty, tx;
+};
+__device__ __forceinline__ WinoTile wino_tile(const WinoGeom& g, int t) {
+  WinoTile r;
+  r.lev = 0;
+#pragma unroll
+  for (int l = 1; l < WINO_MAXL; ++l)
+    if (l < g.nlev && t >= g.tile_begin[l]) r.lev = l;
+  int tb = g.tile_begin[0], th = g.th[0], tw = g.tw[0];
+#pragma unroll
+  for (int l = 1; l < WINO_MAXL; ++l)
+    if (r.lev == l) {
+      tb = g.tile_begin[l];
+      th = g.th[l];
+      tw = g.tw[l];
+    }
+  const int local = t - tb;
+  const int per = th * tw;
+  r.n = local / per;
+  const int rem = local - r.n * per;
+  r.ty = rem / tw;
+  r.tx = rem - r.ty * tw;
+  return r;
+}
+
+// -------------------------------------------------------------------------------------------- input transform
+struct WinoInArgs {
+  WinoGeom g;
+  const float* src[WINO_MAXL];
+  float* V;
+  int C, Cp, T, Tpad;
+};
+
+__global__ __launch_bounds__(256) void wino_input_kernel(const WinoInArgs a) {
+  const int c4n = a.Cp >> 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)a.Tpad * c4n) return;
+  const int t = (int)(idx / c4n), c4 = (int)(idx - (long long)t * c4n);
+  const size_t gs = (size_t)a.Tpad * a.Cp;
+  float* o = a.V + (size_t)t * a.Cp + c4 * 4;
+  if (t >= a.T || c4 * 4 >= a.C) {  // padding rows / channels of the GEMM's 64 x 32 operand tiles: zeros
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 16; ++g) *reinterpret_cast<f32x4*>(o + g * gs) = z;
+    return;
+  }
+  const WinoTile tl = wino_tile(a.g, t);
+  const float* src = a.src[0];
+  int H = a.g.H[0], W = a.g.W[0];
+#pragma unroll
+  for (int l = 1; l < WINO_MAXL; ++l)
+    if (tl.lev == l) {
+      src = a.src[l];
+      H = a.g.H[l];
+      W = a.g.W[l];
+    }
+  const int h0 = 2 * tl.ty - 1, w0 = 2 * tl.tx - 1;
+  const float* base = src + (((long long)tl.n * H + h0) * W + w0) * a.C + c4 * 4;
+  f32x4 d[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bool ok = ((unsigned)(h0 + r) < (unsigned)H) & ((unsigned)(w0 + s) < (unsigned)W);
+      const float* p = ok ? base + ((long long)r * W + s) * a.C : wino_zero16;
+      d[r][s] = *reinterpret_cast<const f32x4*>(p);
+    }
+  f32x4 u[4][4];  // B^T d
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    u[0][s] = d[0][s] - d[2][s];
+    u[1][s] = d[1][s] + d[2][s];
+    u[2][s] = d[2][s] - d[1][s];
+    u[3][s] = d[1][s] - d[3][s];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 0) * gs) = u[i][0] - u[i][2];
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 1) * gs) = u[i][1] + u[i][2];
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 2) * gs) = u[i][2] - u[i][1];
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 3) * gs) = u[i][1] - u[i][3];
+  }
+}
+
+// one LDS-DMA wave-instruction: 64 lanes x 16 bytes, per-lane global source, lane-linear LDS destination.  The builtin
+// only exists for the gfx950 device pass (the host pass of the same translation unit must not see it).
+typedef __attribute__((address_space(3))) void* lds_t;
+__device__ __forceinline__ void glds16(const float* src, lds_t dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+#else
+  (void)src;
+  (void)dst;
+#endif
+}
+
+// -------------------------------------------------------------------------------------------- GEMM + output transform
+struct WinoProb {
+  WinoGeom g;
+  const float* V;     // [16][Tpad][K]
+  const float* U;     // [16][N][K]
+  const float* bias;  // [N] or null
+  float* stats;       // [mtiles][2][N] (WCF_STATS)
+  float* dst[WINO_MAXL];         // per level [Nb][H][W][N]
+  const float* mask[WINO_MAXL];  // per level, same shape as dst (WCF_MASK)
+  int T, Tpad, K, N, Np, flags;  // K: padded to 32; Np: rows of U (N padded to 128)
+  int item_begin, ntn;
+};
+
+struct WinoArgs {
+  WinoProb p[WINO_MAXP];
+  int nprob, total_items;
+};
+
+struct WinoRow {  // per tile row of the current item (LDS)
+  float* dst;
+  const float* mask;
+  int off;    // element offset of output pixel (2ty, 2tx), channel 0
+  int wn;     // W * N: element distance of one output row
+  int valid;  // bit 0: tile row < T, bit 1: pixel row 2ty+1 < H, bit 2: pixel column 2tx+1 < W
+  int pad;
+};
+
+// DMA = true: operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a ring of three unpadded,
+// XOR-swizzled stages with TWO tiles in flight (counted vmcnt + raw s_barrier); DMA = false: register staging into
+// two padded stages, one tile in flight (kept for A/B measurements).
+template <int BM, int BN, bool DMA>
+__global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs a) {
+  constexpr int LS = 36;
+  constexpr int STAGE = (BM + BN) * 32;  // floats per LDS-DMA stage (rows of 32 floats, no padding)
+  constexpr int OPER = DMA ? 3 * STAGE : 2 * (BM + BN) * LS;  // floats of operand buffers
+  constexpr int NT = 256;
+  constexpr int RPP = NT / 8;
+  constexpr int RA = BM / RPP, RB = BN / RPP;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM == 1, "one 32-row MFMA block per wave along M");
+  constexpr int CS = BN + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;
+  float* sB = smem + 2 * BM * LS;
+  WinoRow* rows = reinterpret_cast<WinoRow*>(smem + OPER);
+
+
+  // XCD-contiguous item order: workgroup b runs on XCD b % 8; every XCD takes a contiguous range of items so that the
+  // N tiles of one M tile (same V rows) meet in one L2
+  const int per = (a.total_items + 7) >> 3;
+  for (int it = blockIdx.x; it < per * 8; it += gridDim.x) {
+    const int item = (it & 7) * per + (it >> 3);
+    if (item >= a.total_items) continue;
+    // thread-index arithmetic is re-derived per item (and again before the epilogue) behind an opaque copy of the
+    // thread id: hoisted out of the persistent loop it occupied ~40 registers for the whole kernel, spilled, and the
+    // reloads (scratch loads count on vmcnt) drained the LDS-DMA pipeline in every K iteration
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wid = tid >> 6;
+    const int kq = tid & 7, r0 = tid >> 3;
+    const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
+    const int l31 = lane & 31, lh = lane >> 5;
+    (void)kq;
+    (void)r0;
+    const int pi = (a.nprob > 1 && item >= a.p[1].item_begin) ? 1 : 0;
+    const WinoProb& P = a.p[pi];
+    const int local = item - P.item_begin;
+    const int mt = local / P.ntn, nt = local - mt * P.ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int K = P.K, N = P.N;
+    const int KT = (K + 31) >> 5;
+    const size_t vgs = (size_t)P.Tpad * K, ugs = (size_t)P.Np * K;
+
+    __syncthreads();  // the previous item's epilogue has left the LDS
+    if (tid < BM) {
+      WinoRow r;
+      const int t = m0 + tid;
+      r.valid = 0;
+      r.dst = nullptr;
+      r.mask = nullptr;
+      r.off = 0;
+      r.wn = 0;
+      r.pad = 0;
+      if (t < P.T) {
+        const WinoTile tl = wino_tile(P.g, t);
+        int H = P.g.H[0], W = P.g.W[0];
+        r.dst = P.dst[0];
+        r.mask = P.mask[0];
+#pragma unroll
+        for (int l = 1; l < WINO_MAXL; ++l)
+          if (tl.lev == l) {
+            H = P.g.H[l];
+            W = P.g.W[l];
+            r.dst = P.dst[l];
+            r.mask = P.mask[l];
+          }
+        r.off = ((tl.n * H + 2 * tl.ty) * W + 2 * tl.tx) * N;
+        r.wn = W * N;
+        r.valid = 1 | ((2 * tl.ty + 1 < H) ? 2 : 0) | ((2 * tl.tx + 1 < W) ? 4 : 0);
+      }
+      rows[tid] = r;
+    }
+
+    f32x16 Y[4][TN], acc[TN];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Y[q][j][r] = 0.f;
+    // fold M_g into the output-pixel accumulators: Y[a][b] += AT[a][i] AT[b][j] M_g, AT = [[1,1,1,0],[0,1,-1,-1]]
+    auto fold = [&](int g) {
+      const int gi = g >> 2, gj = g & 3;
+      const int ca[2] = {gi < 3 ? 1 : 0, gi == 0 ? 0 : (gi == 1 ? 1 : -1)};
+      const int cb2[2] = {gj < 3 ? 1 : 0, gj == 0 ? 0 : (gj == 1 ? 1 : -1)};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = ca[q >> 1] * cb2[q & 1];
+        if (c > 0) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Y[q][j] += acc[j];
+        } else if (c < 0) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Y[q][j] -= acc[j];
+        }
+      }
+    };
+
+    if constexpr (DMA) {
+      // One LDS-DMA wave-instruction writes 64 lanes x 16 B = 1 KiB = 8 rows of 128 B, lane-linear; lane l fills
+      // (row l >> 3, 16-byte slot l & 7) and FETCHES logical chunk (l & 7) ^ (l >> 3) of that row, so slot p of row r
+      // holds chunk p ^ (r & 7): eight consecutive rows put a given logical chunk on eight different bank groups and the
+      // fragment reads below (32 rows x one chunk per half-wave) are conflict-free without padding.
+      constexpr int PA = BM / 32, PB = BN / 32;  // pieces per wave and tile (4 waves x 8 rows per piece)
+      const int prow = lane >> 3, sch = (lane & 7) ^ prow;
+      // element offsets of this lane's 16 bytes inside a (g, kc) operand tile; the operands are zero-padded to whole
+      // tiles (sacv_wino_pad_k / _pad_n), so every load is unconditional: scalar base + 32-bit lane offset
+      unsigned aoff[PA], wrow[PB];
+#pragma unroll
+      for (int i = 0; i < PA; ++i) aoff[i] = (unsigned)((m0 + (wid * PA + i) * 8 + prow) * K + sch * 4);
+#pragma unroll
+      for (int i = 0; i < PB; ++i) wrow[i] = (unsigned)((n0 + (wid * PB + i) * 8 + prow) * K + sch * 4);
+      auto issue = [&](int g, int kc, int st) {
+        const int c0 = kc << 5;
+        const float* v = P.V + (size_t)g * vgs + c0;
+        const float* u = P.U + (size_t)g * ugs + c0;
+        float* base = smem + st * STAGE;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) glds16(v + aoff[i], (lds_t)(base + (wid * PA + i) * 256));
+#pragma unroll
+        for (int i = 0; i < PB; ++i) glds16(u + wrow[i], (lds_t)(base + BM * 32 + (wid * PB + i) * 256));
+      };
+      constexpr int NG = PA + PB;  // LDS-DMA instructions per wave and tile
+      static_assert(NG == 6, "the counted waits below are written for 6 DMA instructions per tile");
+      const int total = 16 * KT;
+      const int x7 = l31 & 7;
+      issue(0, 0, 0);
+      {
+        int g1 = 0, k1 = 1;
+        if (k1 >= KT) { k1 = 0; g1 = 1; }
+        issue(g1, k1, 1);  // total >= 16
+      }
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      int cur = 0, q = 0;
+      int ng = 0, nk = 2;  // coordinates of tile q + 2
+      while (nk >= KT) { nk -= KT; ++ng; }
+      for (int g = 0; g < 16; ++g) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int kc = 0; kc < KT; ++kc, ++q) {
+          const bool more = q + 2 < total;
+          int st2 = cur + 2;
+          if (st2 >= 3) st2 -= 3;
+          if (more) issue(ng, nk, st2);
+          if (++nk >= KT) { nk = 0; ++ng; }
+          const float* cA = smem + cur * STAGE + (wm0 + l31) * 32;
+          const float* cB = smem + cur * STAGE + BM * 32 + (wn0 + l31) * 32;
+          f32x4 fa[2], fb[2][TN];
+          {
+            const int o = (lh ^ x7) * 4;
+            fa[0] = *reinterpret_cast<const f32x4*>(cA + o);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * 32 + o);
+          }
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int cb = jj & 1, nbuf = cb ^ 1;
+            if (jj < 3) {
+              const int o = (((jj + 1) * 2 + lh) ^ x7) * 4;
+              fa[nbuf] = *reinterpret_cast<const f32x4*>(cA + o);
+#pragma unroll
+              for (int j = 0; j < TN; ++j) fb[nbuf][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * 32 + o);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][e], fb[cb][j][e], acc[j], 0, 0, 0);
+          }
+          __builtin_amdgcn_s_setprio(0);
+          // tile q + 1 (issued one iteration ago) has landed for this wave; tile q + 2 stays in flight
+          if (more)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          cur = cur == 2 ? 0 : cur + 1;
+        }
+        fold(g);
+      }
+    } else {
+      int aoff[RA], wrow[RB];
+      bool wok[RB];
+  #pragma unroll
+      for (int i = 0; i < RA; ++i) aoff[i] = (m0 + r0 + RPP * i) * K + kq * 4;
+  #pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int n = n0 + r0 + RPP * i;
+        wok[i] = n < N;
+        wrow[i] = n * K + kq * 4;
+      }
+
+      f32x4 ra[RA], rb[RB];
+      const float* lt_v = P.V;
+      const float* lt_u = P.U;
+      bool lt_kok = false;
+      auto load_begin = [&](int g, int kc, bool enable) {
+        const int c0 = kc << 5;
+        lt_v = P.V + (size_t)g * vgs + c0;
+        lt_u = P.U + (size_t)g * ugs + c0;
+        lt_kok = enable && ((c0 + kq * 4) < K);
+      };
+      auto load_a = [&](int i) {
+        if (WINO_ABL & 1) return;
+        const float* ptr = lt_kok ? lt_v + (unsigned)aoff[i] : wino_zero16;
+        ra[i] = *reinterpret_cast<const f32x4*>(ptr);
+      };
+      auto load_b = [&](int i) {
+        if (WINO_ABL & 1) return;
+        const float* ptr = (wok[i] && lt_kok) ? lt_u + (unsigned)wrow[i] : wino_zero16;
+        rb[i] = *reinterpret_cast<const f32x4*>(ptr);
+      };
+      auto store_tile = [&](int buf) {
+        float* dA = sA + buf * BM * LS;
+        float* dB = sB + buf * BN * LS;
+  #pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(dA + (r0 + RPP * i) * LS + kq * 4) = ra[i];
+  #pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(dB + (r0 + RPP * i) * LS + kq * 4) = rb[i];
+      };
+
+
+      load_begin(0, 0, true);
+  #pragma unroll
+      for (int i = 0; i < RA; ++i) load_a(i);
+  #pragma unroll
+      for (int i = 0; i < RB; ++i) load_b(i);
+      store_tile(0);
+      __syncthreads();
+      int cur = 0;
+      for (int g = 0; g < 16; ++g) {
+  #pragma unroll
+        for (int j = 0; j < TN; ++j)
+  #pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int kc = 0; kc < KT; ++kc) {
+          const bool glast = (kc + 1 == KT);
+          const bool last = glast && g == 15;
+          load_begin(glast ? g + 1 : g, glast ? 0 : kc + 1, !last);
+          const float* cA = sA + cur * BM * LS + (wm0 + l31) * LS + 4 * lh;
+          const float* cB = sB + cur * BN * LS + (wn0 + l31) * LS + 4 * lh;
+          f32x4 fa[2], fb[2][TN];
+          fa[0] = *reinterpret_cast<const f32x4*>(cA);
+  #pragma unroll
+          for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * LS);
+  #pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int cb = jj & 1, nbuf = cb ^ 1;
+            if (jj < 3) {
+              fa[nbuf] = *reinterpret_cast<const f32x4*>(cA + (jj + 1) * 8);
+  #pragma unroll
+              for (int j = 0; j < TN; ++j)
+                fb[nbuf][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * LS + (jj + 1) * 8);
+            }
+            // the next K tile's loads ride in the shadow of this tile's MFMAs (conv_gemm.hip conv_nt_kernel)
+            if (jj < RA) load_a(jj);
+            if (jj < RB) load_b(jj);
+            if (!(WINO_ABL & 4)) __builtin_amdgcn_s_setprio(1);
+  #pragma unroll
+            for (int e = 0; e < 4; ++e)
+  #pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][e], fb[cb][j][e], acc[j], 0, 0, 0);
+            if (WINO_ABL & 8) {
+  #pragma unroll
+              for (int m = 0; m < 4 * TN; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                     // 1 MFMA
+                if (m < 1 + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 LDS read
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                     // address VALU
+                if (m == 2 || m == 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 global load
+              }
+            }
+          }
+          if (!(WINO_ABL & 4)) __builtin_amdgcn_s_setprio(0);
+          if (!(WINO_ABL & 16)) {
+            if (!last) store_tile(cur ^ 1);
+            __syncthreads();
+          }
+          cur ^= 1;
+        }
+        fold(g);
+      }
+
+    }
+
+    // ---- epilogue: the four output pixels of every tile, one staged [BM][BN] plane at a time
+    float* stage = smem;
+    constexpr int CG = BN / 4, RS = NT / CG;
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int c4 = tid_e % CG, rr = tid_e / CG;
+    const int n = n0 + c4 * 4;
+    const bool nok = n < N;  // N % 4 == 0
+    const int flags = P.flags;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if ((flags & WCF_BIAS) && nok) bv = *reinterpret_cast<const f32x4*>(P.bias + n);
+    f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+    const int e_lane = tid_e & 63, e_wid = tid_e >> 6;
+    const int e_wm0 = (e_wid >> 1) * WTM, e_wn0 = (e_wid & 1) * WTN, e_l31 = e_lane & 31, e_lh = e_lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pa = q >> 1, pb = q & 1;
+      if (q) __syncthreads();  // the previous plane has been consumed
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stage[(e_wm0 + (r & 3) + 8 * (r >> 2) + 4 * e_lh) * CS + e_wn0 + j * 32 + e_l31] = Y[q][j][r];
+      __syncthreads();
+      const int need = 1 | (pa ? 2 : 0) | (pb ? 4 : 0);
+      for (int row = rr; row < BM; row += RS) {
+        const WinoRow R = rows[row];
+        if (!nok || (R.valid & need) != need) continue;
+        f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4) + bv;
+        const int o = R.off + pa * R.wn + pb * N + n;
+        float* d = R.dst + o;
+        if (flags & WCF_ACCUM) v += *reinterpret_cast<const f32x4*>(d);
+        if (flags & WCF_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (flags & WCF_SIGMOID) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = 1.f / (1.f + __expf(-v[e]));
+        }
+        if (flags & WCF_MASK) {
+          const f32x4 mk = *reinterpret_cast<const f32x4*>(R.mask + o);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(d) = v;
+        ssum += v;
+        ssq += v * v;
+      }
+    }
+    if (flags & WCF_STATS) {
+      __syncthreads();
+      float* red = smem;  // [2][RS][BN]
+      *reinterpret_cast<f32x4*>(red + (size_t)rr * BN + c4 * 4) = ssum;
+      *reinterpret_cast<f32x4*>(red + (size_t)(RS + rr) * BN + c4 * 4) = ssq;
+      __syncthreads();
+      for (int c = tid_e; c < 2 * BN; c += NT) {
+        const int which = c / BN, col = c - which * BN;
+        float s = 0.f;
+        for (int l = 0; l < RS; ++l) s += red[(size_t)(which * RS + l) * BN + col];
+        if (n0 + col < N) P.stats[((size_t)mt * 2 + which) * N + n0 + col] = s;
+      }
+    }
+  }
+}
+
+#ifndef WINO_DMA
+#define WINO_DMA 1  // tuning builds: -DWINO_DMA=0 selects the register-staged main loop
+#endif
+template __global__ void wino_gemm_kernel<64, 128, WINO_DMA != 0>(const WinoArgs);
+
+// -------------------------------------------------------------------------------------------- host side
+static int wino_num_cus() {
+  static int cus = 256;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  });
+  return cus;
+}
+
+static int wino_fill_geom(WinoGeom& g, int nlev, int Nb, const int* H, const int* W, const char* who) {
+  SACV_CHECK_ARG(nlev >= 1 && nlev <= WINO_MAXL, "%s: %d levels (1..%d)", who, nlev, WINO_MAXL);
+  SACV_CHECK_ARG(Nb > 0, "%s: batch", who);
+  g.nlev = nlev;
+  g.Nb = Nb;
+  long long t = 0;
+  for (int l = 0; l < WINO_MAXL; ++l) {
+    g.tile_begin[l] = (int)t;
+    if (l < nlev) {
+      SACV_CHECK_ARG(H[l] > 0 && W[l] > 0, "%s: bad level dims", who);
+      g.H[l] = H[l];
+      g.W[l] = W[l];
+      g.th[l] = (H[l] + 1) / 2;
+      g.tw[l] = (W[l] + 1) / 2;
+      t += (long long)Nb * g.th[l] * g.tw[l];
+    } else {
+      g.H[l] = g.W[l] = g.th[l] = g.tw[l] = 1;
+    }
+  }
+  SACV_CHECK_ARG(t < (1LL << 24), "%s: too many tiles", who);
+  g.tile_begin[WINO_MAXL] = (int)t;
+  for (int l = nlev; l <= WINO_MAXL; ++l) g.tile_begin[l] = (int)t;
+  return SACV_OK;
+}
+
+extern "C" {
+
+// Number of 2x2 output tiles of a pyramid (rows of the transformed operand V before padding to a multiple of 64).
+int sacv_wino_tiles(int nlev, int Nb, const int* H, const int* W) {
+  WinoGeom g;
+  if (wino_fill_geom(g, nlev, Nb, H, W, "wino_tiles") != SACV_OK) return -1;
+  return g.tile_begin[WINO_MAXL];
+}
+
+// Operand padding: the GEMM reads whole 64 x 32 (V) and 128 x 32 (U) tiles without masks, so rows / columns are padded
+// with zeros to these granules by the two transform kernels.
+int sacv_wino_pad_k(int K) { return (K + 31) / 32 * 32; }
+int sacv_wino_pad_n(int N) { return (N + 127) / 128 * 128; }
+
+// U[16][pad_n(N)][pad_k(K)] = G w G^T from a GEMM weight panel [N][9][K] (conv_gemm.hip forward panel: N = Cout,
+// K = Cin; data-gradient panel: N = Cin, K = Cout with flip = 1, the 180-degree rotated kernel of the transposed
+// convolution).
+int sacv_wino_weights(const float* panel, float* U, int N, int K, int flip, void* stream) {
+  SACV_CHECK_ARG(panel && U, "wino_weights: null pointer");
+  SACV_CHECK_ARG(N > 0 && K > 0 && K % 4 == 0, "wino_weights: N=%d K=%d (K must be a multiple of 4)", N, K);
+  const int Np = sacv_wino_pad_n(N), Kp = sacv_wino_pad_k(K);
+  SACV_CHECK_ARG((long long)Np * Kp * 16 < (1LL << 30), "wino_weights: panel too large");
+  const int total = Np * (Kp / 4);
+  hipLaunchKernelGGL(wino_weight_kernel, dim3(sacv_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, panel, U, N, K,
+                     Np, Kp, flip);
+  SACV_CHECK_LAUNCH("wino_weight_kernel");
+  return SACV_OK;
+}
+
+// V[16][Tpad][pad_k(C)] = B^T d B of every 4x4 input patch (pad 1) of the NHWC level tensors
+// src[l] = [Nb][H[l]][W[l]][C].  Tpad = tiles rounded up to a multiple of 64 (padding rows / channels are zero-filled).
+int sacv_wino_input(int nlev, const float* const* src, int Nb, const int* H, const int* W, int C, float* V, int Tpad,
+                    void* stream) {
+  WinoInArgs a;
+  int rc = wino_fill_geom(a.g, nlev, Nb, H, W, "wino_input");
+  if (rc != SACV_OK) return rc;
+  SACV_CHECK_ARG(C > 0 && C % 4 == 0, "wino_input: C=%d must be a positive multiple of 4", C);
+  a.T = a.g.tile_begin[WINO_MAXL];
+  SACV_CHECK_ARG(Tpad >= a.T && Tpad % 64 == 0, "wino_input: Tpad=%d must be a multiple of 64 >= %d", Tpad, a.T);
+  a.Cp = sacv_wino_pad_k(C);
+  SACV_CHECK_ARG((long long)Tpad * a.Cp * 16 < (1LL << 30), "wino_input: V too large for 32-bit element indexing");
+  SACV_CHECK_ARG(V, "wino_input: null V");
+  for (int l = 0; l < WINO_MAXL; ++l) {
+    a.src[l] = l < nlev ? src[l] : nullptr;
+    SACV_CHECK_ARG(l >= nlev || src[l], "wino_input: null level pointer");
+    SACV_CHECK_ARG(l >= nlev || (long long)Nb * H[l] * W[l] * C < (1LL << 30), "wino_input: level too large");
+  }
+  a.V = V;
+  a.C = C;
+  a.Tpad = Tpad;
+  const long long total = (long long)Tpad * (a.Cp / 4);
+  hipLaunchKernelGGL(wino_input_kernel, dim3(sacv_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  SACV_CHECK_LAUNCH("wino_input_kernel");
+  return SACV_OK;
+}
+
+// Rows of one problem's WCF_STATS buffer ([rows][2][N]): 64-tile M tiles.
+int sacv_wino_stats_rows(int tiles) { return (tiles + 63) / 64; }
+
+// 3x3 / stride 1 / pad 1 convolution of nprob (1 or 2) independent problems from their transformed operands.
+// Problem p: V[p] = [16][Tpad[p]][pad_k(K[p])], U[p] = [16][pad_n(N[p])][pad_k(K[p])], outputs dst[p*5 + l] = [Nb][H[l]][W[l]][N[p]]
+// (the pyramid geometry nlev / Nb / H / W is shared by the problems), optional bias[p], mask[p*5 + l] (WCF_MASK),
+// stats[p] (WCF_STATS, sacv_wino_stats_rows rows).  flags[p]: the CF_* epilogue bits of sacv_conv2d_gemm.
+int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, const float* const* V,
+                   const float* const* U, const int* Tpad, const int* K, const int* N, const float* const* bias,
+                   float* const* dst, const float* const* mask, float* const* stats, const int* flags, void* stream) {
+  SACV_CHECK_ARG(nprob >= 1 && nprob <= WINO_MAXP, "wino_gemm: nprob %d (1..%d)", nprob, WINO_MAXP);
+  WinoArgs a;
+  int items = 0;
+  for (int p = 0; p < nprob; ++p) {
+    WinoProb& P = a.p[p];
+    int rc = wino_fill_geom(P.g, nlev, Nb, H, W, "wino_gemm");
+    if (rc != SACV_OK) return rc;
+    P.T = P.g.tile_begin[WINO_MAXL];
+    SACV_CHECK_ARG(V[p] && U[p], "wino_gemm: null operand (problem %d)", p);
+    SACV_CHECK_ARG(K[p] > 0 && K[p] % 4 == 0 && N[p] > 0 && N[p] % 4 == 0,
+                   "wino_gemm: K=%d N=%d must be positive multiples of 4", K[p], N[p]);
+    SACV_CHECK_ARG(Tpad[p] >= P.T && Tpad[p] % 64 == 0, "wino_gemm: Tpad");
+    const int Kp = sacv_wino_pad_k(K[p]), Np = sacv_wino_pad_n(N[p]);
+    SACV_CHECK_ARG((long long)Tpad[p] * Kp * 16 < (1LL << 30) && (long long)Np * Kp * 16 < (1LL << 30),
+                   "wino_gemm: operand too large for 32-bit element indexing");
+    SACV_CHECK_ARG((flags[p] & ~63) == 0, "wino_gemm: unknown flag bits 0x%x", flags[p] & ~63);
+    P.V = V[p];
+    P.U = U[p];
+    P.bias = bias ? bias[p] : nullptr;
+    SACV_CHECK_ARG(!(flags[p] & WCF_BIAS) || P.bias, "wino_gemm: bias flag without bias pointer");
+    P.stats = stats ? stats[p] : nullptr;
+    SACV_CHECK_ARG(!(flags[p] & WCF_STATS) || P.stats, "wino_gemm: WCF_STATS without a stats buffer");
+    for (int l = 0; l < WINO_MAXL; ++l) {
+      P.dst[l] = l < nlev ? dst[p * WINO_MAXL + l] : nullptr;
+      P.mask[l] = (l < nlev && mask) ? mask[p * WINO_MAXL + l] : nullptr;
+      SACV_CHECK_ARG(l >= nlev || P.dst[l], "wino_gemm: null output pointer");
+      SACV_CHECK_ARG(l >= nlev || !(flags[p] & WCF_MASK) || P.mask[l], "wino_gemm: mask flag without mask pointer");
+      SACV_CHECK_ARG(l >= nlev || (long long)Nb * H[l] * W[l] * N[p] < (1LL << 30), "wino_gemm: output too large");
+    }
+    P.Tpad = Tpad[p];
+    P.K = Kp;
+    P.Np = Np;
+    P.N = N[p];
+    P.flags = flags[p];
+    P.item_begin = items;
+    P.ntn = (N[p] + 127) / 128;
+    items += ((P.T + 63) / 64) * P.ntn;
+  }
+  a.nprob = nprob;
+  a.total_items = items;
+  constexpr int BM = 64, BN = 128;
+  constexpr bool DMA = WINO_DMA != 0;
+  const int lds = (DMA ? 3 * (BM + BN) * 32 : 2 * (BM + BN) * 36) * 4 + BM * (int)sizeof(WinoRow);
+  static_assert(2 * (BM + BN) * 32 >= BM * (BN + 4), "the epilogue stage must fit in the operand buffers");
+  static std::once_flag attr;
+  std::call_once(attr, [lds] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel<BM, BN, DMA>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  });
+  int grid = wino_num_cus() * 2;
+  if (grid > items) grid = items;
+  hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, DMA>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  SACV_CHECK_LAUNCH("wino_gemm_kernel");
+  return SACV_OK;
+}
+
+}  // extern "C"

@@ -57,6 +57,10 @@ class DetectorEngine:
         # no gain, 45.9 vs 44.8 ms/step -- the persistent conv kernels already hold every CU's LDS, so two streams'
         # workgroups cannot co-reside.  The switch was removed; weight gradients run in stream order.)
         self._panels = None  # data-gradient weight panels, refreshed by one launch per training step
+        # Winograd F(2x2,3x3) for the stride-1 3x3 head convolutions (csrc/winograd.hip): layer i of both towers in
+        # one launch.  False selects the direct implicit-GEMM kernel for every conv (A/B measurements, tests).
+        self.winograd = True
+        self._wino_cache = {}
 
     def _wgrad(self, dys, xs, dw, cin, kh, kw, stride, pad, **kw_args):
         ops.conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, **kw_args)
@@ -208,6 +212,7 @@ class DetectorEngine:
     def forward(self, images, training=True, keep=True):
         """images: logical [B,3,H,W] fp32 (any strides).  Returns (cls_levels, reg_levels)."""
         ctx = {} if keep else None
+        self._wino_cache = {}  # Winograd-domain weights are per forward (the optimizer step changes the weights)
         if keep:
             self._refresh_dgrad_panels()
         feats = self._backbone_fwd(images, training, keep, ctx)
@@ -337,16 +342,63 @@ class DetectorEngine:
             ctx[tower] = saved
         return outs
 
+    def _wino_u(self, w, dgrad=False):
+        """Winograd-domain weights U = G w G^T of a 3x3 parameter for this step (forward, or the rotated transposed
+        kernel of the data gradient).  Cached per forward(): the weights only change in the optimizer step."""
+        key = (w.data_ptr(), dgrad)
+        u = self._wino_cache.get(key)
+        if u is None:
+            co, ci = w.shape[0], w.shape[1]
+            if dgrad:
+                u = ops.wino_weights(self._dgrad_panel(w), ci, co, flip=True)
+            else:
+                u = ops.wino_weights(ops.fwd_panel(w), co, ci)
+            self._wino_cache[key] = u
+        return u
+
+    def _use_wino(self):
+        return self.winograd and not self.amp
+
     def _heads_fwd(self, feats, ctx):
         a, nc = self.num_anchors, self.num_classes
-        cls = self._tower_fwd(feats, 'cls_head.cls_head', 'cls_head.cls_out', a * nc, CF_SIGMOID, ctx)
-        reg = self._tower_fwd(feats, 'reg_head.reg_head', 'reg_head.reg_out', a * 4, 0, ctx)
+        if self._use_wino():
+            cls, reg = self._towers_fwd_wino(feats, ctx, a * nc, a * 4)
+        else:
+            cls = self._tower_fwd(feats, 'cls_head.cls_head', 'cls_head.cls_out', a * nc, CF_SIGMOID, ctx)
+            reg = self._tower_fwd(feats, 'reg_head.reg_head', 'reg_head.reg_out', a * 4, 0, ctx)
         if ctx is not None:
             ctx['cls_probs'] = cls
             ctx['feat_shapes'] = [tuple(f.shape) for f in feats]
         cls_levels = [t.view(t.shape[0], t.shape[1], t.shape[2], a, nc) for t in cls]
         reg_levels = [t.view(t.shape[0], t.shape[1], t.shape[2], a, 4) for t in reg]
         return cls_levels, reg_levels
+
+    RETINA_TOWERS = (('cls_head.cls_head', 'cls_head.cls_out'), ('reg_head.reg_head', 'reg_head.reg_out'))
+
+    def _towers_fwd_wino(self, feats, ctx, n_cls, n_reg):
+        """RetinaClsHead / RetinaRegHead (head.py:20-36, 55-70) with layer i of BOTH towers in one Winograd launch
+        (the towers are independent chains over the same pyramid: 2 x 352 work items fill the 512 workgroup slots
+        better than 352).  Layer 0 of the two towers reads the same input: one input transform."""
+        p = self.p
+        xs = [feats, feats]
+        saved = [[], []]
+        v0 = ops.wino_input(feats, tag='wino_v0')
+        for li, i in enumerate((0, 2, 4, 6)):
+            names = [f'{t}.{i}' for t, _ in self.RETINA_TOWERS]
+            saved[0].append(xs[0])
+            saved[1].append(xs[1])
+            xs = ops.conv3x3_wino(xs, [self._wino_u(p[n + '.weight']) for n in names], [self.planes] * 2,
+                                  biases=[p[n + '.bias'] for n in names], flags=[CF_RELU] * 2,
+                                  vs=[v0, v0] if li == 0 else None)
+        saved[0].append(xs[0])
+        saved[1].append(xs[1])
+        names = [o for _, o in self.RETINA_TOWERS]
+        outs = ops.conv3x3_wino(xs, [self._wino_u(p[n + '.weight']) for n in names], [n_cls, n_reg],
+                                biases=[p[n + '.bias'] for n in names], flags=[CF_SIGMOID, 0])
+        if ctx is not None:
+            ctx[self.RETINA_TOWERS[0][0]] = saved[0]
+            ctx[self.RETINA_TOWERS[1][0]] = saved[1]
+        return outs
 
     # ------------------------------------------------------------------ FCOS heads
     # FCOSClsRegCntHead (head.py:88-181): two towers of 4 x (3x3 conv no bias, GroupNorm(32), ReLU) shared by
@@ -381,16 +433,50 @@ class DetectorEngine:
         b8[4:5].copy_(p['clsregcnt_head.center_out.bias'])
         return w8, b8
 
+    FCOS_TOWERS = ('clsregcnt_head.cls_head', 'clsregcnt_head.reg_head')
+
+    def _gn_towers_fwd_wino(self, feats, ctx):
+        """Both FCOS towers in lockstep: layer i of the two towers is one Winograd launch (no bias: GroupNorm follows),
+        then GroupNorm + ReLU per level as in _gn_tower_fwd."""
+        p = self.p
+        xs = [feats, feats]
+        saved = [[], []]
+        v0 = ops.wino_input(feats, tag='wino_v0')
+        for li, i in enumerate((0, 3, 6, 9)):
+            ws = [p[f'{t}.{i}.weight'] for t in self.FCOS_TOWERS]
+            yss = ops.conv3x3_wino(xs, [self._wino_u(w) for w in ws], [self.planes] * 2,
+                                   vs=[v0, v0] if li == 0 else None)
+            nxt = []
+            for t, tower in enumerate(self.FCOS_TOWERS):
+                zs, sts = [], []
+                for y in yss[t]:
+                    z, st = ops.groupnorm_fwd(y, p[f'{tower}.{i + 1}.weight'], p[f'{tower}.{i + 1}.bias'], 32, 1e-5,
+                                              True)
+                    zs.append(z)
+                    sts.append(st)
+                saved[t].append((xs[t], yss[t], sts, zs))
+                nxt.append(zs)
+            xs = nxt
+        if ctx is not None:
+            ctx[self.FCOS_TOWERS[0]] = saved[0]
+            ctx[self.FCOS_TOWERS[1]] = saved[1]
+        return xs
+
     def _fcos_heads_fwd(self, feats, ctx):
         p = self.p
         hw = [(f.shape[1], f.shape[2]) for f in feats]
-        cls_x = self._gn_tower_fwd(feats, 'clsregcnt_head.cls_head', ctx)
-        reg_x = self._gn_tower_fwd(feats, 'clsregcnt_head.reg_head', ctx)
         w = p['clsregcnt_head.cls_out.weight']
-        cls = ops.conv_gemm(cls_x, ops.fwd_panel(w), w.shape[0], 3, 3, 1, 1, 0, hw,
-                            bias=p['clsregcnt_head.cls_out.bias'], flags=CF_SIGMOID)
         w8, b8 = self._fcos_w8()
-        y8 = ops.conv_gemm(reg_x, ops.fwd_panel(w8), 8, 3, 3, 1, 1, 0, hw, bias=b8)
+        if self._use_wino():
+            cls_x, reg_x = self._gn_towers_fwd_wino(feats, ctx)
+            cls, y8 = ops.conv3x3_wino([cls_x, reg_x], [self._wino_u(w), self._wino_u(w8)], [w.shape[0], 8],
+                                       biases=[p['clsregcnt_head.cls_out.bias'], b8], flags=[CF_SIGMOID, 0])
+        else:
+            cls_x = self._gn_tower_fwd(feats, 'clsregcnt_head.cls_head', ctx)
+            reg_x = self._gn_tower_fwd(feats, 'clsregcnt_head.reg_head', ctx)
+            cls = ops.conv_gemm(cls_x, ops.fwd_panel(w), w.shape[0], 3, 3, 1, 1, 0, hw,
+                                bias=p['clsregcnt_head.cls_out.bias'], flags=CF_SIGMOID)
+            y8 = ops.conv_gemm(reg_x, ops.fwd_panel(w8), 8, 3, 3, 1, 1, 0, hw, bias=b8)
         regs, ctrs = [], []
         for l, y in enumerate(y8):
             r, c = ops.fcos_split_fwd(y, p['scales'][l:l + 1])
@@ -399,6 +485,30 @@ class DetectorEngine:
         if ctx is not None:
             ctx['fcos_out'] = dict(cls=cls, reg=regs, ctr=ctrs, cls_x=cls_x, reg_x=reg_x, w8=w8)
         return cls, regs, ctrs
+
+    def _gn_towers_bwd_wino(self, dzs2):
+        """Backward of the two FCOS towers in lockstep (dzs2[t]: per-level grads w.r.t. tower t's output)."""
+        p, g = self.p, self.g
+        saved = [self.ctx[t] for t in self.FCOS_TOWERS]
+        cur = dzs2
+        for li, i in reversed(list(enumerate((0, 3, 6, 9)))):
+            dys2, ws = [], []
+            for t, tower in enumerate(self.FCOS_TOWERS):
+                xs, ys, sts, zs = saved[t][li]
+                gname, bname = f'{tower}.{i + 1}.weight', f'{tower}.{i + 1}.bias'
+                dys = [ops.groupnorm_bwd(y, dz, z, st, p[gname], g[gname], g[bname], 32, accumulate=l > 0)
+                       for l, (y, dz, z, st) in enumerate(zip(ys, cur[t], zs, sts))]
+                w = p[f'{tower}.{i}.weight']
+                self._wgrad(dys, xs, g[f'{tower}.{i}.weight'], w.shape[1], 3, 3, 1, 1)
+                dys2.append(dys)
+                ws.append(w)
+            us = [self._wino_u(w, dgrad=True) for w in ws]
+            if li > 0:
+                cur = ops.conv3x3_wino(dys2, us, [self.planes] * 2, mode=1)
+            else:
+                dfeat = ops.conv3x3_wino([dys2[0]], [us[0]], [self.planes], mode=1)[0]
+                ops.conv3x3_wino([dys2[1]], [us[1]], [self.planes], flags=[CF_ACCUM], outs_list=[dfeat], mode=1)
+        return dfeat
 
     def _gn_tower_bwd(self, dzs, tower, accum_into=None):
         """dzs: per-level grads w.r.t. the tower output (after the last GN + ReLU)."""
@@ -430,8 +540,6 @@ class DetectorEngine:
         w = p['clsregcnt_head.cls_out.weight']
         self._wgrad(dz_cls, o['cls_x'], g['clsregcnt_head.cls_out.weight'], w.shape[1], 3, 3, 1, 1)
         self._bias_grad(dz_cls, 'clsregcnt_head.cls_out')
-        d_cls_x = ops.conv_gemm(dz_cls, self._dgrad_panel(w), w.shape[1], 3, 3, 1, 1, 1, hw)
-        dfeat = self._gn_tower_bwd(d_cls_x, 'clsregcnt_head.cls_head')
         # regression + centerness branch (8-channel combined output conv)
         dy8 = [ops.fcos_split_bwd(dr.contiguous(), dc.contiguous(), r, c, p['scales'][l:l + 1], g['scales'], l,
                                   gscale=grad_scale)
@@ -445,6 +553,13 @@ class DetectorEngine:
             ops.colsum(d, 8, db8, accumulate=l > 0)
         g['clsregcnt_head.reg_out.bias'].copy_(db8[0:4])
         g['clsregcnt_head.center_out.bias'].copy_(db8[4:5])
+        if self._use_wino():
+            d_cls_x, d_reg_x = ops.conv3x3_wino([dz_cls, dy8], [self._wino_u(w, dgrad=True),
+                                                                 self._wino_u(o['w8'], dgrad=True)],
+                                                [self.planes] * 2, mode=1)
+            return self._gn_towers_bwd_wino([d_cls_x, d_reg_x])
+        d_cls_x = ops.conv_gemm(dz_cls, self._dgrad_panel(w), w.shape[1], 3, 3, 1, 1, 1, hw)
+        dfeat = self._gn_tower_bwd(d_cls_x, 'clsregcnt_head.cls_head')
         d_reg_x = ops.conv_gemm(dy8, self._dgrad_panel(o['w8']), self.planes, 3, 3, 1, 1, 1, hw)
         return self._gn_tower_bwd(d_reg_x, 'clsregcnt_head.reg_head', accum_into=dfeat)
 
@@ -485,6 +600,37 @@ class DetectorEngine:
                 cur = ops.conv_gemm(cur, wd, w.shape[1], 3, 3, 1, 1, 1, hw)
         return cur
 
+    def _towers_bwd_wino(self, dz_cls, dz_reg):
+        """Backward of the two Retina towers in lockstep: weight gradients on the direct kernel (conv_tn), data
+        gradients on the Winograd path with the ReLU mask and the bias-gradient column sums in the epilogue (as
+        _tower_bwd), layer i of both towers per launch."""
+        p, g = self.p, self.g
+        towers = self.RETINA_TOWERS
+        saved = [self.ctx[t] for t, _ in towers]
+        dys = [dz_cls, dz_reg]
+        for t, (_, out_name) in enumerate(towers):
+            w = p[out_name + '.weight']
+            self._wgrad(dys[t], saved[t][4], g[out_name + '.weight'], w.shape[1], 3, 3, 1, 1)
+            self._bias_grad(dys[t], out_name)
+        ws = [p[o + '.weight'] for _, o in towers]
+        cur, st = ops.conv3x3_wino(dys, [self._wino_u(w, dgrad=True) for w in ws], [self.planes] * 2,
+                                   flags=[CF_MASK] * 2, masks_list=[saved[0][4], saved[1][4]], stats=True, mode=1)
+        for li, i in reversed(list(enumerate((0, 2, 4, 6)))):
+            names = [f'{t}.{i}' for t, _ in towers]
+            ws = [p[n + '.weight'] for n in names]
+            for t in range(2):
+                self._wgrad(cur[t], saved[t][li], g[names[t] + '.weight'], ws[t].shape[1], 3, 3, 1, 1)
+                ops.colsum_finalize(st[t], g[names[t] + '.bias'])
+            us = [self._wino_u(w, dgrad=True) for w in ws]
+            if li > 0:
+                cur, st = ops.conv3x3_wino(cur, us, [self.planes] * 2, flags=[CF_MASK] * 2,
+                                           masks_list=[saved[0][li], saved[1][li]], stats=True, mode=1)
+            else:
+                # both towers feed the same pyramid gradient: the second launch accumulates into the first's output
+                dfeat = ops.conv3x3_wino([cur[0]], [us[0]], [self.planes], mode=1)[0]
+                ops.conv3x3_wino([cur[1]], [us[1]], [self.planes], flags=[CF_ACCUM], outs_list=[dfeat], mode=1)
+        return dfeat
+
     def _conv_bias_bwd(self, dy, x, name, k, stride, pad, need_dx=True, out=None, accumulate=False, mask=None):
         w = self.p[name + '.weight']
         self._wgrad([dy], [x], self.g[name + '.weight'], w.shape[1], k, k, stride, pad)
@@ -515,8 +661,11 @@ class DetectorEngine:
                                   scalar=grad_scale) for d in dreg_levels]
         else:
             dz_reg = [d.reshape(d.shape[0], d.shape[1], d.shape[2], a * 4) for d in dreg_levels]
-        dfeat = self._tower_bwd(dz_cls, 'cls_head.cls_head', 'cls_head.cls_out')
-        dfeat = self._tower_bwd(dz_reg, 'reg_head.reg_head', 'reg_head.reg_out', accum_into=dfeat)
+        if self._use_wino():
+            dfeat = self._towers_bwd_wino(dz_cls, dz_reg)
+        else:
+            dfeat = self._tower_bwd(dz_cls, 'cls_head.cls_head', 'cls_head.cls_out')
+            dfeat = self._tower_bwd(dz_reg, 'reg_head.reg_head', 'reg_head.reg_out', accum_into=dfeat)
         self._trunk_bwd(dfeat, on_stage)
 
     def _trunk_bwd(self, dfeat, on_stage):

@@ -200,6 +200,120 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
     return outs
 
 
+# ------------------------------------------------------------------------------------------ Winograd F(2x2,3x3)
+WINO_MAXL = 5
+
+
+def wino_tiles(nb, hw):
+    """(tiles, tiles padded to the GEMM's 64-row granule) of a pyramid of [nb, h, w, .] levels."""
+    t = sum(nb * ((h + 1) // 2) * ((w + 1) // 2) for h, w in hw)
+    return t, -(-t // 64) * 64
+
+
+def wino_pad_k(k):
+    return -(-k // 32) * 32
+
+
+def wino_pad_n(n):
+    return -(-n // 128) * 128
+
+
+def wino_weights(panel, n, k, flip=False, out=None):
+    """U[16][pad_n(n)][pad_k(k)] = G w G^T of a GEMM panel [n][9][k] (forward panel; the data-gradient panel with
+    flip=True); zero-padded to the GEMM's 128 x 32 operand tiles."""
+    if panel.numel() != n * 9 * k:
+        raise ValueError(f'wino_weights: panel of {panel.numel()} elements is not [{n}][9][{k}]')
+    shape = (16, wino_pad_n(n), wino_pad_k(k))
+    out = out if out is not None else torch.empty(shape, device=panel.device, dtype=torch.float32)
+    if tuple(out.shape) != shape:
+        raise ValueError(f'wino_weights: out is {tuple(out.shape)}, expected {shape}')
+    check(lib.sacv_wino_weights(_ptr(panel), _ptr(out), n, k, int(flip), _stream()), 'wino_weights')
+    return out
+
+
+def wino_input(srcs, out=None, tag='wino_v'):
+    """V[16][Tpad][pad_k(C)] = B^T d B over all levels (NHWC fp32, one batch size, one channel count)."""
+    nb, c = srcs[0].shape[0], srcs[0].shape[3]
+    hw = [(s.shape[1], s.shape[2]) for s in srcs]
+    for s in srcs:
+        _chk(s, 'wino_input src')
+    t, tpad = wino_tiles(nb, hw)
+    cp = wino_pad_k(c)
+    if out is None:
+        out = workspace(16 * tpad * cp * 4, srcs[0].device, tag)[:16 * tpad * cp * 4].view(torch.float32)
+        out = out.view(16, tpad, cp)
+    check(lib.sacv_wino_input(len(srcs), parr([s.data_ptr() for s in srcs]), nb, iarr([h for h, _ in hw]),
+                              iarr([w for _, w in hw]), c, _ptr(out), tpad, _stream()), 'wino_input')
+    return out
+
+
+def conv3x3_wino(srcs_list, us, n_outs, biases=None, flags=None, masks_list=None, outs_list=None, stats=False,
+                 mode=0, vs=None):
+    """3x3 / stride 1 / pad 1 convolution of 1 or 2 independent problems (e.g. layer i of the two head towers) over
+    the same pyramid geometry on the Winograd path.  srcs_list[p]: list of NHWC levels; us[p]: wino_weights(...)
+    [16][n_outs[p]][C_p]; flags[p]: CF_* epilogue bits.  `mode` only labels the timer record (0 forward, 1 data
+    gradient: the caller passes the flipped data-gradient U).  vs[p]: an already transformed input (wino_input).
+    Returns outs_list (and the per-problem CF_STATS buffers when stats=True)."""
+    npb = len(srcs_list)
+    first = srcs_list[0]
+    nb = first[0].shape[0]
+    hw = [(s.shape[1], s.shape[2]) for s in first]
+    nlev = len(first)
+    t, tpad = wino_tiles(nb, hw)
+    flags = list(flags) if flags is not None else [0] * npb
+    biases = biases if biases is not None else [None] * npb
+    for p in range(npb):
+        if [(s.shape[1], s.shape[2]) for s in srcs_list[p]] != hw or srcs_list[p][0].shape[0] != nb:
+            raise ValueError('conv3x3_wino: the problems of one launch share the pyramid geometry')
+        if biases[p] is not None:
+            flags[p] |= CF_BIAS
+        if stats:
+            flags[p] |= CF_STATS
+    if outs_list is None:
+        outs_list = [[torch.empty((nb, h, w, n_outs[p]), device=first[0].device, dtype=torch.float32) for h, w in hw]
+                     for p in range(npb)]
+    stats_bufs = None
+    if stats:
+        rows = lib.sacv_wino_stats_rows(t)
+        stats_bufs = [torch.empty((rows, 2, n_outs[p]), device=first[0].device, dtype=torch.float32)
+                      for p in range(npb)]
+    ks = [srcs_list[p][0].shape[3] for p in range(npb)]
+
+    def pad5(lst):
+        return list(lst) + [0] * (WINO_MAXL - len(lst))
+
+    def launch():
+        v = [vs[p] if vs is not None and vs[p] is not None else wino_input(srcs_list[p], tag=f'wino_v{p}')
+             for p in range(npb)]
+        dst = sum([pad5([o.data_ptr() for o in outs_list[p]]) for p in range(npb)], [])
+        msk = None
+        if masks_list is not None and any(m is not None for m in masks_list):
+            msk = sum([pad5([m.data_ptr() for m in masks_list[p]]) if masks_list[p] is not None else pad5([])
+                       for p in range(npb)], [])
+        check(lib.sacv_wino_gemm(
+            npb, nlev, nb, iarr([h for h, _ in hw]), iarr([w for _, w in hw]),
+            parr([x.data_ptr() for x in v]), parr([u.data_ptr() for u in us]), iarr([tpad] * npb), iarr(ks),
+            iarr(list(n_outs)), parr([_ptr(b) or 0 for b in biases]), parr(dst), parr(msk) if msk else None,
+            parr([s.data_ptr() for s in stats_bufs]) if stats_bufs else None, iarr(flags), _stream()), 'wino_gemm')
+
+    for p in range(npb):
+        if tuple(us[p].shape) != (16, wino_pad_n(n_outs[p]), wino_pad_k(ks[p])):
+            raise ValueError(f'conv3x3_wino: U[{p}] is {tuple(us[p].shape)}, expected '
+                             f'(16, {wino_pad_n(n_outs[p])}, {wino_pad_k(ks[p])})')
+    if TIMER is not None:
+        pix = sum(nb * h * w for h, w in hw)
+        fl = sum(2.0 * pix * n_outs[p] * 9 * ks[p] for p in range(npb))
+        nbytes = 4.0 * sum(sum(s.numel() for s in srcs_list[p]) + sum(o.numel() for o in outs_list[p]) +
+                           us[p].numel() * 9 / 16 for p in range(npb))
+        TIMER.time(f'conv_nt_wino|m{mode} k3 s1 cs{ks[0]} n{"+".join(str(n) for n in n_outs)} np{nlev} pix{pix} '
+                   f'f{flags[0]}', fl, launch, nbytes=nbytes)
+    else:
+        launch()
+    if stats:
+        return outs_list, stats_bufs
+    return outs_list
+
+
 def _conv_gemm_bf16(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias, flags, masks, outs, remap, stats,
                     ext):
     """bf16 activations: one problem per launch, epilogue flags BIAS / ACCUM / STATS / OUT_F32."""

@@ -1,0 +1,163 @@
+"""GPU parity of the Winograd F(2x2,3x3) path (csrc/winograd.hip) through the C ABI.
+
+Three references, tolerance at each assert:
+  * torch fp64 `conv2d` on the CPU (the reference's nn.Conv2d, head.py:20-36 / 55-70, in double precision),
+  * the direct implicit-GEMM kernel `sacv_conv2d_gemm` on the same inputs (already pinned to the reference fixtures),
+  * the yardstick: torch fp32 `conv2d` against the same fp64 result -- the Winograd error must stay within 4x of the
+    error the reference's own fp32 arithmetic makes.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import synth
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'GPU tests need the MI355X'
+    from sacv_amd import ops as _ops
+    return _ops
+
+
+def rnd(seed, *shape, std=1.0):
+    return torch.from_numpy(synth.normal(seed, shape, std))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+LEVELS = [(13, 21), (7, 11), (4, 6), (2, 3), (1, 2)]  # odd and even sizes, a 1-row level
+
+
+def test_weight_transform_matches_G_w_Gt(ops):
+    w = rnd(1, 12, 8, 3, 3, std=0.3)
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    ref = torch.einsum('ik,nckl,jl->ijnc', G, w.double(), G).reshape(16, 12, 8)
+    panel = w.permute(0, 2, 3, 1).contiguous().cuda()  # [N][9][K]
+    full = ops.wino_weights(panel, 12, 8).cpu()
+    assert full.shape == (16, 128, 32)  # zero-padded to the GEMM's 128 x 32 operand tiles
+    got = full[:, :12, :8]
+    assert rel(got, ref) < 2e-7
+    assert float(full.abs().sum()) == float(got.abs().sum())
+    # data-gradient panel [Cin][9][Cout] with the taps rotated by 180 degrees
+    wd = w.flip(2, 3).permute(1, 0, 2, 3)  # [ci][co][kh][kw] of the transposed convolution
+    refd = torch.einsum('ik,nckl,jl->ijnc', G, wd.double(), G).reshape(16, 8, 12)
+    paneld = w.permute(1, 2, 3, 0).contiguous().cuda()  # unflipped [ci][9][co]
+    gotd = ops.wino_weights(paneld, 8, 12, flip=True).cpu()[:, :8, :12]
+    assert rel(gotd, refd) < 2e-7
+
+
+def test_input_transform_matches_Bt_d_B(ops):
+    nb, c = 2, 8
+    xs = [rnd(10 + l, nb, c, h, w) for l, (h, w) in enumerate(LEVELS)]
+    vfull = ops.wino_input([nhwc(x) for x in xs]).cpu()
+    t, tpad = ops.wino_tiles(nb, LEVELS)
+    assert vfull.shape == (16, tpad, 32)  # channels zero-padded to the 32-wide K tile
+    assert float(vfull[:, :, c:].abs().max()) == 0.0
+    v = vfull[:, :, :c]
+    BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float64)
+    row = 0
+    for x, (h, w) in zip(xs, LEVELS):
+        th, tw = (h + 1) // 2, (w + 1) // 2
+        xp = F.pad(x.double(), (1, 2 * tw + 2 - w - 1, 1, 2 * th + 2 - h - 1))
+        patches = xp.unfold(2, 4, 2).unfold(3, 4, 2)  # [nb][c][th][tw][4][4]
+        ref = torch.einsum('ir,nchwrs,js->ijnhwc', BT, patches, BT).reshape(16, nb * th * tw, c)
+        assert torch.equal(v[:, row:row + nb * th * tw].double(), ref.to(torch.float32).double()) or \
+            rel(v[:, row:row + nb * th * tw], ref) < 1e-7
+        row += nb * th * tw
+    assert row == t
+    assert float(v[:, t:].abs().max()) == 0.0 if tpad > t else True
+
+
+@pytest.mark.parametrize('cin,cout,flag_name', [(64, 64, 'bias_relu'), (40, 36, 'bias'), (256, 144, 'sigmoid'),
+                                                (64, 260, 'none')])
+def test_forward_vs_fp64_and_direct(ops, cin, cout, flag_name):
+    nb = 2
+    xs = [rnd(20 + l, nb, cin, h, w) for l, (h, w) in enumerate(LEVELS)]
+    w = rnd(30, cout, cin, 3, 3, std=(2.0 / (9 * cin)) ** 0.5)
+    b = rnd(31, cout, std=0.2)
+    flags = {'bias_relu': ops.CF_RELU, 'bias': 0, 'sigmoid': ops.CF_SIGMOID, 'none': 0}[flag_name]
+    bias = None if flag_name == 'none' else b.cuda()
+    panel = w.permute(0, 2, 3, 1).contiguous().cuda()
+    u = ops.wino_weights(panel, cout, cin)
+    srcs = [nhwc(x) for x in xs]
+    got = ops.conv3x3_wino([srcs], [u], [cout], biases=[bias], flags=[flags])[0]
+    direct = ops.conv_gemm(srcs, panel, cout, 3, 3, 1, 1, 0, LEVELS, bias=bias, flags=flags)
+    for x, g, d in zip(xs, got, direct):
+        def post(y):
+            if flag_name == 'bias_relu':
+                return y.relu()
+            if flag_name == 'sigmoid':
+                return y.sigmoid()
+            return y
+        ref64 = post(F.conv2d(x.double(), w.double(), None if bias is None else b.double(), padding=1))
+        ref32 = post(F.conv2d(x, w, None if bias is None else b, padding=1))
+        e_w, e_d, e_32 = rel(nchw(g), ref64), rel(nchw(d), ref64), rel(ref32, ref64)
+        assert e_w < 4 * max(e_32, e_d) + 1e-7, (e_w, e_d, e_32)
+        assert e_w < 2e-6, e_w
+        assert torch.allclose(nchw(g), nchw(d), rtol=2e-5, atol=2e-5 * float(ref64.abs().max()))
+
+
+def test_data_gradient_mask_stats_accum_two_problems(ops):
+    """Two problems of different widths in one launch, data-gradient operands (flipped U), ReLU-mask + column sums on
+    the first, accumulate on the second -- the epilogues the head towers use (engine._tower_bwd)."""
+    nb, cout, cin = 2, 72, 64
+    dys_a = [rnd(40 + l, nb, cout, h, w) for l, (h, w) in enumerate(LEVELS)]
+    dys_b = [rnd(50 + l, nb, 36, h, w) for l, (h, w) in enumerate(LEVELS)]
+    wa = rnd(60, cout, cin, 3, 3, std=0.05)
+    wb = rnd(61, 36, cin, 3, 3, std=0.05)
+    masks = [rnd(70 + l, nb, cin, h, w) for l, (h, w) in enumerate(LEVELS)]
+    prev = [rnd(80 + l, nb, cin, h, w) for l, (h, w) in enumerate(LEVELS)]
+    ua = ops.wino_weights(wa.permute(1, 2, 3, 0).contiguous().cuda(), cin, cout, flip=True)
+    ub = ops.wino_weights(wb.permute(1, 2, 3, 0).contiguous().cuda(), cin, 36, flip=True)
+    outs_b = [nhwc(p) for p in prev]
+    (ga, gb), (sa, sb) = ops.conv3x3_wino([[nhwc(d) for d in dys_a], [nhwc(d) for d in dys_b]], [ua, ub], [cin, cin],
+                                          flags=[ops.CF_MASK, ops.CF_ACCUM],
+                                          masks_list=[[nhwc(m) for m in masks], None],
+                                          outs_list=[[torch.empty((nb, h, w, cin), device='cuda')
+                                                      for h, w in LEVELS], outs_b],
+                                          stats=True, mode=1)
+    col = torch.zeros(cin, dtype=torch.float64)
+    for dy, m, g in zip(dys_a, masks, ga):
+        ref = F.conv_transpose2d(dy.double(), wa.double(), padding=1) * (m > 0)
+        assert rel(nchw(g), ref) < 2e-6
+        col += ref.sum(dim=(0, 2, 3))
+    got_col = sa[:, 0, :].double().sum(0).cpu()
+    assert rel(got_col, col) < 1e-5
+    for dy, p, g in zip(dys_b, prev, gb):
+        ref = F.conv_transpose2d(dy.double(), wb.double(), padding=1) + p.double()
+        assert rel(nchw(g), ref) < 2e-6
+    # column sums of the accumulate problem count the stored (accumulated) values
+    tot = sum(nchw(g).double().sum(dim=(0, 2, 3)) for g in gb)
+    assert rel(sb[:, 0, :].double().sum(0).cpu(), tot) < 1e-5
+
+
+def test_head_tower_shape_is_deterministic(ops):
+    """The full-size launch of the headline workload (5 levels of 2 x 800x1333, 256 -> 256): two runs are bit-identical
+    and agree with the direct kernel."""
+    nb, c = 2, 256
+    hw = [(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)]
+    g = torch.Generator(device='cuda').manual_seed(5)
+    srcs = [torch.randn((nb, h, w, c), device='cuda', generator=g) for h, w in hw]
+    w = torch.randn((c, 3, 3, c), device='cuda', generator=g) * (2.0 / (9 * c)) ** 0.5
+    b = torch.randn(c, device='cuda', generator=g) * 0.1
+    u = ops.wino_weights(w, c, c)
+    o1 = ops.conv3x3_wino([srcs], [u], [c], biases=[b], flags=[ops.CF_RELU])[0]
+    o2 = ops.conv3x3_wino([srcs], [u], [c], biases=[b], flags=[ops.CF_RELU])[0]
+    d = ops.conv_gemm(srcs, w, c, 3, 3, 1, 1, 0, hw, bias=b, flags=ops.CF_RELU)
+    for a, bb, dd in zip(o1, o2, d):
+        assert torch.equal(a, bb)
+        assert rel(a, dd) < 3e-6

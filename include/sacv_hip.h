@@ -65,12 +65,15 @@ int sacv_conv2d_gemm_stats_rows(int nprob, const int* Nb, const int* Hd, const i
  *      matrix-core flops than sacv_conv2d_gemm; same results up to fp32 rounding. ----------------------------- */
 /* tiles of 2x2 output pixels over the pyramid: sum_l Nb * ceil(H[l]/2) * ceil(W[l]/2) */
 int sacv_wino_tiles(int nlev, int Nb, const int* H, const int* W /*host arrays*/);
-/* U[16][N][K] = G w G^T from a GEMM panel [N][9][K] (forward panel; data-gradient panel with flip = 1) */
+/* U[16][pad_n(N)][pad_k(K)] = G w G^T from a GEMM panel [N][9][K] (forward panel; data-gradient panel with flip = 1) */
 int sacv_wino_weights(const float* panel, float* U, int N, int K, int flip, void* stream);
-/* V[16][Tpad][C] = B^T d B of every 4x4 input patch; Tpad = tiles rounded up to a multiple of 64 */
+/* V[16][Tpad][pad_k(C)] = B^T d B of every 4x4 input patch; Tpad = tiles rounded up to a multiple of 64 */
 int sacv_wino_input(int nlev, const float* const* src /*host array*/, int Nb, const int* H, const int* W, int C,
                     float* V, int Tpad, void* stream);
 int sacv_wino_stats_rows(int tiles);
+/* operand padding of U / V: K (input channels) to a multiple of 32, N (rows of U) to a multiple of 128, zero-filled */
+int sacv_wino_pad_k(int K);
+int sacv_wino_pad_n(int N);
 /* nprob (1 or 2) independent convolutions over the same pyramid geometry (e.g. layer i of both head towers):
  * dst[p*5 + l] = [Nb][H[l]][W[l]][N[p]]; flags[p] = SACV_CF_* bits; mask[p*5 + l] with SACV_CF_MASK;
  * stats[p] = [sacv_wino_stats_rows][2][N[p]] with SACV_CF_STATS */
@@ -79,6 +82,14 @@ int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, cons
                    const float* const* bias /*host array or NULL*/, float* const* dst /*host array [nprob*5]*/,
                    const float* const* mask /*host array [nprob*5] or NULL*/, float* const* stats /*host array or NULL*/,
                    const int* flags, void* stream);
+
+/* weight gradient on the same path: dw (+)= G^T [ sum_tiles (A dY A^T) (x) V ] G from V = sacv_wino_input(x) kept
+ * from the forward pass and dy[l] = [Nb][H[l]][W[l]][Cout]; 16 split-K GEMMs in one launch + a fixed-order reduction
+ * (deterministic).  dw_layout as sacv_conv2d_wgrad.  Cin (padded to 32) must be a multiple of 64. */
+long long sacv_wino_wgrad_workspace_bytes(int Tpad, int Cout, int Cin);
+int sacv_wino_wgrad(int nlev, const float* const* dy /*host array*/, int Nb, const int* H, const int* W, int Cout,
+                    const float* V, int Tpad, int Cin, float* dw, int accumulate, int dw_layout, float* workspace,
+                    void* stream);
 
 long long sacv_conv2d_wgrad_workspace_bytes(int nseg, const int* Nb, const int* Ho, const int* Wo, int Cin_pad,
                                             int Cout, int KH, int KW, int chunk);

@@ -50,6 +50,13 @@ def main():
         print(f'{cin}->{cout} pix {pix}: direct {t_d*1e3:.0f} us ({fl/t_d/1e9:.1f} TF)  wino {t_w*1e3:.0f} us '
               f'({fl/t_w/1e9:.1f} TF-eq) = input {t_in*1e3:.0f} + gemm {t_g*1e3:.0f}; weights {t_u*1e3:.0f} us',
               flush=True)
+        if cin == 256:
+            gys = [torch.randn((nb, h, w, cout), device='cuda', generator=g) for h, w in hw]
+            dw = torch.empty((cout, 3, 3, cin), device='cuda').permute(0, 3, 1, 2)
+            t_wd = timeit(lambda: ops.conv_wgrad(gys, srcs, dw, cin, 3, 3, 1, 1))
+            t_ww = timeit(lambda: ops.wino_wgrad(gys, v, dw, cin))
+            print(f'   weight gradient: direct {t_wd*1e3:.0f} us ({fl/t_wd/1e9:.1f} TF)  wino {t_ww*1e3:.0f} us '
+                  f'({fl/t_ww/1e9:.1f} TF-eq)', flush=True)
         if cin == cout:
             srcs2 = [torch.randn((nb, h, w, cin), device='cuda', generator=g) for h, w in hw]
             t_2 = timeit(lambda: ops.conv3x3_wino([srcs, srcs2], [u, u], [cout, cout], biases=[b, b],

@@ -568,6 +568,269 @@ __global__ __launch_bounds__(256, 2) void wino_gemm_kernel(const WinoArgs a) {
   }
 }
 
+// -------------------------------------------------------------------------------------------- weight gradient
+// dU_g[n][c] = sum_t dM_g[t][n] V_g[t][c] with dM = A dY A^T (the 2x2 output-gradient tile expanded to 4x4), then
+// dW = G^T dU G: 16 split-K (over tiles) TN GEMMs in one launch, 2.25x fewer matrix-core flops than conv_tn_kernel.
+struct WinoDyArgs {
+  WinoGeom g;
+  const float* dy[WINO_MAXL];  // per level [Nb][H][W][N]
+  float* dM;                   // [16][Tpad][N]
+  int N, T, Tpad;
+};
+
+__global__ __launch_bounds__(256) void wino_dy_kernel(const WinoDyArgs a) {
+  const int c4n = a.N >> 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)a.Tpad * c4n) return;
+  const int t = (int)(idx / c4n), c4 = (int)(idx - (long long)t * c4n);
+  const size_t gs = (size_t)a.Tpad * a.N;
+  float* o = a.dM + (size_t)t * a.N + c4 * 4;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  if (t >= a.T) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) *reinterpret_cast<f32x4*>(o + g * gs) = z;
+    return;
+  }
+  const WinoTile tl = wino_tile(a.g, t);
+  const float* src = a.dy[0];
+  int H = a.g.H[0], W = a.g.W[0];
+#pragma unroll
+  for (int l = 1; l < WINO_MAXL; ++l)
+    if (tl.lev == l) {
+      src = a.dy[l];
+      H = a.g.H[l];
+      W = a.g.W[l];
+    }
+  const int h0 = 2 * tl.ty, w0 = 2 * tl.tx;
+  const float* base = src + (((long long)tl.n * H + h0) * W + w0) * a.N + c4 * 4;
+  const bool hv = h0 + 1 < H, wv = w0 + 1 < W;
+  const f32x4 d00 = *reinterpret_cast<const f32x4*>(base);
+  const f32x4 d01 = wv ? *reinterpret_cast<const f32x4*>(base + a.N) : z;
+  const f32x4 d10 = hv ? *reinterpret_cast<const f32x4*>(base + (long long)W * a.N) : z;
+  const f32x4 d11 = (hv && wv) ? *reinterpret_cast<const f32x4*>(base + ((long long)W + 1) * a.N) : z;
+  // rows: A d = (d0, d0 + d1, d0 - d1, -d1); then the same along the columns
+  const f32x4 r[4][2] = {{d00, d01}, {d00 + d10, d01 + d11}, {d00 - d10, d01 - d11}, {-d10, -d11}};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 0) * gs) = r[i][0];
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 1) * gs) = r[i][0] + r[i][1];
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 2) * gs) = r[i][0] - r[i][1];
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 3) * gs) = -r[i][1];
+  }
+}
+
+struct WinoWgradArgs {
+  const float* dM;  // [16][Tpad][Cout]
+  const float* V;   // [16][Tpad][Kp]
+  float* part;      // [nchunks][Cout][16 * Kp]
+  int Tpad, Cout, Kp;
+  int nchunks, chunk;  // tile rows per split (multiple of 32)
+};
+
+// Same tile engine as conv_tn_kernel (conv_gemm.hip): 32-row K tiles of both operands staged [32][BM] / [32][BN] in
+// LDS, register prefetch of the next tile, interleaved b64 fragment reads; the operands are plain row-major matrices
+// here (no spatial gather).  A workgroup = (Cout tile, (g, Cin) tile, split of the tile rows); Kp % BN == 0, so a
+// tile never straddles two g.
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(const WinoWgradArgs a) {
+  constexpr int RA = BM / 32, RB = BN / 32;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                // [2][32][BM]
+  float* sB = smem + 2 * 32 * BM;  // [2][32][BN]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int N2 = 16 * a.Kp;
+  const int ntm = (a.Cout + BM - 1) / BM;
+  const int ntn = N2 / BN;
+  int bid = blockIdx.x;
+  const int tm = bid % ntm;
+  bid /= ntm;
+  const int tn = bid % ntn;
+  const int ck = bid / ntn;
+  const int pix0 = ck * a.chunk;
+  const int pix1 = min(pix0 + a.chunk, a.Tpad);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int g = n0 / a.Kp, c0 = n0 - g * a.Kp;
+  const float* __restrict__ dm = a.dM + (size_t)g * a.Tpad * a.Cout;
+  const float* __restrict__ v = a.V + (size_t)g * a.Tpad * a.Kp + c0;
+
+  constexpr int CGA = BM / 4, RSA = 256 / CGA;
+  constexpr int CGB = BN / 4, RSB = 256 / CGB;
+  const int ca = tid % CGA, rra = tid / CGA;
+  const int cb = tid % CGB, rrb = tid / CGB;
+  const int co = m0 + ca * 4;
+  const bool co_ok = co < a.Cout;  // Cout % 4 == 0
+
+  f32x4 ra[RA], rb[RB];
+  auto load_a = [&](int i, int p0) {
+    const int pix = p0 + rra + i * RSA;
+    const float* ptr = dm + (unsigned)(pix * a.Cout + co);
+    ptr = co_ok ? ptr : wino_zero16;
+    ra[i] = *reinterpret_cast<const f32x4*>(ptr);
+  };
+  auto load_b = [&](int i, int p0) {
+    const int pix = p0 + rrb + i * RSB;
+    rb[i] = *reinterpret_cast<const f32x4*>(v + (unsigned)(pix * a.Kp + cb * 4));
+  };
+  auto store_tile = [&](int buf) {
+    float* dA = sA + buf * 32 * BM;
+    float* dB = sB + buf * 32 * BN;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(dA + (rra + i * RSA) * BM + ca * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(dB + (rrb + i * RSB) * BN + cb * 4) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int KT = (pix1 - pix0) >> 5;  // chunk and Tpad are multiples of 32
+  if (KT > 0) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) load_a(i, pix0);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) load_b(i, pix0);
+    store_tile(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool have_next = kt + 1 < KT;
+    const int pnext = have_next ? pix0 + ((kt + 1) << 5) : pix0;  // the last prefetch re-reads a valid tile, unused
+    const float* cA = sA + cur * 32 * BM + wm0 + (TM == 2 ? 2 * l31 : l31);
+    const float* cB = sB + cur * 32 * BN + wn0 + (TN == 2 ? 2 * l31 : l31);
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto read_a = [&](float (&dst)[TM], int krow) {
+      if (TM == 2) {
+        f32x2 q = *reinterpret_cast<const f32x2*>(cA + krow * BM);
+        dst[0] = q[0];
+        dst[TM - 1] = q[1];
+      } else {
+        dst[0] = cA[krow * BM];
+      }
+    };
+    auto read_b = [&](float (&dst)[TN], int krow) {
+      if (TN == 2) {
+        f32x2 q = *reinterpret_cast<const f32x2*>(cB + krow * BN);
+        dst[0] = q[0];
+        dst[TN - 1] = q[1];
+      } else {
+        dst[0] = cB[krow * BN];
+      }
+    };
+    float fa[2][TM], fb[2][TN];
+    read_a(fa[0], lh);
+    read_b(fb[0], lh);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int cbuf = s & 1, nbuf = cbuf ^ 1;
+      if (s < 15) {
+        read_a(fa[nbuf], 2 * (s + 1) + lh);
+        read_b(fb[nbuf], 2 * (s + 1) + lh);
+      }
+      if ((s & 3) == 0 && (s >> 2) < RA) load_a(s >> 2, pnext);
+      if ((s & 3) == 2 && (s >> 2) < RB) load_b(s >> 2, pnext);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cbuf][i], fb[cbuf][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int m = 0; m < TM * TN; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if (m < 2) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        if (m == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (have_next) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  constexpr int CS = BN + 4;
+  float* stage = smem;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ri = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = wm0 + (TM == 2 ? 2 * ri + i : ri);
+        const int col = wn0 + (TN == 2 ? 2 * l31 + j : l31);
+        stage[row * CS + col] = acc[i][j][r];
+      }
+  __syncthreads();
+  float* __restrict__ part = a.part + (size_t)ck * a.Cout * N2;
+  constexpr int CG = BN / 4, RS = 256 / CG;
+  const int c4 = tid % CG, rr = tid / CG;
+  const int n = n0 + c4 * 4;
+#pragma unroll 4
+  for (int row = rr; row < BM; row += RS) {
+    const int m = m0 + row;
+    if (m < a.Cout)
+      *reinterpret_cast<f32x4*>(part + (size_t)m * N2 + n) = *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4);
+  }
+}
+
+// dw[co][kh][kw][ci] (channels_last, dw_ohwi = 1) or [co][ci][kh][kw] (=)/(+=) (G^T dU G)[kh][kw], dU summed over the
+// splits in a fixed order.  One thread per (co, 4 input channels).
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                 int nchunks, int Cout, int Cin, int Kp, int accumulate,
+                                                                 int dw_ohwi) {
+  const int c4n = Cin >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Cout * c4n) return;
+  const int co = idx / c4n, ci = (idx - co * c4n) * 4;
+  const size_t N2 = (size_t)16 * Kp, slab = (size_t)Cout * N2;
+  f32x4 u[4][4];
+#pragma unroll
+  for (int g = 0; g < 16; ++g) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const float* p = part + (size_t)co * N2 + (size_t)g * Kp + ci;
+    for (int c = 0; c < nchunks; ++c) s += *reinterpret_cast<const f32x4*>(p + c * slab);
+    u[g >> 2][g & 3] = s;
+  }
+  f32x4 t[3][4];  // G^T u: rows kh = (u0 + (u1 + u2)/2, (u1 - u2)/2, u3 + (u1 + u2)/2)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x4 hs = 0.5f * (u[1][j] + u[2][j]);
+    t[0][j] = u[0][j] + hs;
+    t[1][j] = 0.5f * (u[1][j] - u[2][j]);
+    t[2][j] = u[3][j] + hs;
+  }
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const f32x4 hs = 0.5f * (t[kh][1] + t[kh][2]);
+    const f32x4 w3[3] = {t[kh][0] + hs, 0.5f * (t[kh][1] - t[kh][2]), t[kh][3] + hs};
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      if (dw_ohwi) {
+        float* o = dw + ((size_t)co * 9 + kh * 3 + kw) * Cin + ci;
+        f32x4 val = w3[kw];
+        if (accumulate) val += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = val;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float* o = dw + ((size_t)co * Cin + ci + e) * 9 + kh * 3 + kw;
+          *o = accumulate ? *o + w3[kw][e] : w3[kw][e];
+        }
+      }
+    }
+  }
+}
+
 #ifndef WINO_DMA
 #define WINO_DMA 1  // tuning builds: -DWINO_DMA=0 selects the register-staged main loop
 #endif
@@ -731,6 +994,103 @@ int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, cons
   if (grid > items) grid = items;
   hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, DMA>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
   SACV_CHECK_LAUNCH("wino_gemm_kernel");
+  return SACV_OK;
+}
+
+// Workspace of sacv_wino_wgrad in bytes: dM [16][Tpad][Cout] followed by the split slabs [nchunks][Cout][16 * Kp].
+static int wino_wgrad_plan(int Tpad, int Cout, int Kp, int* BNout, int* chunk_out) {
+  const int BN = (Kp % 128 == 0) ? 128 : 64;
+  const int tiles = ((Cout + 127) / 128) * (16 * Kp / BN);
+  const int slots = 2 * wino_num_cus();
+  int best = 1;
+  double best_cost = 1e30;
+  for (int c = 1; c <= 32; ++c) {
+    const int chunk = ((Tpad + c - 1) / c + 31) / 32 * 32;
+    if (chunk < 256 && c > 1) break;
+    const int n = (Tpad + chunk - 1) / chunk;
+    const double rounds = (double)(((long long)tiles * n + slots - 1) / slots);
+    const double cost = rounds * (chunk + 48.0) + 0.02 * n * 32;  // + epilogue per workgroup + slab traffic
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = chunk;
+    }
+  }
+  *BNout = BN;
+  *chunk_out = best;
+  return (Tpad + best - 1) / best;
+}
+
+long long sacv_wino_wgrad_workspace_bytes(int Tpad, int Cout, int K) {
+  if (Tpad <= 0 || Cout <= 0 || K <= 0) return -1;
+  const int Kp = sacv_wino_pad_k(K);
+  int BN, chunk;
+  const int n = wino_wgrad_plan(Tpad, Cout, Kp, &BN, &chunk);
+  return 4LL * ((long long)16 * Tpad * Cout + (long long)n * Cout * 16 * Kp);
+}
+
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution over a pyramid: dw (+)= sum over levels x (*) dy, from
+// V = sacv_wino_input(x) (kept from the forward pass) and the output gradients dy[l] = [Nb][H[l]][W[l]][Cout].
+// dw_layout 0: OIHW, 1: [Cout][3][3][Cin] (channels_last).  Cin must be a multiple of 64.
+int sacv_wino_wgrad(int nlev, const float* const* dy, int Nb, const int* H, const int* W, int Cout, const float* V,
+                    int Tpad, int Cin, float* dw, int accumulate, int dw_layout, float* workspace, void* stream) {
+  WinoDyArgs d;
+  int rc = wino_fill_geom(d.g, nlev, Nb, H, W, "wino_wgrad");
+  if (rc != SACV_OK) return rc;
+  d.T = d.g.tile_begin[WINO_MAXL];
+  SACV_CHECK_ARG(V && dw && workspace, "wino_wgrad: null pointer");
+  SACV_CHECK_ARG(Cout > 0 && Cout % 4 == 0 && Cin > 0 && Cin % 4 == 0, "wino_wgrad: Cout=%d Cin=%d must be multiples of 4",
+                 Cout, Cin);
+  const int Kp = sacv_wino_pad_k(Cin);
+  SACV_CHECK_ARG(Kp % 64 == 0, "wino_wgrad: Cin=%d padded to %d is not a multiple of 64 (use sacv_conv2d_wgrad)", Cin, Kp);
+  SACV_CHECK_ARG(Tpad >= d.T && Tpad % 64 == 0, "wino_wgrad: Tpad");
+  SACV_CHECK_ARG((long long)Tpad * Cout * 16 < (1LL << 30) && (long long)Tpad * Kp * 16 < (1LL << 30) &&
+                     (long long)Cout * Kp * 16 < (1LL << 30),
+                 "wino_wgrad: operand too large for 32-bit element indexing");
+  for (int l = 0; l < WINO_MAXL; ++l) {
+    d.dy[l] = l < nlev ? dy[l] : nullptr;
+    SACV_CHECK_ARG(l >= nlev || dy[l], "wino_wgrad: null level pointer");
+    SACV_CHECK_ARG(l >= nlev || (long long)Nb * H[l] * W[l] * Cout < (1LL << 30), "wino_wgrad: level too large");
+  }
+  hipStream_t st = (hipStream_t)stream;
+  d.dM = workspace;
+  d.N = Cout;
+  d.Tpad = Tpad;
+  const long long total = (long long)Tpad * (Cout / 4);
+  hipLaunchKernelGGL(wino_dy_kernel, dim3(sacv_cdiv(total, 256)), dim3(256), 0, st, d);
+  SACV_CHECK_LAUNCH("wino_dy_kernel");
+
+  WinoWgradArgs a;
+  int BN;
+  a.nchunks = wino_wgrad_plan(Tpad, Cout, Kp, &BN, &a.chunk);
+  a.dM = workspace;
+  a.V = V;
+  a.part = workspace + (size_t)16 * Tpad * Cout;
+  a.Tpad = Tpad;
+  a.Cout = Cout;
+  a.Kp = Kp;
+  const int grid = ((Cout + 127) / 128) * (16 * Kp / BN) * a.nchunks;
+  if (BN == 128) {
+    const int lds = 2 * 32 * (128 + 128) * 4 > 128 * 132 * 4 ? 2 * 32 * (128 + 128) * 4 : 128 * 132 * 4;
+    static std::once_flag once;
+    std::call_once(once, [lds] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel<128, 128>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    });
+    hipLaunchKernelGGL((wino_wgrad_kernel<128, 128>), dim3(grid), dim3(256), lds, st, a);
+  } else {
+    const int lds = 2 * 32 * (128 + 64) * 4 > 128 * 68 * 4 ? 2 * 32 * (128 + 64) * 4 : 128 * 68 * 4;
+    static std::once_flag once;
+    std::call_once(once, [lds] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel<128, 64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    });
+    hipLaunchKernelGGL((wino_wgrad_kernel<128, 64>), dim3(grid), dim3(256), lds, st, a);
+  }
+  SACV_CHECK_LAUNCH("wino_wgrad_kernel");
+  const int rtotal = Cout * (Cin / 4);
+  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(sacv_cdiv(rtotal, 256)), dim3(256), 0, st, a.part, dw, a.nchunks, Cout,
+                     Cin, Kp, accumulate, dw_layout);
+  SACV_CHECK_LAUNCH("wino_wgrad_reduce_kernel");
   return SACV_OK;
 }
 

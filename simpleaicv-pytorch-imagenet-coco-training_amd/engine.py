@@ -378,27 +378,52 @@ class DetectorEngine:
     def _towers_fwd_wino(self, feats, ctx, n_cls, n_reg):
         """RetinaClsHead / RetinaRegHead (head.py:20-36, 55-70) with layer i of BOTH towers in one Winograd launch
         (the towers are independent chains over the same pyramid: 2 x 352 work items fill the 512 workgroup slots
-        better than 352).  Layer 0 of the two towers reads the same input: one input transform."""
+        better than 352).  Layer 0 of the two towers reads the same input: one input transform.  When the pass is
+        kept for a backward, every layer's transformed input V stays alive for its weight gradient."""
         p = self.p
+        keep = ctx is not None
         xs = [feats, feats]
-        saved = [[], []]
-        v0 = ops.wino_input(feats, tag='wino_v0')
+        saved, vsaved = [[], []], [[], []]
         for li, i in enumerate((0, 2, 4, 6)):
             names = [f'{t}.{i}' for t, _ in self.RETINA_TOWERS]
-            saved[0].append(xs[0])
-            saved[1].append(xs[1])
+            vs = self._wino_inputs(xs, keep, shared=li == 0)
+            for t in range(2):
+                saved[t].append(xs[t])
+                vsaved[t].append(vs[t])
             xs = ops.conv3x3_wino(xs, [self._wino_u(p[n + '.weight']) for n in names], [self.planes] * 2,
-                                  biases=[p[n + '.bias'] for n in names], flags=[CF_RELU] * 2,
-                                  vs=[v0, v0] if li == 0 else None)
-        saved[0].append(xs[0])
-        saved[1].append(xs[1])
+                                  biases=[p[n + '.bias'] for n in names], flags=[CF_RELU] * 2, vs=vs)
         names = [o for _, o in self.RETINA_TOWERS]
+        vs = self._wino_inputs(xs, keep)
+        for t in range(2):
+            saved[t].append(xs[t])
+            vsaved[t].append(vs[t])
         outs = ops.conv3x3_wino(xs, [self._wino_u(p[n + '.weight']) for n in names], [n_cls, n_reg],
-                                biases=[p[n + '.bias'] for n in names], flags=[CF_SIGMOID, 0])
-        if ctx is not None:
-            ctx[self.RETINA_TOWERS[0][0]] = saved[0]
-            ctx[self.RETINA_TOWERS[1][0]] = saved[1]
+                                biases=[p[n + '.bias'] for n in names], flags=[CF_SIGMOID, 0], vs=vs)
+        if keep:
+            for t in range(2):
+                ctx[self.RETINA_TOWERS[t][0]] = saved[t]
+                ctx[self.RETINA_TOWERS[t][0] + '.wino_v'] = vsaved[t]
         return outs
+
+    def _wino_inputs(self, xs2, keep, shared=False):
+        """Transformed inputs of the two towers' next layer: fresh tensors when they are kept for the backward pass,
+        the shared scratch buffers otherwise."""
+        def one(xs, tag):
+            if not keep:
+                return ops.wino_input(xs, tag=tag)
+            nb, c = xs[0].shape[0], xs[0].shape[3]
+            _, tpad = ops.wino_tiles(nb, [(x.shape[1], x.shape[2]) for x in xs])
+            return ops.wino_input(xs, out=torch.empty((16, tpad, ops.wino_pad_k(c)), device=xs[0].device,
+                                                      dtype=torch.float32))
+        v0 = one(xs2[0], 'wino_v0')
+        return [v0, v0 if shared else one(xs2[1], 'wino_v1')]
+
+    def _wino_wgrad(self, dys, xs, v, dw, cin):
+        """3x3 weight gradient: Winograd path from the kept V when the channel count allows it, else conv_tn."""
+        if v is not None and ops.wino_wgrad_supported(cin) and dys[0].shape[3] >= 64:
+            ops.wino_wgrad(dys, v, dw, cin)
+        else:
+            self._wgrad(dys, xs, dw, cin, 3, 3, 1, 1)
 
     # ------------------------------------------------------------------ FCOS heads
     # FCOSClsRegCntHead (head.py:88-181): two towers of 4 x (3x3 conv no bias, GroupNorm(32), ReLU) shared by
@@ -439,13 +464,15 @@ class DetectorEngine:
         """Both FCOS towers in lockstep: layer i of the two towers is one Winograd launch (no bias: GroupNorm follows),
         then GroupNorm + ReLU per level as in _gn_tower_fwd."""
         p = self.p
+        keep = ctx is not None
         xs = [feats, feats]
-        saved = [[], []]
-        v0 = ops.wino_input(feats, tag='wino_v0')
+        saved, vsaved = [[], []], [[], []]
         for li, i in enumerate((0, 3, 6, 9)):
             ws = [p[f'{t}.{i}.weight'] for t in self.FCOS_TOWERS]
-            yss = ops.conv3x3_wino(xs, [self._wino_u(w) for w in ws], [self.planes] * 2,
-                                   vs=[v0, v0] if li == 0 else None)
+            vs = self._wino_inputs(xs, keep, shared=li == 0)
+            vsaved[0].append(vs[0])
+            vsaved[1].append(vs[1])
+            yss = ops.conv3x3_wino(xs, [self._wino_u(w) for w in ws], [self.planes] * 2, vs=vs)
             nxt = []
             for t, tower in enumerate(self.FCOS_TOWERS):
                 zs, sts = [], []
@@ -457,9 +484,10 @@ class DetectorEngine:
                 saved[t].append((xs[t], yss[t], sts, zs))
                 nxt.append(zs)
             xs = nxt
-        if ctx is not None:
-            ctx[self.FCOS_TOWERS[0]] = saved[0]
-            ctx[self.FCOS_TOWERS[1]] = saved[1]
+        if keep:
+            for t in range(2):
+                ctx[self.FCOS_TOWERS[t]] = saved[t]
+                ctx[self.FCOS_TOWERS[t] + '.wino_v'] = vsaved[t]
         return xs
 
     def _fcos_heads_fwd(self, feats, ctx):
@@ -469,8 +497,11 @@ class DetectorEngine:
         w8, b8 = self._fcos_w8()
         if self._use_wino():
             cls_x, reg_x = self._gn_towers_fwd_wino(feats, ctx)
+            vs = self._wino_inputs([cls_x, reg_x], ctx is not None)
+            if ctx is not None:
+                ctx['fcos_out_v'] = vs
             cls, y8 = ops.conv3x3_wino([cls_x, reg_x], [self._wino_u(w), self._wino_u(w8)], [w.shape[0], 8],
-                                       biases=[p['clsregcnt_head.cls_out.bias'], b8], flags=[CF_SIGMOID, 0])
+                                       biases=[p['clsregcnt_head.cls_out.bias'], b8], flags=[CF_SIGMOID, 0], vs=vs)
         else:
             cls_x = self._gn_tower_fwd(feats, 'clsregcnt_head.cls_head', ctx)
             reg_x = self._gn_tower_fwd(feats, 'clsregcnt_head.reg_head', ctx)
@@ -490,6 +521,7 @@ class DetectorEngine:
         """Backward of the two FCOS towers in lockstep (dzs2[t]: per-level grads w.r.t. tower t's output)."""
         p, g = self.p, self.g
         saved = [self.ctx[t] for t in self.FCOS_TOWERS]
+        vsaved = [self.ctx[t + '.wino_v'] for t in self.FCOS_TOWERS]
         cur = dzs2
         for li, i in reversed(list(enumerate((0, 3, 6, 9)))):
             dys2, ws = [], []
@@ -499,7 +531,7 @@ class DetectorEngine:
                 dys = [ops.groupnorm_bwd(y, dz, z, st, p[gname], g[gname], g[bname], 32, accumulate=l > 0)
                        for l, (y, dz, z, st) in enumerate(zip(ys, cur[t], zs, sts))]
                 w = p[f'{tower}.{i}.weight']
-                self._wgrad(dys, xs, g[f'{tower}.{i}.weight'], w.shape[1], 3, 3, 1, 1)
+                self._wino_wgrad(dys, xs, vsaved[t][li], g[f'{tower}.{i}.weight'], w.shape[1])
                 dys2.append(dys)
                 ws.append(w)
             us = [self._wino_u(w, dgrad=True) for w in ws]
@@ -538,7 +570,8 @@ class DetectorEngine:
         dz_cls = [ops.eltwise(ops.EW_SCALE_SIGMOID_BWD, d.reshape(pr.shape), pr, scalar=grad_scale)
                   for d, pr in zip(dcls_levels, o['cls'])]
         w = p['clsregcnt_head.cls_out.weight']
-        self._wgrad(dz_cls, o['cls_x'], g['clsregcnt_head.cls_out.weight'], w.shape[1], 3, 3, 1, 1)
+        vcls = self.ctx['fcos_out_v'][0] if self._use_wino() else None
+        self._wino_wgrad(dz_cls, o['cls_x'], vcls, g['clsregcnt_head.cls_out.weight'], w.shape[1])
         self._bias_grad(dz_cls, 'clsregcnt_head.cls_out')
         # regression + centerness branch (8-channel combined output conv)
         dy8 = [ops.fcos_split_bwd(dr.contiguous(), dc.contiguous(), r, c, p['scales'][l:l + 1], g['scales'], l,
@@ -601,16 +634,17 @@ class DetectorEngine:
         return cur
 
     def _towers_bwd_wino(self, dz_cls, dz_reg):
-        """Backward of the two Retina towers in lockstep: weight gradients on the direct kernel (conv_tn), data
-        gradients on the Winograd path with the ReLU mask and the bias-gradient column sums in the epilogue (as
-        _tower_bwd), layer i of both towers per launch."""
+        """Backward of the two Retina towers in lockstep: weight gradients and data gradients on the Winograd path
+        (ReLU mask and bias-gradient column sums in the data-gradient epilogue, as _tower_bwd), layer i of both towers
+        per data-gradient launch."""
         p, g = self.p, self.g
         towers = self.RETINA_TOWERS
         saved = [self.ctx[t] for t, _ in towers]
+        vsaved = [self.ctx[t + '.wino_v'] for t, _ in towers]
         dys = [dz_cls, dz_reg]
         for t, (_, out_name) in enumerate(towers):
             w = p[out_name + '.weight']
-            self._wgrad(dys[t], saved[t][4], g[out_name + '.weight'], w.shape[1], 3, 3, 1, 1)
+            self._wino_wgrad(dys[t], saved[t][4], vsaved[t][4], g[out_name + '.weight'], w.shape[1])
             self._bias_grad(dys[t], out_name)
         ws = [p[o + '.weight'] for _, o in towers]
         cur, st = ops.conv3x3_wino(dys, [self._wino_u(w, dgrad=True) for w in ws], [self.planes] * 2,
@@ -619,7 +653,7 @@ class DetectorEngine:
             names = [f'{t}.{i}' for t, _ in towers]
             ws = [p[n + '.weight'] for n in names]
             for t in range(2):
-                self._wgrad(cur[t], saved[t][li], g[names[t] + '.weight'], ws[t].shape[1], 3, 3, 1, 1)
+                self._wino_wgrad(cur[t], saved[t][li], vsaved[t][li], g[names[t] + '.weight'], ws[t].shape[1])
                 ops.colsum_finalize(st[t], g[names[t] + '.bias'])
             us = [self._wino_u(w, dgrad=True) for w in ws]
             if li > 0:

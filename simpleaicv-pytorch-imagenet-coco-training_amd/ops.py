@@ -314,6 +314,38 @@ def conv3x3_wino(srcs_list, us, n_outs, biases=None, flags=None, masks_list=None
     return outs_list
 
 
+def wino_wgrad(dys, v, dw, cin, accumulate=False):
+    """dw (logical OIHW view, stored OIHW or channels_last) (+)= x (*) dy of a 3x3 / stride 1 / pad 1 convolution over
+    the pyramid, from v = wino_input(x) of the forward pass and the per-level output gradients dys."""
+    nb, cout = dys[0].shape[0], dys[0].shape[3]
+    hw = [(d.shape[1], d.shape[2]) for d in dys]
+    for d in dys:
+        _chk(d, 'wino_wgrad dy')
+    t, tpad = wino_tiles(nb, hw)
+    if tuple(v.shape) != (16, tpad, wino_pad_k(cin)):
+        raise ValueError(f'wino_wgrad: V is {tuple(v.shape)}, expected (16, {tpad}, {wino_pad_k(cin)})')
+    if tuple(dw.shape) != (cout, cin, 3, 3):
+        raise ValueError(f'wino_wgrad: dw is {tuple(dw.shape)}, expected ({cout}, {cin}, 3, 3)')
+    layout = weight_layout(dw)
+    ws = workspace(lib.sacv_wino_wgrad_workspace_bytes(tpad, cout, cin), dys[0].device, 'wino_wgrad')
+
+    def launch():
+        check(lib.sacv_wino_wgrad(len(dys), parr([d.data_ptr() for d in dys]), nb, iarr([h for h, _ in hw]),
+                                  iarr([w for _, w in hw]), cout, _ptr(v), tpad, cin, _ptr(dw), int(accumulate), layout,
+                                  ws.data_ptr(), _stream()), 'wino_wgrad')
+
+    if TIMER is not None:
+        pix = sum(nb * h * w for h, w in hw)
+        TIMER.time(f'conv_tn_wino|k3 s1 ci{cin} co{cout} np{len(dys)}', 2.0 * pix * cout * 9 * cin, launch)
+    else:
+        launch()
+    return dw
+
+
+def wino_wgrad_supported(cin):
+    return wino_pad_k(cin) % 64 == 0
+
+
 def _conv_gemm_bf16(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias, flags, masks, outs, remap, stats,
                     ext):
     """bf16 activations: one problem per launch, epilogue flags BIAS / ACCUM / STATS / OUT_F32."""

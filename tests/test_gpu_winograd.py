@@ -161,3 +161,30 @@ def test_head_tower_shape_is_deterministic(ops):
     for a, bb, dd in zip(o1, o2, d):
         assert torch.equal(a, bb)
         assert rel(a, dd) < 3e-6
+
+
+@pytest.mark.parametrize('cin,cout,layout', [(64, 64, 'ohwi'), (128, 72, 'oihw'), (64, 260, 'ohwi')])
+def test_weight_gradient_vs_fp64_and_direct(ops, cin, cout, layout):
+    """dw = sum over levels x (*) dy on the Winograd path (V kept from the forward transform) against torch fp64
+    autograd and the direct kernel; both gradient storage layouts; overwrite and accumulate."""
+    nb = 2
+    xs = [rnd(90 + l, nb, cin, h, w) for l, (h, w) in enumerate(LEVELS)]
+    dys = [rnd(95 + l, nb, cout, h, w) for l, (h, w) in enumerate(LEVELS)]
+    ref = torch.zeros(cout, cin, 3, 3, dtype=torch.float64)
+    ref32 = torch.zeros(cout, cin, 3, 3)
+    for x, dy in zip(xs, dys):
+        ref += torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dy.double(), padding=1)
+        ref32 += torch.nn.grad.conv2d_weight(x, (cout, cin, 3, 3), dy, padding=1)
+    srcs, gys = [nhwc(x) for x in xs], [nhwc(d) for d in dys]
+    v = ops.wino_input(srcs, tag='test_keep')
+    dw = torch.empty((cout, cin, 3, 3), device='cuda')
+    if layout == 'ohwi':
+        dw = torch.empty((cout, 3, 3, cin), device='cuda').permute(0, 3, 1, 2)
+    ops.wino_wgrad(gys, v, dw, cin)
+    direct = torch.empty_like(dw)
+    ops.conv_wgrad(gys, srcs, direct, cin, 3, 3, 1, 1)
+    e_w, e_d, e_32 = rel(dw.cpu(), ref), rel(direct.cpu(), ref), rel(ref32, ref)
+    assert e_w < 4 * max(e_d, e_32) + 1e-7, (e_w, e_d, e_32)
+    assert e_w < 3e-6, e_w
+    ops.wino_wgrad(gys, v, dw, cin, accumulate=True)
+    assert rel(dw.cpu(), 2 * ref) < 3e-6

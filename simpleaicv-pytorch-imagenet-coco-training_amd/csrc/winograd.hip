@@ -772,23 +772,29 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(const WinoWgradArgs 
 }
 
 // dw[co][kh][kw][ci] (channels_last, dw_ohwi = 1) or [co][ci][kh][kw] (=)/(+=) (G^T dU G)[kh][kw], dU summed over the
-// splits in a fixed order.  One thread per (co, 4 input channels).
+// splits in a fixed order.  A block = 16 outputs (co, 4 input channels) x 16 g: thread (g, o) sums the splits of its
+// dU_g (coalesced 256-byte rows per g), the 16 sums of an output meet in LDS and 16 threads apply G^T . G.
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                  int nchunks, int Cout, int Cin, int Kp, int accumulate,
                                                                  int dw_ohwi) {
+  __shared__ f32x4 us[16][16];
   const int c4n = Cin >> 2;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Cout * c4n) return;
-  const int co = idx / c4n, ci = (idx - co * c4n) * 4;
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + o;
+  const bool ok = idx < Cout * c4n;
+  const int co = ok ? idx / c4n : 0, ci = ok ? (idx - co * c4n) * 4 : 0;
   const size_t N2 = (size_t)16 * Kp, slab = (size_t)Cout * N2;
-  f32x4 u[4][4];
-#pragma unroll
-  for (int g = 0; g < 16; ++g) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (ok) {
     const float* p = part + (size_t)co * N2 + (size_t)g * Kp + ci;
     for (int c = 0; c < nchunks; ++c) s += *reinterpret_cast<const f32x4*>(p + c * slab);
-    u[g >> 2][g & 3] = s;
   }
+  us[g][o] = s;
+  __syncthreads();
+  if (g != 0 || !ok) return;
+  f32x4 u[4][4];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) u[q >> 2][q & 3] = us[q][o];
   f32x4 t[3][4];  // G^T u: rows kh = (u0 + (u1 + u2)/2, (u1 - u2)/2, u3 + (u1 + u2)/2)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -804,15 +810,15 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
       if (dw_ohwi) {
-        float* o = dw + ((size_t)co * 9 + kh * 3 + kw) * Cin + ci;
+        float* d = dw + ((size_t)co * 9 + kh * 3 + kw) * Cin + ci;
         f32x4 val = w3[kw];
-        if (accumulate) val += *reinterpret_cast<const f32x4*>(o);
-        *reinterpret_cast<f32x4*>(o) = val;
+        if (accumulate) val += *reinterpret_cast<const f32x4*>(d);
+        *reinterpret_cast<f32x4*>(d) = val;
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float* o = dw + ((size_t)co * Cin + ci + e) * 9 + kh * 3 + kw;
-          *o = accumulate ? *o + w3[kw][e] : w3[kw][e];
+          float* d = dw + ((size_t)co * Cin + ci + e) * 9 + kh * 3 + kw;
+          *d = accumulate ? *d + w3[kw][e] : w3[kw][e];
         }
       }
     }
@@ -1079,7 +1085,7 @@ int sacv_wino_wgrad(int nlev, const float* const* dy, int Nb, const int* H, cons
   }
   SACV_CHECK_LAUNCH("wino_wgrad_kernel");
   const int rtotal = Cout * (Cin / 4);
-  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(sacv_cdiv(rtotal, 256)), dim3(256), 0, st, a.part, dw, a.nchunks, Cout,
+  hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(sacv_cdiv(rtotal, 16)), dim3(256), 0, st, a.part, dw, a.nchunks, Cout,
                      Cin, Kp, accumulate, dw_layout);
   SACV_CHECK_LAUNCH("wino_wgrad_reduce_kernel");
   return SACV_OK;

@@ -309,6 +309,31 @@ class DetectorEngine:
         return ops.conv_gemm([x], wp, w.shape[0], k, k, stride, pad, 0, [hw], bias=self.p[name + '.bias'],
                              flags=flags)[0]
 
+    WINO_MIN_TILES = 6000  # a single 3x3 conv goes to the Winograd path from this many 2x2 output tiles (enough
+    #                        64-tile work items to occupy the 256 CUs; below it the direct kernel is faster)
+
+    def _conv3x3_bias(self, x, name, ctx):
+        """3x3 / stride 1 / pad 1 convolution + bias of one level: Winograd path for large levels (P3), else direct."""
+        tiles = x.shape[0] * ((x.shape[1] + 1) // 2) * ((x.shape[2] + 1) // 2)
+        w = self.p[name + '.weight']
+        if not self._use_wino() or tiles < self.WINO_MIN_TILES:
+            return self._conv_bias(x, name, 3, 1, 1)
+        keep = ctx is not None
+        v = self._wino_inputs([[x], [x]], keep, shared=True)[0]
+        if keep:
+            ctx['wino_v:' + name] = v
+        return ops.conv3x3_wino([[x]], [self._wino_u(w)], [w.shape[0]], biases=[self.p[name + '.bias']], vs=[v])[0][0]
+
+    def _conv3x3_bias_bwd(self, dy, x, name):
+        """Backward of _conv3x3_bias: returns dx; fills the weight and bias gradients."""
+        v = self.ctx.get('wino_v:' + name)
+        if v is None:
+            return self._conv_bias_bwd(dy, x, name, 3, 1, 1)
+        w = self.p[name + '.weight']
+        self._wino_wgrad([dy], [x], v, self.g[name + '.weight'], w.shape[1])
+        self._bias_grad([dy], name)
+        return ops.conv3x3_wino([[dy]], [self._wino_u(w, dgrad=True)], [w.shape[1]], mode=1)[0][0]
+
     def _fpn_fwd(self, c3, c4, c5, ctx):
         p5 = self._conv_bias(c5, 'fpn.P5_1', 1, 1, 0)
         p4l = self._conv_bias(c4, 'fpn.P4_1', 1, 1, 0)
@@ -317,7 +342,7 @@ class DetectorEngine:
         p3 = ops.upsample_add_fwd(p4, p3l)
         p5o = self._conv_bias(p5, 'fpn.P5_2', 3, 1, 1)
         p4o = self._conv_bias(p4, 'fpn.P4_2', 3, 1, 1)
-        p3o = self._conv_bias(p3, 'fpn.P3_2', 3, 1, 1)
+        p3o = self._conv3x3_bias(p3, 'fpn.P3_2', ctx)
         p6 = self._conv_bias(p5o if self.fcos else c5, 'fpn.P6', 3, 2, 1)  # use_p5 (fpn.py:80)
         p6r = ops.eltwise(ops.EW_RELU, p6)
         p7 = self._conv_bias(p6r, 'fpn.P7.1', 3, 2, 1)
@@ -767,7 +792,7 @@ class DetectorEngine:
             dc5 = self._conv_bias_bwd(dp6, f['c5'], 'fpn.P6', 3, 2, 1)
         dp5 = self._conv_bias_bwd(dp5o, f['p5'], 'fpn.P5_2', 3, 1, 1)
         dp4 = self._conv_bias_bwd(dp4o, f['p4'], 'fpn.P4_2', 3, 1, 1)
-        dp3 = self._conv_bias_bwd(dp3o, f['p3'], 'fpn.P3_2', 3, 1, 1)
+        dp3 = self._conv3x3_bias_bwd(dp3o, f['p3'], 'fpn.P3_2')
         # P3 = up(P4) + P3_1(C3)
         ops.upsample_bwd(dp3, dp4, accumulate=True)
         dc3 = self._conv_bias_bwd(dp3, f['c3'], 'fpn.P3_1', 1, 1, 0)

@@ -410,7 +410,7 @@ def main():
             # HBM traffic per launch of the same kernel family from the PMC passes committed under profiles/
             # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read-doubling applied there)
             traffic = None
-            for tname in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+            for tname in ('r02b_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
                 tpath = os.path.join(ROOT, 'profiles', tname)
                 if os.path.exists(tpath) and args.model == 'retinanet' and (H, W) == (800, 1333):
                     traffic = round(json.load(open(tpath))['hbm_bytes_per_launch'])
@@ -423,18 +423,41 @@ def main():
             secondary = None
             if tn['launches']:
                 ach = tn['flops'] / (tn['ms'] * 1e-3) / 1e12
-                secondary = dict(kernel='conv_tn_kernel + wgrad_reduce (weight gradient)', bound='mfma',
+                secondary = dict(kernel='weight gradient: conv_tn_kernel + wgrad_reduce (direct), wino_wgrad_kernel + transforms (Winograd, head 3x3 convolutions); algorithmic flops / time', bound='mfma',
                                  achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                                  frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                                  launches_per_step=tn['launches'] // args.steps,
                                  share_of_step_ms=round(tn['ms'] / args.steps, 2))
-            roofline = dict(kernel='conv_nt_kernel<128,{128|64},mode> (implicit-GEMM conv forward + data gradient, fp32 MFMA 32x32x2)',
+            wino = dict(launches=0, flops=0.0, ms=0.0)
+            for name, v in agg.items():
+                if name.startswith('conv_nt_wino'):
+                    for f_ in wino:
+                        wino[f_] += v[f_]
+            paths = None
+            if wino['launches']:
+                d_fl, d_ms = k['flops'] - wino['flops'], k['ms'] - wino['ms']
+                paths = dict(
+                    winograd=dict(calls_per_step=wino['launches'] // args.steps,
+                                  algorithmic_tflops=round(wino['flops'] / (wino['ms'] * 1e-3) / 1e12, 2),
+                                  matrix_core_tflops=round(wino['flops'] / 2.25 / (wino['ms'] * 1e-3) / 1e12, 2),
+                                  share_of_step_ms=round(wino['ms'] / args.steps, 2),
+                                  note='F(2x2,3x3): 2.25x fewer matrix-core flops than the direct sum; time includes '
+                                       'the input transform'),
+                    direct=dict(calls_per_step=(k['launches'] - wino['launches']) // args.steps,
+                                algorithmic_tflops=round(d_fl / (d_ms * 1e-3) / 1e12, 2),
+                                share_of_step_ms=round(d_ms / args.steps, 2)))
+            roofline = dict(kernel='convolution forward + data gradient: conv_nt_kernel<128,{128|64},mode> (implicit GEMM) and, '
+                                   'for the stride-1 3x3 head / P3 convolutions, wino_gemm_kernel<64,128> (Winograd '
+                                   'F(2x2,3x3), 16 chained GEMMs + output transform); fp32 MFMA 32x32x2; `achieved` = '
+                                   'algorithmic (direct-convolution) flops / time',
                             bound='mfma', achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                             frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
                             launches_per_step=k['launches'] // args.steps,
                             avg_launch_ms=round(per_launch_ms, 4), algorithmic_gflop_per_launch=round(
                                 per_launch_flops / 1e9, 2),
                             share_of_step_ms=round(k['ms'] / args.steps, 2))
+            if paths:
+                roofline['paths'] = paths
             if secondary:
                 roofline['second_kernel'] = secondary
         if args.class_table and rank == 0:

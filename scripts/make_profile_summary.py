@@ -23,12 +23,26 @@ def read_stats(path):
     return rows
 
 
-def pmc_per_launch(path, counter, match):
+# kernels of the forward + data-gradient convolution family (bench.py's conv_nt_* timer records): the direct
+# implicit-GEMM kernel with its split-tile fix-up, and the Winograd path (transforms + GEMM).  A "launch" of the family
+# is one convolution call = one dispatch of a main kernel.
+NT_MAIN = ('conv_nt_kernel', 'wino_gemm_kernel')
+NT_AUX = ('conv_fixup_kernel', 'wino_input_kernel', 'wino_weight_kernel')
+TN_FAMILY = ('conv_tn_kernel', 'wgrad_reduce_kernel', 'wino_wgrad_kernel', 'wino_dy_kernel', 'wino_wgrad_reduce_kernel')
+
+
+def pmc_per_launch(path, counter, mains, aux=()):
+    """(sum of the counter over the family's dispatches, number of main-kernel dispatches)."""
     tot, n = 0.0, 0
     for r in csv.DictReader(open(path)):
-        if r['Counter_Name'] == counter and match in r['Kernel_Name']:
+        if r['Counter_Name'] != counter:
+            continue
+        name = r['Kernel_Name']
+        if any(m in name for m in mains):
             tot += float(r['Counter_Value'])
             n += 1
+        elif any(m in name for m in aux):
+            tot += float(r['Counter_Value'])
     return tot, n
 
 
@@ -115,9 +129,10 @@ def main():
         f.write(open(stats_p).read())
     bench = json.loads([l for l in open(bench_p) if l.startswith('{')][-1])
     # PMC traffic of the conv_nt family
-    fs, n1 = pmc_per_launch(pf, 'FETCH_SIZE', 'conv_nt_kernel')
-    ws, n2 = pmc_per_launch(pw, 'WRITE_SIZE', 'conv_nt_kernel')
-    traffic = dict(kernel='conv_nt_kernel<128,*,*>', launches=n1, fetch_size_kb_per_launch=fs / n1,
+    fs, n1 = pmc_per_launch(pf, 'FETCH_SIZE', NT_MAIN, NT_AUX)
+    ws, n2 = pmc_per_launch(pw, 'WRITE_SIZE', NT_MAIN, NT_AUX)
+    traffic = dict(kernel='conv_nt_kernel<128,*,*> + conv_fixup_kernel, wino_gemm_kernel + wino_input_kernel + '
+                          'wino_weight_kernel (per convolution call)', launches=n1, fetch_size_kb_per_launch=fs / n1,
                    write_size_kb_per_launch=ws / n2, hbm_bytes_per_launch=(2 * fs / n1 + ws / n2) * 1024,
                    note='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 2 '
                         '--warmup 1; gfx950 correction: FETCH_SIZE counts 64 B per 128-B request, so reads are doubled '
@@ -135,18 +150,22 @@ def main():
     for name, calls, tot, avg, pct in rows[:30]:
         md.append(f'| `{name[:60]}` | {calls / steps:.1f} | {tot / steps / 1e6:.3f} | {avg / 1e3:.1f} | {pct:.2f} |')
     r = bench['roofline']
-    nt_ms = sum(v[1] for k, v in by.items() if 'conv_nt_kernel' in k) / steps / 1e6
-    nt_calls = sum(v[0] for k, v in by.items() if 'conv_nt_kernel' in k) / steps
-    tn_ms = sum(v[1] for k, v in by.items() if 'conv_tn_kernel' in k) / steps / 1e6
+    fam = lambda names: sum(v[1] for k, v in by.items() if any(n in k for n in names)) / steps / 1e6
+    nt_ms = fam(NT_MAIN + NT_AUX)
+    nt_calls = sum(v[0] for k, v in by.items() if any(n in k for n in NT_MAIN)) / steps
+    tn_ms = fam(TN_FAMILY)
+    wino_ms, direct_ms = fam(('wino_gemm_kernel', 'wino_input_kernel', 'wino_weight_kernel')), fam(('conv_nt_kernel', 'conv_fixup_kernel'))
     md += ['', '## Roofline per kernel class', '',
-           f'* MFMA-bound: `conv_nt_kernel` (forward + data gradient) -- bench.py HIP events: {r["achieved"]} TFLOP/s of {r["peak"]} '
-           f'(fp32 matrix) = {r["frac"]}; avg launch {r["avg_launch_ms"]} ms, {r["algorithmic_gflop_per_launch"]} algorithmic GFLOP/launch '
-           f'({r["launches_per_step"]} launches/step). rocprofv3 over the same kernels: {nt_calls:.0f} launches/step, {nt_ms:.2f} ms/step '
-           f'(avg {nt_ms / nt_calls:.4f} ms; the HIP-event figure also covers the fix-up kernel of split tiles). '
-           f'HBM traffic {traffic["hbm_bytes_per_launch"] / 1e6:.0f} MB/launch (PMC).',
-           f'* MFMA-bound: `conv_tn_kernel` (weight gradient) -- the same algorithmic flops as the forward convolutions '
+           f'* MFMA-bound: convolution forward + data gradient (`conv_nt_kernel` direct, `wino_gemm_kernel` Winograd F(2x2,3x3) for the '
+           f'head 3x3 convolutions) -- bench.py HIP events: {r["achieved"]} ALGORITHMIC TFLOP/s of {r["peak"]} '
+           f'(fp32 matrix) = {r["frac"]}; avg call {r["avg_launch_ms"]} ms, {r["algorithmic_gflop_per_launch"]} algorithmic GFLOP/call '
+           f'({r["launches_per_step"]} convolution calls/step). rocprofv3 over the same kernels (incl. fix-up and Winograd transforms): '
+           f'{nt_calls:.0f} main-kernel launches/step, {nt_ms:.2f} ms/step (avg {nt_ms / nt_calls:.4f} ms): direct {direct_ms:.2f} ms, '
+           f'Winograd {wino_ms:.2f} ms. HBM traffic {traffic["hbm_bytes_per_launch"] / 1e6:.0f} MB/call (PMC).',
+           f'* MFMA-bound: weight gradient (`conv_tn_kernel` direct, `wino_wgrad_kernel` Winograd; with their reductions / transforms) -- '
+           f'the same algorithmic flops as the forward convolutions '
            f'({r["algorithmic_gflop_per_launch"] * r["launches_per_step"] / 2 / 1e3:.3f} TFLOP/step) in {tn_ms:.2f} ms = '
-           f'{r["algorithmic_gflop_per_launch"] * r["launches_per_step"] / 2 / tn_ms:.1f} TFLOP/s, plus `wgrad_reduce`.',
+           f'{r["algorithmic_gflop_per_launch"] * r["launches_per_step"] / 2 / tn_ms:.1f} TFLOP/s.',
            '* HBM-bound classes (algorithmic bytes / rocprof time, peak 8 TB/s spec):', '',
            '| kernel | algorithmic GB/step | ms/step | achieved TB/s | frac of 8 TB/s | bytes counted |', '|---|---|---|---|---|---|']
     extra = [('adamw_gated_kernel', 37968692 * 4 * 7 / 1e9, 'read p,g,m,v write p,m,v'),

@@ -188,3 +188,43 @@ def test_weight_gradient_vs_fp64_and_direct(ops, cin, cout, layout):
     assert e_w < 3e-6, e_w
     ops.wino_wgrad(gys, v, dw, cin, accumulate=True)
     assert rel(dw.cpu(), 2 * ref) < 3e-6
+
+
+@pytest.mark.parametrize('name,crit', [('resnet50_retinanet', 'RetinaLoss'), ('resnet50_fcos', 'FCOSLoss')])
+def test_detector_step_winograd_matches_direct(name, crit):
+    """The whole training forward + backward with the head / P3 convolutions on the Winograd path against the same
+    model on the direct kernels only (engine.winograd = False): losses within 2e-6 relative, every gradient tensor
+    within 2e-4 (RetinaNet) / 1e-3 (FCOS) relative L2 (two fp32 summation orders of the same sums; the direct path is the one pinned to the
+    reference fixtures in test_gpu_fullsize / test_gpu_pinned / test_gpu_trainer)."""
+    from oracle import model as omodel
+    from sacv_amd.detection import models, losses
+    H, W = 544, 736  # P3 = 68 x 92: enough tiles for the P3 smoothing conv to take the Winograd path as well
+    images = torch.tensor(synth.images(7, 2, H, W)).cuda()
+    annots = torch.tensor(synth.annotations(8, 2, H, W, boxes_per_image=6)).cuda()
+    out = {}
+    torch.manual_seed(0)
+    state0 = (omodel.init_retinanet_state(0) if name == 'resnet50_retinanet'
+              else {k: v.clone() for k, v in models.__dict__[name](num_classes=80).state_dict().items()})
+    for wino in (True, False):
+        net = models.__dict__[name](num_classes=80)
+        net.load_state_dict(state0)
+        net = net.cuda().train()
+        net.engine.winograd = wino
+        net.engine.WINO_MIN_TILES = 1000  # P3 = 68 x 92 here: 3128 tiles, below the production threshold
+        criterion = losses.__dict__[crit]()
+        preds = net(images)
+        if wino:  # the context of the kept forward pass lives until backward() consumes it
+            assert any(k.startswith('wino_v:') for k in net.engine.ctx), 'P3 smoothing conv not on the Winograd path'
+        ld = criterion(preds, annots)
+        loss = sum(ld.values())
+        loss.backward()
+        torch.cuda.synchronize()
+        out[wino] = (float(loss.detach()), {k: g.clone() for k, g in net.arena.grad_views.items()})
+    lw, gw = out[True]
+    ld_, gd = out[False]
+    assert abs(lw - ld_) <= 2e-6 * abs(ld_), (lw, ld_)
+    worst = max((rel(gw[k], gd[k]), k) for k in gd if float(gd[k].double().norm()) > 0)
+    # FCOS: every tower conv is followed by GroupNorm, whose backward subtracts two large projections -- the rounding
+    # difference of the conv outputs comes out amplified (the fixtures hold this model's gradients to 3e-4 median /
+    # 9e-3 max against the reference, tests/test_gpu_fcos.py)
+    assert worst[0] < (2e-4 if name == 'resnet50_retinanet' else 1e-3), worst

@@ -709,6 +709,10 @@ int sacv_conv2d_gemm_bf16(const void* src, void* dst, int Nb, int Hs, int Ws, in
   a.flags = flags;
   a.stats = stats;
   hipStream_t st = (hipStream_t)stream;
+  // stride-1 1x1 convolutions / Linear layers are plain GEMMs over contiguous rows: the LDS-DMA kernel (gemm_bf16.hip)
+  if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && !ext && remap_s == 0 && Hs == Hd && Ws == Wd &&
+      sacv_internal_gemm_nt_bf16_supported(M, N, Cs))
+    return sacv_internal_gemm_nt_bf16(src, w, dst, bias, stats, M, N, Cs, flags, stream);
   if (N <= 64)
     return mode == 0 ? launch_nt_h<128, 64, 0>(a, st) : launch_nt_h<128, 64, 1>(a, st);
   return mode == 0 ? launch_nt_h<128, 128, 0>(a, st) : launch_nt_h<128, 128, 1>(a, st);

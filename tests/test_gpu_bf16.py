@@ -91,6 +91,37 @@ def test_conv_bf16_forward_dgrad_wgrad(n, h, w, cin, cout, k, s):
         assert float((dwl.cpu() - wr.grad).abs().max()) <= 2e-3 * float(wr.grad.abs().max()), 'wgrad channels_last'
 
 
+def test_linear_gemm_dma_kernel_ragged_edges():
+    """Stride-1 1x1 problems with >= 300 tiles of 256 x 128 go to gemm_nt_bf16_dma_kernel (csrc/gemm_bf16.hip): M and N
+    that are not multiples of the tile (clamped rows, masked stores), all epilogue options, per-128-row statistics."""
+    from sacv_amd import ops
+    m, k, n = 256 * 20 + 37, 192, 128 * 15 + 8  # 21 x 16 = 336 tiles
+    x = q(rnd(11, 1, k, 1, m))                       # NCHW [1, k, 1, m]
+    wt = q(rnd(12, n, k, 1, 1, std=(2.0 / k)**0.5))
+    bias = rnd(13, n)
+    y_ref = F.conv2d(x, wt)
+    xd = nhwc(x).cuda().to(BF)
+    wp = wt.view(n, k).cuda().to(BF)
+    (y,), st = ops.conv_gemm([xd], wp, n, 1, 1, 1, 0, 0, [(1, m)], stats=True)
+    close_bf16(y.permute(0, 3, 1, 2), y_ref, 'gemm forward')
+    assert st.shape[0] == -(-m // 128)
+    yf = y.float().view(-1, n)
+    for r in (0, 7, st.shape[0] - 1):  # per-granule sums, incl. the ragged last one
+        blk = yf[r * 128:(r + 1) * 128]
+        torch.testing.assert_close(st[r, 0].cpu(), blk.sum(0).cpu(), rtol=1e-4, atol=1e-2)
+        torch.testing.assert_close(st[r, 1].cpu(), (blk * blk).sum(0).cpu(), rtol=1e-4, atol=1e-2)
+    base = torch.full((1, 1, m, n), 0.5, device='cuda')
+    y32 = ops.conv_gemm([xd], wp, n, 1, 1, 1, 0, 0, [(1, m)], bias=bias.cuda(),
+                        flags=ops.CFH_OUT_F32 | ops.CF_ACCUM, outs=[base])[0]
+    ref32 = (y_ref + bias.view(1, -1, 1, 1) + 0.5).permute(0, 2, 3, 1)
+    assert float((y32.cpu() - ref32).abs().max()) <= 2e-3 * float(ref32.abs().max())
+    # the memory right behind the outputs is untouched (rows >= M are computed from clamped rows but never stored)
+    guard = torch.full((m * n + 4096,), 7.0, device='cuda', dtype=BF)
+    out = guard[:m * n].view(1, 1, m, n)
+    ops.conv_gemm([xd], wp, n, 1, 1, 1, 0, 0, [(1, m)], outs=[out])
+    assert bool((guard[m * n:] == 7.0).all())
+
+
 def test_bn_and_pooling_bf16_match_the_fp32_kernels_on_rounded_data():
     from sacv_amd import ops
     n, h, w, c = 3, 9, 7, 72

@@ -133,14 +133,16 @@ def bench_classification(args, rank, world, group, ops, synth):
         out = trainer.step(images, labels)
     timer = None
     if not args.no_kernel_timer:
-        timer = ops.TIMER = ops.KernelTimer()
+        timer = ops.KernelTimer()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        ops.TIMER = timer if (timer is not None and i % args.timer_every == 0) else None
         out = trainer.step(images, labels)
     sync()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    n_inst = len(range(0, args.steps, args.timer_every))  # timed steps that carried per-launch events
     loss = trainer.finish_step(out)
     if world > 1:
         t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
@@ -159,8 +161,8 @@ def bench_classification(args, rank, world, group, ops, synth):
             roofline = dict(kernel='conv_nt_kernel (implicit-GEMM conv forward + data gradient, fp32 MFMA 32x32x2)',
                             bound='mfma', achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                             frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
-                            launches_per_step=k['launches'] // args.steps,
-                            share_of_step_ms=round(k['ms'] / args.steps, 2))
+                            launches_per_step=k['launches'] // n_inst,
+                            share_of_step_ms=round(k['ms'] / n_inst, 2))
         elif k['launches']:
             # bf16: these convolutions sit at or below the HBM ridge -> algorithmic bytes (input +
             # output + weights, each once) / HIP-event time against 8 TB/s; the matrix-core rate rides along
@@ -173,8 +175,8 @@ def bench_classification(args, rank, world, group, ops, synth):
             roofline = dict(kernel='conv_nt_bf16_kernel (implicit-GEMM conv forward + data gradient, bf16 MFMA 32x32x16)',
                             bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                             frac=round(gbs / PEAK_HBM_GBS, 4), traffic=None,
-                            launches_per_step=k['launches'] // args.steps,
-                            share_of_step_ms=round(k['ms'] / args.steps, 2),
+                            launches_per_step=k['launches'] // n_inst,
+                            share_of_step_ms=round(k['ms'] / n_inst, 2),
                             matrix_tflops=round(k['flops'] / (k['ms'] * 1e-3) / 1e12, 1))
             if cls3['launches']:
                 g3 = cls3['bytes'] / (cls3['ms'] * 1e-3) / 1e9
@@ -182,7 +184,7 @@ def bench_classification(args, rank, world, group, ops, synth):
                                               avg_launch_us=round(cls3['ms'] / cls3['launches'] * 1e3, 1),
                                               matrix_tflops=round(cls3['flops'] / (cls3['ms'] * 1e-3) / 1e12, 1))
         if os.environ.get('SACV_BENCH_DUMP') and rank == 0:
-            recs = timer.records[-(len(timer.records) // args.steps):]
+            recs = timer.records[-(len(timer.records) // n_inst):]
             with open(os.environ['SACV_BENCH_DUMP'], 'w') as f:
                 for key, flops, e0, e1 in recs:
                     ms = e0.elapsed_time(e1)
@@ -191,7 +193,7 @@ def bench_classification(args, rank, world, group, ops, synth):
             with open(args.class_table, 'w') as f:
                 json.dump(dict(model='resnet50_cls', dtype=args.dtype, batch=CB, steps=args.steps,
                                peak_tflops_bf16_mfma=2500.0, peak_tflops_fp32_mfma=PEAK_FP32_MFMA_TFLOPS,
-                               peak_hbm_gbs=PEAK_HBM_GBS, classes=class_table(agg, args.steps)), f, indent=1)
+                               peak_hbm_gbs=PEAK_HBM_GBS, classes=class_table(agg, n_inst)), f, indent=1)
     if rank == 0:
         print(json.dumps({
             'metric': 'images/sec/node ResNet50 ImageNet 224x224 bs=256/GPU (secondary, SURVEY 8f-1)',
@@ -232,14 +234,16 @@ def bench_mae(args, rank, world, group, ops, synth):
         out = trainer.step(images)
     timer = None
     if not args.no_kernel_timer:
-        timer = ops.TIMER = ops.KernelTimer()
+        timer = ops.KernelTimer()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        ops.TIMER = timer if (timer is not None and i % args.timer_every == 0) else None
         out = trainer.step(images)
     sync()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    n_inst = len(range(0, args.steps, args.timer_every))  # timed steps that carried per-launch events
     loss = trainer.finish_step(out)
     if world > 1:
         t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
@@ -258,13 +262,13 @@ def bench_mae(args, rank, world, group, ops, synth):
             roofline = dict(kernel='conv_nt_bf16 / conv_tn_bf16 as Linear GEMMs (bf16 MFMA 32x32x16: forward, data and '
                                    'weight gradients of patch-embed / qkv / proj / fc1 / fc2 / pred)',
                             bound='mfma', achieved=round(tf, 1), peak=2500.0, unit='TFLOP/s', frac=round(tf / 2500.0, 4),
-                            traffic=None, launches_per_step=k['launches'] // args.steps,
-                            share_of_step_ms=round(k['ms'] / args.steps, 2),
+                            traffic=None, launches_per_step=k['launches'] // n_inst,
+                            share_of_step_ms=round(k['ms'] / n_inst, 2),
                             algorithmic_gbs=round(k['bytes'] / (k['ms'] * 1e-3) / 1e9, 1))
         if args.class_table and rank == 0:
             with open(args.class_table, 'w') as f:
                 json.dump(dict(model='vit_mae', dtype='bf16', batch=MB, steps=args.steps, peak_tflops_bf16_mfma=2500.0,
-                               peak_hbm_gbs=PEAK_HBM_GBS, classes=class_table(agg, args.steps)), f, indent=1)
+                               peak_hbm_gbs=PEAK_HBM_GBS, classes=class_table(agg, n_inst)), f, indent=1)
     if rank == 0:
         print(json.dumps({
             'metric': 'images/sec/node ViT-B/16 MAE pre-training 224x224 bs=128/GPU (secondary, SURVEY 8f-4)',
@@ -291,6 +295,9 @@ def main():
                     help='retinanet = the headline metric; fcos = secondary workload (BASELINE config 4); '
                          'resnet50_cls = ResNet50 ImageNet classification, bs 256/GPU, 224x224 (SURVEY.md 8f-1)')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--timer-every', type=int, default=5,
+                    help='per-launch HIP events (the roofline measurement) on every Nth timed step: each event costs '
+                         '~2.7 us of launch-stream time, 440 of them 1.2 ms of a 31 ms step')
     ap.add_argument('--image-size', default='800x1333',
                     help='HxW of the synthetic batch: 800x1333 = the headline shape S1, 1333x1333 = the collater\'s '
                          'padded square S2 (SURVEY.md 8d)')
@@ -365,17 +372,19 @@ def main():
         out = trainer.step(images, annots)
     timer = None
     if not args.no_kernel_timer:
-        timer = ops.TIMER = ops.KernelTimer()
+        timer = ops.KernelTimer()
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
+        ops.TIMER = timer if (timer is not None and i % args.timer_every == 0) else None
         out = trainer.step(images, annots)
         marks[i + 1].record()  # an event on the launch stream: no synchronisation inside the timed region
     sync()
     elapsed = time.perf_counter() - t0
     ops.TIMER = None
+    n_inst = len(range(0, args.steps, args.timer_every))  # timed steps that carried per-launch events
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     ms_median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] +
                                                                                 per_step[len(per_step) // 2])
@@ -391,7 +400,7 @@ def main():
     if timer is not None:
         agg = timer.summary()
         if os.environ.get('SACV_BENCH_DUMP') and rank == 0:  # per-launch table of the last step (tuning aid)
-            recs = timer.records[-(len(timer.records) // args.steps):]
+            recs = timer.records[-(len(timer.records) // n_inst):]
             with open(os.environ['SACV_BENCH_DUMP'], 'w') as f:
                 for key, flops, e0, e1 in recs:
                     ms = e0.elapsed_time(e1)
@@ -426,8 +435,8 @@ def main():
                 secondary = dict(kernel='weight gradient: conv_tn_kernel + wgrad_reduce (direct), wino_wgrad_kernel + transforms (Winograd, head 3x3 convolutions); algorithmic flops / time', bound='mfma',
                                  achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                                  frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                                 launches_per_step=tn['launches'] // args.steps,
-                                 share_of_step_ms=round(tn['ms'] / args.steps, 2))
+                                 launches_per_step=tn['launches'] // n_inst,
+                                 share_of_step_ms=round(tn['ms'] / n_inst, 2))
             wino = dict(launches=0, flops=0.0, ms=0.0)
             for name, v in agg.items():
                 if name.startswith('conv_nt_wino'):
@@ -437,25 +446,26 @@ def main():
             if wino['launches']:
                 d_fl, d_ms = k['flops'] - wino['flops'], k['ms'] - wino['ms']
                 paths = dict(
-                    winograd=dict(calls_per_step=wino['launches'] // args.steps,
+                    winograd=dict(calls_per_step=wino['launches'] // n_inst,
                                   algorithmic_tflops=round(wino['flops'] / (wino['ms'] * 1e-3) / 1e12, 2),
                                   matrix_core_tflops=round(wino['flops'] / 2.25 / (wino['ms'] * 1e-3) / 1e12, 2),
-                                  share_of_step_ms=round(wino['ms'] / args.steps, 2),
+                                  share_of_step_ms=round(wino['ms'] / n_inst, 2),
                                   note='F(2x2,3x3): 2.25x fewer matrix-core flops than the direct sum; time includes '
                                        'the input transform'),
-                    direct=dict(calls_per_step=(k['launches'] - wino['launches']) // args.steps,
+                    direct=dict(calls_per_step=(k['launches'] - wino['launches']) // n_inst,
                                 algorithmic_tflops=round(d_fl / (d_ms * 1e-3) / 1e12, 2),
-                                share_of_step_ms=round(d_ms / args.steps, 2)))
+                                share_of_step_ms=round(d_ms / n_inst, 2)))
             roofline = dict(kernel='convolution forward + data gradient: conv_nt_kernel<128,{128|64},mode> (implicit GEMM) and, '
                                    'for the stride-1 3x3 head / P3 convolutions, wino_gemm_kernel<64,128> (Winograd '
                                    'F(2x2,3x3), 16 chained GEMMs + output transform); fp32 MFMA 32x32x2; `achieved` = '
                                    'algorithmic (direct-convolution) flops / time',
                             bound='mfma', achieved=round(achieved, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
                             frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic,
-                            launches_per_step=k['launches'] // args.steps,
+                            launches_per_step=k['launches'] // n_inst,
                             avg_launch_ms=round(per_launch_ms, 4), algorithmic_gflop_per_launch=round(
                                 per_launch_flops / 1e9, 2),
-                            share_of_step_ms=round(k['ms'] / args.steps, 2))
+                            share_of_step_ms=round(k['ms'] / n_inst, 2))
+            roofline['instrumented_steps'] = f'{n_inst} of the {args.steps} timed steps (every {args.timer_every}th)'
             if paths:
                 roofline['paths'] = paths
             if secondary:
@@ -464,7 +474,7 @@ def main():
             with open(args.class_table, 'w') as f:
                 json.dump(dict(model=args.model, image_size=[H, W], batch=BATCH, steps=args.steps,
                                peak_tflops_fp32_mfma=PEAK_FP32_MFMA_TFLOPS, peak_hbm_gbs=PEAK_HBM_GBS,
-                               classes=class_table(agg, args.steps)), f, indent=1)
+                               classes=class_table(agg, n_inst)), f, indent=1)
     if rank == 0:
         line = {
             'metric': 'images/sec/node RetinaNet-R50 COCO 1333x800 bs=2/GPU',

@@ -611,10 +611,9 @@ class DetectorEngine:
             ops.colsum(d, 8, db8, accumulate=l > 0)
         g['clsregcnt_head.reg_out.bias'].copy_(db8[0:4])
         g['clsregcnt_head.center_out.bias'].copy_(db8[4:5])
-        if self._use_wino():
-            d_cls_x, d_reg_x = ops.conv3x3_wino([dz_cls, dy8], [self._wino_u(w, dgrad=True),
-                                                                 self._wino_u(o['w8'], dgrad=True)],
-                                                [self.planes] * 2, mode=1)
+        if self._use_wino():  # separate launches: 80 vs 8 input channels (see _towers_bwd_wino)
+            d_cls_x = ops.conv3x3_wino([dz_cls], [self._wino_u(w, dgrad=True)], [self.planes], mode=1)[0]
+            d_reg_x = ops.conv3x3_wino([dy8], [self._wino_u(o['w8'], dgrad=True)], [self.planes], mode=1)[0]
             return self._gn_towers_bwd_wino([d_cls_x, d_reg_x])
         d_cls_x = ops.conv_gemm(dz_cls, self._dgrad_panel(w), w.shape[1], 3, 3, 1, 1, 1, hw)
         dfeat = self._gn_tower_bwd(d_cls_x, 'clsregcnt_head.cls_head')
@@ -671,9 +670,14 @@ class DetectorEngine:
             w = p[out_name + '.weight']
             self._wino_wgrad(dys[t], saved[t][4], vsaved[t][4], g[out_name + '.weight'], w.shape[1])
             self._bias_grad(dys[t], out_name)
-        ws = [p[o + '.weight'] for _, o in towers]
-        cur, st = ops.conv3x3_wino(dys, [self._wino_u(w, dgrad=True) for w in ws], [self.planes] * 2,
-                                   flags=[CF_MASK] * 2, masks_list=[saved[0][4], saved[1][4]], stats=True, mode=1)
+        # the two output convs have very different depths (720 / 36 channels): in one launch the item lengths differ
+        # 11x and the static item order leaves whole XCDs idle (1384 us against 922 + 104 us separately)
+        cur, st = [], []
+        for t, (_, o) in enumerate(towers):
+            c, s_ = ops.conv3x3_wino([dys[t]], [self._wino_u(p[o + '.weight'], dgrad=True)], [self.planes],
+                                     flags=[CF_MASK], masks_list=[saved[t][4]], stats=True, mode=1)
+            cur.append(c[0])
+            st.append(s_[0])
         for li, i in reversed(list(enumerate((0, 2, 4, 6)))):
             names = [f'{t}.{i}' for t, _ in towers]
             ws = [p[n + '.weight'] for n in names]

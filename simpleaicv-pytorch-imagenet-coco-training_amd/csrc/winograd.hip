@@ -12,7 +12,7 @@
 //                                                             launch; t runs over level, image, tile row, tile col)
 //   wino_gemm_kernel     M_g = V[g] U[g]^T for g = 0..15 back to back in ONE workgroup per (64 tiles x 128 channels)
 //                        item, each M_g folded into the four output accumulators Y[a][b] += A^T[a][i] A^T[b][j] M_g
-//                        (VALU adds once per g), so M never goes to memory and the inner loop sees one long K
+//                        (VALU fmas once per g), so M never goes to memory and the inner loop sees one long K
 //                        (16 x Cin) with no epilogue in between; the epilogue writes the 2x2 pixels of every tile with
 //                        the fused bias / ReLU / sigmoid / accumulate / ReLU-mask / column-sum options of the direct
 //                        kernel (conv_gemm.hip vec_epilogue).
@@ -825,9 +825,6 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
   }
 }
 
-#ifndef WINO_SGB
-#define WINO_SGB 0  // tuning builds: sched_group_barrier interleave of the MFMA block
-#endif
 #ifndef WINO_WN
 #define WINO_WN 2  // waves along N of the GEMM kernel (tuning builds: -DWINO_WN=4: 8 waves of 32 x 32, same speed)
 #endif

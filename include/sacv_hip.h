@@ -296,6 +296,11 @@ int sacv_comm_broadcast(void* comm, float* buf, long long count, int root, void*
 int sacv_conv2d_gemm_bf16(const void* src, void* dst, int Nb, int Hs, int Ws, int Hd, int Wd, const void* w,
                           const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode, int flags,
                           int remap_s, int Hr, int Wr, const int* ext, float* stats, void* stream);
+/* nn.Linear on bf16 rows (vit.py:139-160, vit_mae.py): y[M][N] (bf16, or fp32 with SACV_CFH_OUT_F32) =
+ * x[M][K] w[N][K]^T (+ bias) (+ residual: an fp32 [M][N] tensor, the residual stream -- the block's `x + proj(...)`
+ * without a copy of x) (+ y with SACV_CF_ACCUM).  Large problems run on the LDS-DMA pipelined GEMM (gemm_bf16.hip). */
+int sacv_linear_bf16(const void* x, const void* w, void* y, const float* bias, const float* residual, long long M,
+                     int N, int K, int flags, void* stream);
 long long sacv_conv2d_wgrad_bf16_workspace_bytes(int Nb, int Ho, int Wo, int Cin_pad, int Cout, int KH, int KW,
                                                  int chunk);
 /* fp32 weight gradient from bf16 dy / x (fp32 slabs per `chunk` pixels, a multiple of 64, summed in fixed order) */

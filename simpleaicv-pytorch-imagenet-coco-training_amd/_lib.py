@@ -25,6 +25,7 @@ SIGNATURES = {
     'sacv_wino_weights': (I, [P, P, I, I, I, P]),
     'sacv_wino_input': (I, [I, P, I, P, P, I, P, I, P]),
     'sacv_wino_stats_rows': (I, [I]),
+    'sacv_linear_bf16': (I, [P, P, P, P, P, LL, I, I, I, P]),
     'sacv_wino_pad_k': (I, [I]),
     'sacv_wino_pad_n': (I, [I]),
     'sacv_wino_wgrad_workspace_bytes': (LL, [I, I, I]),

@@ -46,6 +46,7 @@ struct ConvArgsH {
   int flags;
   int ntiles;
   float* stats;  // [mtiles][2][N]
+  const float* residual;  // optional fp32 [M][N] added in the epilogue (the ViT residual stream), never remapped
 };
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -244,6 +245,15 @@ __global__ __launch_bounds__(256, 2) void conv_nt_bf16_kernel(const ConvArgsH a)
         orow = ((size_t)nn * a.Hr + (size_t)hd * a.remap_s + a.remap_oh) * a.Wr + (size_t)wd * a.remap_s + a.remap_ow;
       }
       const size_t o = orow * a.N + n;
+      if (a.residual) {
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.residual + o);
+        const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.residual + o + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] += r0[e];
+          v[4 + e] += r1[e];
+        }
+      }
       if (flags & CFH_OUT_F32) {
         float* d = reinterpret_cast<float*>(a.dst) + o;
         if (flags & CF_ACCUM) {
@@ -648,10 +658,12 @@ extern "C" {
 // panel [N][KH*KW*Cs] (mode 0: the weight itself when stored channels_last or 1x1; mode 1: the [Cin][taps*Cout]
 // panel); dst [M][N] bf16, or fp32 with SACV_CFH_OUT_F32.  flags: SACV_CF_BIAS | SACV_CF_ACCUM | SACV_CF_STATS |
 // SACV_CFH_OUT_F32.  remap / ext as in sacv_conv2d_gemm.  Cs and N must be multiples of 8.
-int sacv_conv2d_gemm_bf16(const void* src, void* dst, int Nb, int Hs, int Ws, int Hd, int Wd, const void* w,
-                          const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode, int flags,
-                          int remap_s, int Hr, int Wr, const int* ext, float* stats, void* stream) {
+static int conv2d_gemm_bf16_impl(const void* src, void* dst, int Nb, int Hs, int Ws, int Hd, int Wd, const void* w,
+                                 const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode,
+                                 int flags, int remap_s, int Hr, int Wr, const int* ext, float* stats,
+                                 const float* residual, void* stream) {
   SACV_CHECK_ARG(src && dst && w, "conv2d_gemm_bf16: null pointer");
+  SACV_CHECK_ARG(!residual || (remap_s == 0 && !ext), "conv2d_gemm_bf16: residual with a remapped destination");
   SACV_CHECK_ARG(Cs % 8 == 0 && Cs > 0 && N % 8 == 0 && N > 0, "conv2d_gemm_bf16: Cs=%d and N=%d must be multiples of 8",
                  Cs, N);
   SACV_CHECK_ARG(KH > 0 && KW > 0 && (mode == 0 || mode == 1), "conv2d_gemm_bf16: bad KH/KW/mode");
@@ -708,14 +720,31 @@ int sacv_conv2d_gemm_bf16(const void* src, void* dst, int Nb, int Hs, int Ws, in
   }
   a.flags = flags;
   a.stats = stats;
+  a.residual = residual;
   hipStream_t st = (hipStream_t)stream;
   // stride-1 1x1 convolutions / Linear layers are plain GEMMs over contiguous rows: the LDS-DMA kernel (gemm_bf16.hip)
   if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && !ext && remap_s == 0 && Hs == Hd && Ws == Wd &&
       sacv_internal_gemm_nt_bf16_supported(M, N, Cs))
-    return sacv_internal_gemm_nt_bf16(src, w, dst, bias, stats, M, N, Cs, flags, stream);
+    return sacv_internal_gemm_nt_bf16(src, w, dst, bias, residual, stats, M, N, Cs, flags, stream);
   if (N <= 64)
     return mode == 0 ? launch_nt_h<128, 64, 0>(a, st) : launch_nt_h<128, 64, 1>(a, st);
   return mode == 0 ? launch_nt_h<128, 128, 0>(a, st) : launch_nt_h<128, 128, 1>(a, st);
+}
+
+int sacv_conv2d_gemm_bf16(const void* src, void* dst, int Nb, int Hs, int Ws, int Hd, int Wd, const void* w,
+                          const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode, int flags,
+                          int remap_s, int Hr, int Wr, const int* ext, float* stats, void* stream) {
+  return conv2d_gemm_bf16_impl(src, dst, Nb, Hs, Ws, Hd, Wd, w, bias, Cs, N, KH, KW, stride, pad, mode, flags, remap_s,
+                               Hr, Wr, ext, stats, nullptr, stream);
+}
+
+// nn.Linear on bf16 rows: y[M][N] (bf16, or fp32 with SACV_CFH_OUT_F32) = x[M][K] w[N][K]^T (+ bias) (+ residual, an
+// fp32 [M][N] tensor: the ViT residual stream, vit.py:139-160) (+ y with SACV_CF_ACCUM).  K and N multiples of 8.
+int sacv_linear_bf16(const void* x, const void* w, void* y, const float* bias, const float* residual, long long M,
+                     int N, int K, int flags, void* stream) {
+  SACV_CHECK_ARG(M > 0 && M < (1LL << 31), "linear_bf16: M");
+  return conv2d_gemm_bf16_impl(x, y, 1, 1, (int)M, 1, (int)M, w, bias, K, N, 1, 1, 1, 0, 0, flags, 0, 0, 0, nullptr,
+                               nullptr, residual, stream);
 }
 
 long long sacv_conv2d_wgrad_bf16_workspace_bytes(int Nb, int Ho, int Wo, int Cin_pad, int Cout, int KH, int KW,

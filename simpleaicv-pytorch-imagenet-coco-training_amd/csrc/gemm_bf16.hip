@@ -43,6 +43,7 @@ struct GemmArgsH {
   const bf16* B;  // [N][K]
   void* C;        // [M][N] bf16, or fp32 with GCF_OUT_F32
   const float* bias;
+  const float* residual;  // optional fp32 [M][N] added in the epilogue
   float* stats;  // [ceil(M/128)][2][N]: the 128-row granule of conv_nt_bf16_kernel's CF_STATS buffer
   int M, N, K;
   int flags;
@@ -197,6 +198,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_dma_kernel(const GemmArgs
           v[4 + e] = v1[e] + bv[4 + e];
         }
         const size_t o = (size_t)m * a.N + n;
+        if (a.residual) {
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.residual + o);
+          const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.residual + o + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] += r0[e];
+            v[4 + e] += r1[e];
+          }
+        }
         if (flags & GCF_OUT_F32) {
           float* d = reinterpret_cast<float*>(a.C) + o;
           if (flags & GCF_ACCUM) {
@@ -282,13 +292,14 @@ int sacv_internal_gemm_nt_bf16_supported(long long M, int N, int K) {
   return tiles >= 300;
 }
 
-int sacv_internal_gemm_nt_bf16(const void* A, const void* B, void* C, const float* bias, float* stats, long long M,
-                               int N, int K, int flags, void* stream) {
+int sacv_internal_gemm_nt_bf16(const void* A, const void* B, void* C, const float* bias, const float* residual,
+                               float* stats, long long M, int N, int K, int flags, void* stream) {
   GemmArgsH a;
   a.A = (const bf16*)A;
   a.B = (const bf16*)B;
   a.C = C;
   a.bias = bias;
+  a.residual = residual;
   a.stats = stats;
   a.M = (int)M;
   a.N = N;

@@ -36,8 +36,8 @@ int sacv_internal_wgrad_reduce(const float* part, float* dw, int chunks, int Cou
 // internal: plain bf16 NT GEMM on the LDS-DMA pipelined kernel (gemm_bf16.hip), used by sacv_conv2d_gemm_bf16 for
 // stride-1 1x1 problems / Linear layers; flags = the CF_* bits of the bf16 convolution
 int sacv_internal_gemm_nt_bf16_supported(long long M, int N, int K);
-int sacv_internal_gemm_nt_bf16(const void* A, const void* B, void* C, const float* bias, float* stats, long long M,
-                               int N, int K, int flags, void* stream);
+int sacv_internal_gemm_nt_bf16(const void* A, const void* B, void* C, const float* bias, const float* residual,
+                               float* stats, long long M, int N, int K, int flags, void* stream);
 
 static inline int sacv_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

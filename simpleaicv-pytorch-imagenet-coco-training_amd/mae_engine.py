@@ -52,15 +52,14 @@ class MAEEngine:
         h, m1, r1 = V.layernorm_fwd(x, p[pre + '.norm1.weight'], p[pre + '.norm1.bias'], LN_EPS)
         qkv = V.linear_fwd(h, self._wf(pre + '.attn.qkv.weight'), p[pre + '.attn.qkv.bias'])
         a, lse = V.attention_fwd(qkv, b, n, heads)
-        x1 = x.clone()
-        V.linear_fwd(a, self._wf(pre + '.attn.proj.weight'), p[pre + '.attn.proj.bias'], out=x1, accumulate=True,
-                     out_f32=True)
+        # x1 = x + proj(a): the residual is an epilogue input of the GEMM (no copy of x; x stays for the backward pass)
+        x1 = V.linear_fwd(a, self._wf(pre + '.attn.proj.weight'), p[pre + '.attn.proj.bias'], out_f32=True,
+                          residual=x)
         h2, m2, r2 = V.layernorm_fwd(x1, p[pre + '.norm2.weight'], p[pre + '.norm2.bias'], LN_EPS)
         f = V.linear_fwd(h2, self._wf(pre + '.mlp.fc1.weight'), p[pre + '.mlp.fc1.bias'])
         gl = V.gelu_fwd(f)
-        x2 = x1.clone()
-        V.linear_fwd(gl, self._wf(pre + '.mlp.fc2.weight'), p[pre + '.mlp.fc2.bias'], out=x2, accumulate=True,
-                     out_f32=True)
+        x2 = V.linear_fwd(gl, self._wf(pre + '.mlp.fc2.weight'), p[pre + '.mlp.fc2.bias'], out_f32=True,
+                          residual=x1)
         if keep:
             s.x0, s.m1, s.r1, s.h, s.qkv, s.a, s.lse = x, m1, r1, h, qkv, a, lse
             s.x1, s.m2, s.r2, s.h2, s.f, s.g = x1, m2, r2, h2, f, gl

@@ -170,14 +170,32 @@ def mse_loss(pred, label, mask, want_grad=True, grad_scale=1.0):
 
 
 # ------------------------------------------------------------------------------------------ Linear = 1x1 GEMM
-def linear_fwd(x, w_panel, bias, out=None, accumulate=False, out_f32=False):
-    """y[R,N] = x[R,K] @ W[N,K]^T + bias on the bf16 matrix cores.  out_f32: fp32 destination; accumulate: y += ..."""
+def linear_fwd(x, w_panel, bias, out=None, accumulate=False, out_f32=False, residual=None):
+    """y[R,N] = x[R,K] @ W[N,K]^T + bias (+ residual, fp32 [R,N]) on the bf16 matrix cores.  out_f32: fp32
+    destination; accumulate: y += ..."""
     r, k = x.shape
     n = w_panel.shape[0]
-    flags = (ops.CFH_OUT_F32 if out_f32 else 0) | (ops.CF_ACCUM if accumulate else 0)
-    outs = [out.view(1, 1, r, n)] if out is not None else None
-    y = ops.conv_gemm([x.view(1, 1, r, k)], w_panel, n, 1, 1, 1, 0, 0, [(1, r)], bias=bias, flags=flags, outs=outs)[0]
-    return y.view(r, n)
+    flags = (ops.CFH_OUT_F32 if out_f32 else 0) | (ops.CF_ACCUM if accumulate else 0) | (ops.CF_BIAS if bias is not None else 0)
+    if out is None:
+        out = torch.empty((r, n), device=x.device, dtype=torch.float32 if out_f32 else BF16)
+    _chk(x, 'linear x', BF16)
+    _chk(w_panel, 'linear weight panel', BF16)
+    _chk(out, 'linear out', torch.float32 if out_f32 else BF16)
+    if residual is not None:
+        _chk(residual, 'linear residual')
+        if tuple(residual.shape) != (r, n):
+            raise ValueError(f'linear_fwd: residual is {tuple(residual.shape)}, expected ({r}, {n})')
+
+    def launch():
+        check(lib.sacv_linear_bf16(_ptr(x), _ptr(w_panel), _ptr(out), _ptr(bias), _ptr(residual), r, n, k, flags,
+                                   _stream()), 'linear_bf16')
+
+    if ops.TIMER is not None:
+        ops.TIMER.time(f'conv_nt_bf16|m0 k1 s1 cs{k} n{n} pix{r} f{flags}', 2.0 * r * n * k, launch,
+                       nbytes=2.0 * (x.numel() + w_panel.numel()) + out.numel() * (4 if out_f32 else 2))
+    else:
+        launch()
+    return out
 
 
 def linear_dgrad(dy, w_dpanel, k):

@@ -165,6 +165,9 @@ long long sacv_colsum_workspace_floats(int R, int C);
 int sacv_colsum(const float* x, float* out, int R, int C, int accumulate, float* workspace, void* stream);
 int sacv_colsum_finalize(const float* partial, int nblocks, int stride, int C, float* out, int accumulate,
                          void* stream);
+/* n (<= 16) such second stages in one launch (the parameter gradients of one transformer block) */
+int sacv_colsum_finalize_multi(int n, const float* const* partial /*host arrays*/, const int* nblocks, const int* stride,
+                               const int* C, float* const* out, const int* accumulate, void* stream);
 
 /* ---- targets and losses (detection/models/anchor.py, detection/losses.py) ---------------------------- */
 /* RetinaAnchors.__call__ (anchor.py:18-86): bit-exact vs NumPy fp32; fw/fh/areas/... are host arrays */
@@ -358,6 +361,9 @@ int sacv_mae_decoder_tokens_bwd(const float* dx, const long long* shuffle_ids, v
 int sacv_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int R,
                        int C, float eps, void* stream);
 long long sacv_layernorm_bwd_workspace_floats(int R, int C);
+/* rows actually written of the partial buffer [rows][2C] (dbeta | dgamma) when the second stage is deferred
+ * (dgamma = dbeta = NULL) to sacv_colsum_finalize_multi */
+int sacv_layernorm_bwd_partial_rows(int R);
 int sacv_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        float* dx, float* dgamma, float* dbeta, int R, int C, int accumulate_dx, int accumulate_params,
                        float* workspace, void* stream);
@@ -365,6 +371,8 @@ int sacv_layernorm_bwd(const void* dy, const float* x, const float* mean, const 
 int sacv_gelu_fwd(const void* x, void* y, long long n, void* stream);
 int sacv_gelu_bwd(const void* dy, const void* x, void* dx, long long n, void* stream);
 long long sacv_colsum_bf16_workspace_floats(int R, int C);
+/* rows actually written of the partial buffer [rows][C] when out = NULL (second stage deferred) */
+int sacv_colsum_bf16_partial_rows(int R);
 int sacv_colsum_bf16(const void* x, float* out, int R, int C, int accumulate, float* workspace, void* stream);
 /* MultiHeadAttention core (vit.py:73-86): qkv bf16 [B][n][3][H][d] -> out bf16 [B][n][H*d];
  * softmax(bf16(QK^T) * scale) in fp32, probabilities cast to bf16 for the product with V (autocast's dtypes) */

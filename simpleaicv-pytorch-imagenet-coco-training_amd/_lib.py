@@ -20,6 +20,9 @@ SIGNATURES = {
     'sacv_conv2d_gemm_stats_rows': (I, [I, P, P, P]),
     'sacv_bn_finalize_stats': (I, [P, I, I, I, F, F, P, P, P, P, P, P]),
     'sacv_colsum_finalize': (I, [P, I, I, I, P, I, P]),
+    'sacv_colsum_finalize_multi': (I, [I, P, P, P, P, P, P, P]),
+    'sacv_layernorm_bwd_partial_rows': (I, [I]),
+    'sacv_colsum_bf16_partial_rows': (I, [I]),
     'sacv_conv2d_gemm_workspace_bytes': (LL, []),
     'sacv_wino_tiles': (I, [I, I, P, P]),
     'sacv_wino_weights': (I, [P, P, I, I, I, P]),

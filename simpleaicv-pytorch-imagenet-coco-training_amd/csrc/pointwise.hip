@@ -269,6 +269,35 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
   }
 }
 
+// up to 16 independent second stages in one launch (the parameter gradients of one transformer block: 4 Linear biases,
+// 2 x (LayerNorm dbeta, dgamma)): blockIdx.y = job, same fixed summation order as colsum_finalize_kernel
+#define SACV_COLSUM_MULTI 16
+struct ColsumJobs {
+  const float* partial[SACV_COLSUM_MULTI];
+  float* out[SACV_COLSUM_MULTI];
+  int nblocks[SACV_COLSUM_MULTI], stride[SACV_COLSUM_MULTI], C[SACV_COLSUM_MULTI], accumulate[SACV_COLSUM_MULTI];
+};
+__global__ __launch_bounds__(256) void colsum_finalize_multi_kernel(const ColsumJobs j) {
+  __shared__ double red[256];
+  const int job = blockIdx.y;
+  const int C = j.C[job], nblocks = j.nblocks[job], stride = j.stride[job];
+  const float* __restrict__ partial = j.partial[job];
+  const int cl = threadIdx.x % 16, part = threadIdx.x / 16;
+  const int c = blockIdx.x * 16 + cl;
+  if (blockIdx.x * 16 >= C) return;
+  double s = 0.0;
+  if (c < C)
+    for (int b = part; b < nblocks; b += 16) s += (double)partial[(size_t)b * stride + c];
+  red[part * 16 + cl] = s;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    double t = 0.0;
+    for (int k = 0; k < 16; ++k) t += red[k * 16 + cl];
+    float* out = j.out[job];
+    out[c] = j.accumulate[job] ? out[c] + (float)t : (float)t;
+  }
+}
+
 static int grid_for(size_t work, int cap = 8192) {
   size_t b = (work + 255) / 256;
   if (b < 1) b = 1;
@@ -362,6 +391,29 @@ int sacv_colsum_finalize(const float* partial, int nblocks, int stride, int C, f
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partial,
                      nblocks, stride, C, out, accumulate);
   SACV_CHECK_LAUNCH("colsum_finalize");
+  return SACV_OK;
+}
+
+// n (<= 16) second stages in one launch: out[i][c] (+)= sum_b partial[i][b * stride[i] + c], c < C[i]
+int sacv_colsum_finalize_multi(int n, const float* const* partial, const int* nblocks, const int* stride, const int* C,
+                               float* const* out, const int* accumulate, void* stream) {
+  SACV_CHECK_ARG(n >= 1 && n <= SACV_COLSUM_MULTI, "colsum_finalize_multi: n=%d (1..%d)", n, SACV_COLSUM_MULTI);
+  ColsumJobs j;
+  int cmax = 0;
+  for (int i = 0; i < SACV_COLSUM_MULTI; ++i) {
+    const int k = i < n ? i : 0;
+    SACV_CHECK_ARG(partial[k] && out[k] && nblocks[k] > 0 && C[k] > 0 && stride[k] >= C[k],
+                   "colsum_finalize_multi: bad job %d", k);
+    j.partial[i] = partial[k];
+    j.out[i] = out[k];
+    j.nblocks[i] = nblocks[k];
+    j.stride[i] = stride[k];
+    j.C[i] = C[k];
+    j.accumulate[i] = accumulate[k];
+    if (i < n && C[k] > cmax) cmax = C[k];
+  }
+  hipLaunchKernelGGL(colsum_finalize_multi_kernel, dim3((cmax + 15) / 16, n), dim3(256), 0, (hipStream_t)stream, j);
+  SACV_CHECK_LAUNCH("colsum_finalize_multi");
   return SACV_OK;
 }
 

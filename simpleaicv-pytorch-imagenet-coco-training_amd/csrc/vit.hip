@@ -788,6 +788,14 @@ int sacv_layernorm_fwd(const float* x, const float* gamma, const float* beta, vo
   return SACV_OK;
 }
 
+// rows of the LayerNorm-backward partial buffer [rows][2C] actually written for R input rows
+int sacv_layernorm_bwd_partial_rows(int R) {
+  int nb = R < 1024 ? (R + 15) / 16 : 512;
+  int rpb = (R + nb - 1) / nb;
+  rpb = (rpb + 3) / 4 * 4;
+  return (R + rpb - 1) / rpb;
+}
+
 long long sacv_layernorm_bwd_workspace_floats(int R, int C) {
   const int nb = R < 1024 ? (R + 15) / 16 : 512;
   return (long long)nb * 2 * C;
@@ -797,16 +805,19 @@ long long sacv_layernorm_bwd_workspace_floats(int R, int C) {
 int sacv_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                        float* dx, float* dgamma, float* dbeta, int R, int C, int accumulate_dx, int accumulate_params,
                        float* workspace, void* stream) {
-  SACV_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace, "layernorm_bwd: null pointer");
+  SACV_CHECK_ARG(dy && x && mean && rstd && gamma && dx && workspace, "layernorm_bwd: null pointer");
+  SACV_CHECK_ARG((dgamma != nullptr) == (dbeta != nullptr), "layernorm_bwd: dgamma and dbeta are given or deferred together");
   SACV_CHECK_ARG(R > 0 && C % 8 == 0 && C <= 3072, "layernorm_bwd: C=%d unsupported", C);
   int nb = R < 1024 ? (R + 15) / 16 : 512;
   int rpb = (R + nb - 1) / nb;
   rpb = (rpb + 3) / 4 * 4;
-  nb = (R + rpb - 1) / rpb;
+  nb = (R + rpb - 1) / rpb;  // = sacv_layernorm_bwd_partial_rows(R)
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * C * sizeof(float), st, (const bf16*)dy, x,
                      mean, rstd, gamma, dx, workspace, R, C, rpb, accumulate_dx);
   SACV_CHECK_LAUNCH("layernorm_bwd");
+  if (!dgamma) return SACV_OK;  // deferred: the caller sums workspace [rows][2C] (dbeta | dgamma) later, e.g. with
+                                // sacv_colsum_finalize_multi over all parameter gradients of a transformer block
   int rc = sacv_colsum_finalize(workspace, nb, 2 * C, C, dbeta, accumulate_params, stream);
   if (rc != SACV_OK) return rc;
   return sacv_colsum_finalize(workspace + C, nb, 2 * C, C, dgamma, accumulate_params, stream);
@@ -833,8 +844,16 @@ long long sacv_colsum_bf16_workspace_floats(int R, int C) {
   return (long long)nb * C;
 }
 
+// rows of the partial buffer [rows][C] actually written for R input rows
+int sacv_colsum_bf16_partial_rows(int R) {
+  int nb = R < 256 ? 1 : (R < 4096 ? 64 : 512);
+  const int rpb = (R + nb - 1) / nb;
+  return (R + rpb - 1) / rpb;
+}
+
+// out == NULL: first stage only (partials in workspace [sacv_colsum_bf16_partial_rows(R)][C]), finalized by the caller
 int sacv_colsum_bf16(const void* x, float* out, int R, int C, int accumulate, float* workspace, void* stream) {
-  SACV_CHECK_ARG(x && out && workspace && R > 0 && C % 8 == 0, "colsum_bf16: bad args");
+  SACV_CHECK_ARG(x && workspace && R > 0 && C % 8 == 0, "colsum_bf16: bad args");
   int nb = R < 256 ? 1 : (R < 4096 ? 64 : 512);
   int rpb = (R + nb - 1) / nb;
   nb = (R + rpb - 1) / rpb;
@@ -843,6 +862,7 @@ int sacv_colsum_bf16(const void* x, float* out, int R, int C, int accumulate, fl
   hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3(nb), dim3(256), (size_t)rl * C * sizeof(float),
                      (hipStream_t)stream, (const bf16*)x, workspace, R, C, rpb);
   SACV_CHECK_LAUNCH("colsum_bf16_partial");
+  if (!out) return SACV_OK;
   return sacv_colsum_finalize(workspace, nb, C, C, out, accumulate, stream);
 }
 

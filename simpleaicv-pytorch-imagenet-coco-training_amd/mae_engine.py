@@ -66,25 +66,28 @@ class MAEEngine:
         return x2, s
 
     def _block_bwd(self, dx, s, pre, b, n, heads):
-        """dx fp32 [R,C]: gradient w.r.t. the block output; returns it w.r.t. the block input (in place)."""
+        """dx fp32 [R,C]: gradient w.r.t. the block output; returns it w.r.t. the block input (in place).  The second
+        stages of the block's 8 column sums (4 Linear biases, 2 x LayerNorm dgamma / dbeta) go out as ONE launch."""
         p, g = self.p, self.g
         c = dx.shape[1]
+        q = V.ColsumQueue()
         dxb = ops.cast_bf16(dx)
-        V.linear_wgrad(dxb, s.g, g[pre + '.mlp.fc2.weight'], g[pre + '.mlp.fc2.bias'])
+        V.linear_wgrad(dxb, s.g, g[pre + '.mlp.fc2.weight'], g[pre + '.mlp.fc2.bias'], queue=q)
         dg = V.linear_dgrad(dxb, self._wd(pre + '.mlp.fc2.weight'), s.g.shape[1])
         df = V.gelu_bwd(dg, s.f)
-        V.linear_wgrad(df, s.h2, g[pre + '.mlp.fc1.weight'], g[pre + '.mlp.fc1.bias'])
+        V.linear_wgrad(df, s.h2, g[pre + '.mlp.fc1.weight'], g[pre + '.mlp.fc1.bias'], queue=q)
         dh2 = V.linear_dgrad(df, self._wd(pre + '.mlp.fc1.weight'), c)
         V.layernorm_bwd(dh2, s.x1, s.m2, s.r2, p[pre + '.norm2.weight'], g[pre + '.norm2.weight'],
-                        g[pre + '.norm2.bias'], dx=dx)
+                        g[pre + '.norm2.bias'], dx=dx, queue=q)
         dxb = ops.cast_bf16(dx)
-        V.linear_wgrad(dxb, s.a, g[pre + '.attn.proj.weight'], g[pre + '.attn.proj.bias'])
+        V.linear_wgrad(dxb, s.a, g[pre + '.attn.proj.weight'], g[pre + '.attn.proj.bias'], queue=q)
         da = V.linear_dgrad(dxb, self._wd(pre + '.attn.proj.weight'), c)
         dqkv = V.attention_bwd(s.qkv, s.a, da, s.lse, b, n, heads)
-        V.linear_wgrad(dqkv, s.h, g[pre + '.attn.qkv.weight'], g[pre + '.attn.qkv.bias'])
+        V.linear_wgrad(dqkv, s.h, g[pre + '.attn.qkv.weight'], g[pre + '.attn.qkv.bias'], queue=q)
         dh = V.linear_dgrad(dqkv, self._wd(pre + '.attn.qkv.weight'), c)
         V.layernorm_bwd(dh, s.x0, s.m1, s.r1, p[pre + '.norm1.weight'], g[pre + '.norm1.weight'],
-                        g[pre + '.norm1.bias'], dx=dx)
+                        g[pre + '.norm1.bias'], dx=dx, queue=q)
+        q.flush()
         return dx
 
     # ------------------------------------------------------------------ forward

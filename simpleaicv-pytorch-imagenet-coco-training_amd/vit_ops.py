@@ -90,16 +90,51 @@ def layernorm_fwd(x, gamma, beta, eps=1e-6):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx=None, accumulate_params=False):
-    """dx (given: accumulated into; None: created) fp32; dgamma / dbeta fp32 gradient views."""
+class ColsumQueue:
+    """Deferred second stages of column sums (Linear bias gradients, LayerNorm dgamma / dbeta): the first-stage
+    kernels write their partials into buffers of their own, `flush()` finalizes up to 16 of them per launch
+    (sacv_colsum_finalize_multi) -- a transformer block's backward pass has 8, each a ~10 us launch on its own."""
+
+    def __init__(self):
+        self.jobs = []
+
+    def add(self, partial, nblocks, stride, c, out, accumulate=False):
+        self.jobs.append((partial, nblocks, stride, c, out, int(accumulate)))
+        if len(self.jobs) == 16:
+            self.flush()
+
+    def flush(self):
+        if not self.jobs:
+            return
+        j = self.jobs
+        check(lib.sacv_colsum_finalize_multi(len(j), ops.parr([p.data_ptr() for p, *_ in j]), ops.iarr([x[1] for x in j]),
+                                             ops.iarr([x[2] for x in j]), ops.iarr([x[3] for x in j]),
+                                             ops.parr([x[4].data_ptr() for x in j]), ops.iarr([x[5] for x in j]),
+                                             _stream()), 'colsum_finalize_multi')
+        self.jobs = []
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dx=None, accumulate_params=False, queue=None):
+    """dx (given: accumulated into; None: created) fp32; dgamma / dbeta fp32 gradient views.  queue: a ColsumQueue
+    that finalizes dgamma / dbeta later (their partials then live in a buffer of this call)."""
     r, c = x.shape
     acc = dx is not None
     if dx is None:
         dx = torch.empty((r, c), device=x.device, dtype=torch.float32)
-    ws = workspace(lib.sacv_layernorm_bwd_workspace_floats(r, c) * 4, x.device, 'ln')
+    nfl = lib.sacv_layernorm_bwd_workspace_floats(r, c)
+    if queue is None:
+        ws = workspace(nfl * 4, x.device, 'ln')
+        check(lib.sacv_layernorm_bwd(_ptr(_chk(dy, 'dy', BF16)), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx),
+                                     _ptr(dgamma), _ptr(dbeta), r, c, int(acc), int(accumulate_params),
+                                     ws.data_ptr(), _stream()), 'layernorm_bwd')
+        return dx
+    part = torch.empty(nfl, device=x.device, dtype=torch.float32)
     check(lib.sacv_layernorm_bwd(_ptr(_chk(dy, 'dy', BF16)), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(dx),
-                                 _ptr(dgamma), _ptr(dbeta), r, c, int(acc), int(accumulate_params), ws.data_ptr(),
-                                 _stream()), 'layernorm_bwd')
+                                 None, None, r, c, int(acc), int(accumulate_params), part.data_ptr(), _stream()),
+          'layernorm_bwd')
+    nb = lib.sacv_layernorm_bwd_partial_rows(r)
+    queue.add(part, nb, 2 * c, c, dbeta, accumulate_params)
+    queue.add(part[c:], nb, 2 * c, c, dgamma, accumulate_params)
     return dx
 
 
@@ -115,11 +150,18 @@ def gelu_bwd(dy, x):
     return dx
 
 
-def colsum_bf16(x, out, accumulate=False):
+def colsum_bf16(x, out, accumulate=False, queue=None):
     r, c = x.shape
-    ws = workspace(lib.sacv_colsum_bf16_workspace_floats(r, c) * 4, x.device, 'colsum')
-    check(lib.sacv_colsum_bf16(_ptr(_chk(x, 'colsum x', BF16)), _ptr(out), r, c, int(accumulate), ws.data_ptr(),
+    nfl = lib.sacv_colsum_bf16_workspace_floats(r, c)
+    if queue is None:
+        ws = workspace(nfl * 4, x.device, 'colsum')
+        check(lib.sacv_colsum_bf16(_ptr(_chk(x, 'colsum x', BF16)), _ptr(out), r, c, int(accumulate), ws.data_ptr(),
+                                   _stream()), 'colsum_bf16')
+        return out
+    part = torch.empty(nfl, device=x.device, dtype=torch.float32)
+    check(lib.sacv_colsum_bf16(_ptr(_chk(x, 'colsum x', BF16)), None, r, c, int(accumulate), part.data_ptr(),
                                _stream()), 'colsum_bf16')
+    queue.add(part, lib.sacv_colsum_bf16_partial_rows(r), c, c, out, accumulate)
     return out
 
 
@@ -204,10 +246,10 @@ def linear_dgrad(dy, w_dpanel, k):
     return ops.conv_gemm([dy.view(1, 1, r, n)], w_dpanel, k, 1, 1, 1, 0, 1, [(1, r)])[0].view(r, k)
 
 
-def linear_wgrad(dy, x, dw, db):
-    """dw[N,K] = dy^T x (fp32 gradient view), db[N] = column sums of dy."""
+def linear_wgrad(dy, x, dw, db, queue=None):
+    """dw[N,K] = dy^T x (fp32 gradient view), db[N] = column sums of dy (second stage through `queue` when given)."""
     r, n = dy.shape
     k = x.shape[1]
     ops.conv_wgrad([dy.view(1, 1, r, n)], [x.view(1, 1, r, k)], dw.reshape(n, k, 1, 1), k, 1, 1, 1, 0)
     if db is not None:
-        colsum_bf16(dy, db)
+        colsum_bf16(dy, db, queue=queue)

@@ -562,39 +562,56 @@ __global__ __launch_bounds__(256) void pack_dgrad_batched_bf16_kernel(const Pack
   }
 }
 
-// im2col of the stem for the bf16 GEMM: fp32 image (any strides) -> bf16 [M][Kpad], Kpad a multiple of 64
-__global__ void im2col_stem_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ col, int Nb, int Cin, int H,
-                                        int W, long long sN, long long sC, long long sH, long long sW, int Ho, int Wo,
-                                        int KH, int KW, int stride, int pad, int Kpad) {
+// im2col of the stem for the bf16 GEMM: fp32 image (any strides) -> bf16 [M][Kpad], Kpad a multiple of 64.
+// A block = STEM_PW consecutive output pixels of one output row: the KH input rows they touch are staged in LDS as
+// [kh][column][ci] with coalesced, bounds-masked loads (zero outside the image), and a matrix row is then KH runs of
+// KW * Cin contiguous LDS floats.  A thread owns one 8-wide k group (LDS offsets computed once) and walks the pixels;
+// the 16-byte stores of a block cover contiguous rows.  (Gathering straight from the image -- 8 scattered 4-byte loads
+// per 16-byte store -- ran at 1.65 TB/s of the 1.2 GB this writes at batch 256.)
+#define STEM_PW 32
+__global__ __launch_bounds__(256) void im2col_stem_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ col,
+                                                               int Nb, int Cin, int H, int W, long long sN,
+                                                               long long sC, long long sH, long long sW, int Ho,
+                                                               int Wo, int KH, int KW, int stride, int pad, int Kpad) {
+  extern __shared__ float patch[];  // [KH][span][Cin]
+  const int span = (STEM_PW - 1) * stride + KW;
+  const int wo0 = blockIdx.x * STEM_PW, ho = blockIdx.y, n = blockIdx.z;
+  const int hb = ho * stride - pad, wb0 = wo0 * stride - pad;
+  const float* __restrict__ src = x + n * sN;
+  const int per_row = span * Cin;
+  for (int i = threadIdx.x; i < KH * per_row; i += 256) {
+    const int kh = i / per_row, r = i - kh * per_row;
+    const int cidx = r / Cin, ci = r - cidx * Cin;
+    const int hi = hb + kh, wi = wb0 + cidx;
+    float v = 0.f;
+    if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v = src[ci * sC + hi * sH + wi * sW];
+    patch[i] = v;
+  }
+  __syncthreads();
   const int G = Kpad >> 3;
-  const size_t total = (size_t)Nb * Ho * Wo * G;
-  const int K = KH * KW * Cin;
-  const float rcin = 1.0f / (float)Cin, rkw = 1.0f / (float)KW;
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-    const int gq = (int)(t % G);
-    const size_t m = t / G;
-    const int wo = (int)(m % Wo);
-    const size_t qq = m / Wo;
-    const int ho = (int)(qq % Ho);
-    const int n = (int)(qq / Ho);
-    const float* __restrict__ src = x + n * sN;
-    const int hb = ho * stride - pad, wb = wo * stride - pad;
+  const int RPB = 256 / G;
+  const int gq = threadIdx.x % G, pr = threadIdx.x / G;
+  if (pr >= RPB) return;
+  const int K = KH * KW * Cin, run = KW * Cin;
+  int off[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 8 * gq + e;
+    if (k < K) {
+      const int kh = k / run;
+      off[e] = kh * per_row + (k - kh * run);
+    } else {
+      off[e] = -1;
+    }
+  }
+  const int npw = min(STEM_PW, Wo - wo0);
+  const size_t m0 = ((size_t)n * Ho + ho) * Wo + wo0;
+  for (int pq = pr; pq < npw; pq += RPB) {
+    const float* base = patch + pq * stride * Cin;
     bf16x8 v;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = 8 * gq + e;
-      float f = 0.f;
-      if (k < K) {
-        const int tap = (int)(((float)k + 0.5f) * rcin);
-        const int ci = k - tap * Cin;
-        const int kh = (int)(((float)tap + 0.5f) * rkw);
-        const int kw = tap - kh * KW;
-        const int hi = hb + kh, wi = wb + kw;
-        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) f = src[ci * sC + hi * sH + wi * sW];
-      }
-      v[e] = (bf16)f;
-    }
-    *reinterpret_cast<bf16x8*>(col + t * 8) = v;
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)(off[e] >= 0 ? base[off[e]] : 0.f);
+    *reinterpret_cast<bf16x8*>(col + ((m0 + pq) * G + gq) * 8) = v;
   }
 }
 
@@ -832,11 +849,14 @@ int sacv_im2col_stem_bf16(const float* x, void* col, int Nb, int Cin, int H, int
                           void* stream) {
   SACV_CHECK_ARG(x && col, "im2col_stem_bf16: null pointer");
   SACV_CHECK_ARG(Kpad % 64 == 0 && Kpad >= Cin * KH * KW, "im2col_stem_bf16: Kpad must be a multiple of 64 >= K");
-  const size_t total = (size_t)Nb * Ho * Wo * (Kpad / 8);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(im2col_stem_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (bf16*)col, Nb, Cin,
-                     H, W, sN, sC, sH, sW, Ho, Wo, KH, KW, stride, pad, Kpad);
+  SACV_CHECK_ARG(Kpad / 8 <= 256, "im2col_stem_bf16: Kpad %d too large", Kpad);
+  const size_t lds = (size_t)KH * ((STEM_PW - 1) * stride + KW) * Cin * sizeof(float);
+  SACV_CHECK_ARG(lds <= 64 * 1024, "im2col_stem_bf16: %d x %d taps, stride %d, %d channels do not fit the LDS patch", KH,
+                 KW, stride, Cin);
+  SACV_CHECK_ARG(Ho <= 65535 && Nb <= 65535, "im2col_stem_bf16: grid");
+  hipLaunchKernelGGL(im2col_stem_bf16_kernel, dim3((Wo + STEM_PW - 1) / STEM_PW, Ho, Nb), dim3(256), lds,
+                     (hipStream_t)stream, x, (bf16*)col, Nb, Cin, H, W, sN, sC, sH, sW, Ho, Wo, KH, KW, stride, pad,
+                     Kpad);
   SACV_CHECK_LAUNCH("im2col_stem_bf16");
   return SACV_OK;
 }

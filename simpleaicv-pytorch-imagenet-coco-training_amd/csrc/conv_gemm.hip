@@ -890,39 +890,48 @@ __global__ void pack_w_stem_kernel(const float* __restrict__ w, float* __restric
 // explicit im2col for the 7x7/s2 stem (Cin = 3 is too narrow for 16-byte gathers):
 // col[m][k], k = (kh*KW+kw)*Cin + ci, zero padded to Kpad.  Input given by element strides so
 // NCHW-contiguous and channels_last images are both accepted (SURVEY.md finding 3).
-__global__ void im2col_stem_kernel(const float* __restrict__ x, float* __restrict__ col, int Nb, int Cin, int H,
-                                   int W, long long sN, long long sC, long long sH, long long sW, int Ho, int Wo,
-                                   int KH, int KW, int stride, int pad, int Kpad) {
-  // one thread per 4 consecutive k of one output pixel: the pixel decode (two integer divisions) is shared by
-  // the four elements, the small k -> (kh, kw, ci) decodes use exact float reciprocals (k < 2^10), and the
-  // result leaves as one coalesced 16-byte store.
+__global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restrict__ x, float* __restrict__ col, int Nb,
+                                                          int Cin, int H, int W, long long sN, long long sC,
+                                                          long long sH, long long sW, int Ho, int Wo, int KH, int KW,
+                                                          int stride, int pad, int Kpad) {
+  // a thread owns ONE group of 4 consecutive k (its k -> (kh, kw, ci) decode is done once) and walks output pixels;
+  // the block is G = Kpad / 4 groups x RPB pixels, so its 16-byte stores cover contiguous rows of the matrix
   const int G = Kpad >> 2;
-  const size_t total = (size_t)Nb * Ho * Wo * G;
+  const int RPB = 256 / G;
+  const int g = threadIdx.x % G, pr = threadIdx.x / G;
+  if (pr >= RPB) return;
   const int K = KH * KW * Cin;
-  const float rcin = 1.0f / (float)Cin, rkw = 1.0f / (float)KW;
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-    const int g = (int)(t % G);
-    const size_t m = t / G;
+  int kh[4], kw[4];
+  long long koff[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int k = 4 * g + e;
+    if (k < K) {
+      const int tap = k / Cin, ci = k - tap * Cin;
+      kh[e] = tap / KW;
+      kw[e] = tap - kh[e] * KW;
+      koff[e] = ci * sC + kh[e] * sH + kw[e] * sW;
+    } else {
+      kh[e] = -100000;  // never inside the image
+      kw[e] = 0;
+      koff[e] = 0;
+    }
+  }
+  const size_t npix = (size_t)Nb * Ho * Wo;
+  for (size_t m = (size_t)blockIdx.x * RPB + pr; m < npix; m += (size_t)gridDim.x * RPB) {
     const int wo = (int)(m % Wo);
     const size_t q = m / Wo;
     const int ho = (int)(q % Ho);
     const int n = (int)(q / Ho);
-    const float* __restrict__ src = x + n * sN;
     const int hb = ho * stride - pad, wb = wo * stride - pad;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ src = x + n * sN + hb * sH + wb * sW;
+    f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int k = 4 * g + e;
-      if (k < K) {
-        const int tap = (int)(((float)k + 0.5f) * rcin);
-        const int ci = k - tap * Cin;
-        const int kh = (int)(((float)tap + 0.5f) * rkw);
-        const int kw = tap - kh * KW;
-        const int hi = hb + kh, wi = wb + kw;
-        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) v[e] = src[ci * sC + hi * sH + wi * sW];
-      }
+      const bool ok = ((unsigned)(hb + kh[e]) < (unsigned)H) & ((unsigned)(wb + kw[e]) < (unsigned)W);
+      v[e] = ok ? src[koff[e]] : 0.f;
     }
-    *reinterpret_cast<f32x4*>(col + t * 4) = v;
+    *reinterpret_cast<f32x4*>(col + (m * G + g) * 4) = v;
   }
 }
 
@@ -1328,9 +1337,11 @@ int sacv_im2col_stem(const float* x, float* col, int Nb, int Cin, int H, int W, 
                      void* stream) {
   SACV_CHECK_ARG(x && col, "im2col_stem: null pointer");
   SACV_CHECK_ARG(Kpad % 32 == 0 && Kpad >= Cin * KH * KW, "im2col_stem: Kpad must be a multiple of 32 >= K");
-  size_t total = (size_t)Nb * Ho * Wo * (Kpad / 4);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 65536) blocks = 65536;
+  SACV_CHECK_ARG(Kpad / 4 <= 256, "im2col_stem: Kpad %d too large", Kpad);
+  const size_t npix = (size_t)Nb * Ho * Wo;
+  const int rpb = 256 / (Kpad / 4);
+  const size_t nblk = (npix + rpb - 1) / rpb;
+  const int blocks = (int)(nblk > 16384 ? 16384 : nblk);
   hipLaunchKernelGGL(im2col_stem_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, col, Nb, Cin, H, W, sN,
                      sC, sH, sW, Ho, Wo, KH, KW, stride, pad, Kpad);
   SACV_CHECK_LAUNCH("im2col_stem");

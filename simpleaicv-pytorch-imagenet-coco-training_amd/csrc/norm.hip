@@ -57,43 +57,47 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_partial_kernel(const floa
   }
 }
 
-// Second stage: 16 channels per 256-thread block, 16 threads per channel each summing a fixed strided
-// subset of the per-block partials (coalesced 64-byte rows), then a fixed-order fp64 combine in LDS.
-#define FIN_CH 4
-#define FIN_PARTS 64
+// Second stage: `fch` channels per 256-thread block (4, or 1 when there are many partial rows and few channels: a
+// 64-channel layer at batch 256 has 6 272 rows of partials and would otherwise run on 16 workgroups), 256 / fch threads
+// per channel each summing a fixed strided subset of the per-block partials, then a fixed-order fp64 combine in LDS.
+#define FIN_THREADS 256
+__device__ __forceinline__ int fin_channels(int nblocks, int C) { return (nblocks >= 2048 && C <= 1024) ? 1 : 4; }
+static int fin_channels_host(int nblocks, int C) { return (nblocks >= 2048 && C <= 1024) ? 1 : 4; }
 __device__ __forceinline__ void finalize_sums(const float* __restrict__ partial, int nblocks, int C, int c, int part,
-                                              bool valid, double* red, double& s, double& q) {
+                                              int fch, bool valid, double* red, double& s, double& q) {
+  const int parts = FIN_THREADS / fch;
   double ls = 0.0, lq = 0.0;
   if (valid) {
-    for (int b = part; b < nblocks; b += FIN_PARTS) {
+    for (int b = part; b < nblocks; b += parts) {
       ls += (double)partial[(size_t)b * 2 * C + c];
       lq += (double)partial[(size_t)b * 2 * C + C + c];
     }
   }
-  const int cl = threadIdx.x % FIN_CH;
-  red[(part * FIN_CH + cl) * 2 + 0] = ls;
-  red[(part * FIN_CH + cl) * 2 + 1] = lq;
+  const int cl = threadIdx.x % fch;
+  red[(part * fch + cl) * 2 + 0] = ls;
+  red[(part * fch + cl) * 2 + 1] = lq;
   __syncthreads();
   s = 0.0;
   q = 0.0;
   if (part == 0) {
-    for (int k = 0; k < FIN_PARTS; ++k) {
-      s += red[(k * FIN_CH + cl) * 2 + 0];
-      q += red[(k * FIN_CH + cl) * 2 + 1];
+    for (int k = 0; k < parts; ++k) {
+      s += red[(k * fch + cl) * 2 + 0];
+      q += red[(k * fch + cl) * 2 + 1];
     }
   }
 }
 
-__global__ __launch_bounds__(FIN_CH* FIN_PARTS) void bn_stats_finalize_kernel(
+__global__ __launch_bounds__(FIN_THREADS) void bn_stats_finalize_kernel(
     const float* __restrict__ partial, int nblocks, int R, int C, float eps, float momentum, float* __restrict__ mean,
     float* __restrict__ invstd, float* __restrict__ running_mean, float* __restrict__ running_var,
     long long* __restrict__ num_batches_tracked) {
-  __shared__ double red[FIN_CH * FIN_PARTS * 2];
-  const int cl = threadIdx.x % FIN_CH, part = threadIdx.x / FIN_CH;
-  const int c = blockIdx.x * FIN_CH + cl;
+  __shared__ double red[FIN_THREADS * 2];
+  const int fch = fin_channels(nblocks, C);
+  const int cl = threadIdx.x % fch, part = threadIdx.x / fch;
+  const int c = blockIdx.x * fch + cl;
   if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
   double s, q;
-  finalize_sums(partial, nblocks, C, c, part, c < C, red, s, q);
+  finalize_sums(partial, nblocks, C, c, part, fch, c < C, red, s, q);
   if (part != 0 || c >= C) return;
   double m = s / R;
   double var = q / R - m * m;
@@ -256,17 +260,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const T* __r
 
 // dgamma/dbeta (assign or accumulate) + per-channel means kept in `coef` for the apply pass:
 // coef[0][c] = sum_g / R, coef[1][c] = sum_gx / R
-__global__ __launch_bounds__(FIN_CH* FIN_PARTS) void bn_bwd_finalize_kernel(const float* __restrict__ partial,
+__global__ __launch_bounds__(FIN_THREADS) void bn_bwd_finalize_kernel(const float* __restrict__ partial,
                                                                               int nblocks, int R, int C,
                                                                               float* __restrict__ dgamma,
                                                                               float* __restrict__ dbeta,
                                                                               float* __restrict__ coef,
                                                                               int accumulate) {
-  __shared__ double red[FIN_CH * FIN_PARTS * 2];
-  const int cl = threadIdx.x % FIN_CH, part = threadIdx.x / FIN_CH;
-  const int c = blockIdx.x * FIN_CH + cl;
+  __shared__ double red[FIN_THREADS * 2];
+  const int fch = fin_channels(nblocks, C);
+  const int cl = threadIdx.x % fch, part = threadIdx.x / fch;
+  const int c = blockIdx.x * fch + cl;
   double s, q;
-  finalize_sums(partial, nblocks, C, c, part, c < C, red, s, q);
+  finalize_sums(partial, nblocks, C, c, part, fch, c < C, red, s, q);
   if (part != 0 || c >= C) return;
   if (accumulate) {
     dbeta[c] += (float)s;
@@ -375,7 +380,8 @@ static int bn_train_bwd_impl(const T* dz, const T* zmask, const T* y, const floa
   hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(nb), dim3(BN_THREADS), lds_for(C, V), st, dz, zmask, y, mean,
                      invstd, gamma, zmask ? nullptr : beta, workspace, R, C, rpb);
   SACV_CHECK_LAUNCH("bn_bwd_partial");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, st,
+  const int FCH = fin_channels_host(nb, C);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FCH - 1) / FCH), dim3(FIN_THREADS), 0, st,
                      workspace, nb, R, C, dgamma,
                      dbeta, coef, accumulate);
   SACV_CHECK_LAUNCH("bn_bwd_finalize");
@@ -408,7 +414,8 @@ int sacv_bn_train_stats(const float* y, int R, int C, float eps, float momentum,
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(BN_THREADS), lds_for(C), st, y, workspace, R, C, rpb);
   SACV_CHECK_LAUNCH("bn_stats_partial");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0, st,
+  const int FCH = fin_channels_host(nb, C);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FCH - 1) / FCH), dim3(FIN_THREADS), 0, st,
                      workspace, nb, R, C, eps,
                      momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
   SACV_CHECK_LAUNCH("bn_stats_finalize");
@@ -421,7 +428,8 @@ int sacv_bn_finalize_stats(const float* partial, int nblocks, int R, int C, floa
                            float* invstd, float* running_mean, float* running_var, long long* num_batches_tracked,
                            void* stream) {
   SACV_CHECK_ARG(partial && mean && invstd && nblocks > 0 && R > 0 && C > 0, "bn_finalize_stats: bad args");
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_CH * FIN_PARTS), 0,
+  const int FCH = fin_channels_host(nblocks, C);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FCH - 1) / FCH), dim3(FIN_THREADS), 0,
                      (hipStream_t)stream, partial, nblocks, R, C, eps, momentum, mean, invstd, running_mean,
                      running_var, num_batches_tracked);
   SACV_CHECK_LAUNCH("bn_stats_finalize");

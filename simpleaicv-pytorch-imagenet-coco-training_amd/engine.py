@@ -27,7 +27,7 @@ def _out_hw(h, w, k, s, p):
 
 class _CBA:
     """Saved state of one conv + BatchNorm (+ residual) (+ ReLU) layer."""
-    __slots__ = ('prefix', 'x', 'y', 'mean', 'invstd', 'z', 'k', 'stride', 'pad', 'relu', 'residual')
+    __slots__ = ('prefix', 'x', 'y', 'mean', 'invstd', 'z', 'k', 'stride', 'pad', 'relu', 'residual', 'wino_v')
 
 
 class DetectorEngine:
@@ -117,11 +117,31 @@ class DetectorEngine:
         cout = w.shape[0]
         wp = self._fwd_panel(w)
         hw = _out_hw(x.shape[1], x.shape[2], k, stride, pad)
+        if self._wino_trunk_ok(x, w, k, stride, pad):
+            # stride-1 3x3 conv with enough work items for the Winograd GEMM (the bs-256 classifier's layer2 / layer3)
+            v = self._wino_inputs([[x], [x]], keep and training, shared=True)[0]
+            r = ops.conv3x3_wino([[x]], [self._wino_u(w)], [cout], vs=[v], stats=training)
+            (y,), st = (r[0][0], r[1][0]) if training else (r[0], None)
+            z, c = self._bn_fwd(x, y, prefix, k, stride, pad, relu, training, residual, keep, st)
+            if c is not None:
+                c.wino_v = v if training else None
+            return z, c
         if training:  # batch statistics come out of the conv epilogue (no extra pass over y)
             (y,), st = ops.conv_gemm([x], wp, cout, k, k, stride, pad, 0, [hw], stats=True)
         else:
             y, st = ops.conv_gemm([x], wp, cout, k, k, stride, pad, 0, [hw])[0], None
         return self._bn_fwd(x, y, prefix, k, stride, pad, relu, training, residual, keep, st)
+
+    WINO_TRUNK_MIN_ITEMS = 300  # 64-tile x 128-channel work items from which a trunk 3x3 conv takes the Winograd path
+
+    def _wino_trunk_ok(self, x, w, k, stride, pad):
+        if not (self._use_wino() and k == 3 and stride == 1 and pad == 1):
+            return False
+        cout, cin = w.shape[0], w.shape[1]
+        if cin < 128 or cout < 128 or cin % 32 != 0:
+            return False
+        tiles = x.shape[0] * ((x.shape[1] + 1) // 2) * ((x.shape[2] + 1) // 2)
+        return -(-tiles // 64) * -(-cout // 128) >= self.WINO_TRUNK_MIN_ITEMS
 
     def _bn_fwd(self, x, y, prefix, k, stride, pad, relu, training, residual, keep, stats=None):
         p = self.p
@@ -142,6 +162,7 @@ class DetectorEngine:
         if not keep:
             return z, None
         c = _CBA()
+        c.wino_v = None
         c.prefix, c.x, c.y, c.mean, c.invstd, c.z = prefix, x, y, mean, invstd, z
         c.k, c.stride, c.pad, c.relu, c.residual = k, stride, pad, relu, residual is not None
         return z, c
@@ -158,6 +179,15 @@ class DetectorEngine:
                                   relu_beta=p[bn + 'bias'] if recompute else None)
         w = p[wname]
         cin = w.shape[1]
+        v = getattr(c, 'wino_v', None)
+        if v is not None:  # the forward pass took the Winograd path: so do both gradients
+            self._wino_wgrad([dy], [c.x], v, g[wname], cin)
+            dx = None
+            if need_dx:
+                dx = ops.conv3x3_wino([[dy]], [self._wino_u(w, dgrad=True)], [cin],
+                                      flags=[CF_ACCUM if dx_accum else 0],
+                                      outs_list=[[dx_out]] if dx_out is not None else None, mode=1)[0][0]
+            return dx, gm
         self._wgrad([dy], [c.x], g[wname], cin, c.k, c.k, c.stride, c.pad)
         dx = None
         if need_dx:
@@ -822,6 +852,7 @@ class ClassifierEngine(DetectorEngine):
     def forward(self, images, training=True, keep=True):
         """images logical [B,3,H,W] -> logits [B, num_classes]"""
         ctx = {} if keep else None
+        self._wino_cache = {}  # Winograd-domain weights are per forward (see DetectorEngine.forward)
         if keep:
             self._refresh_dgrad_panels()
         c5 = self._backbone_fwd(images, training, keep, ctx)[3]

@@ -228,3 +228,36 @@ def test_detector_step_winograd_matches_direct(name, crit):
     # difference of the conv outputs comes out amplified (the fixtures hold this model's gradients to 3e-4 median /
     # 9e-3 max against the reference, tests/test_gpu_fcos.py)
     assert worst[0] < (2e-4 if name == 'resnet50_retinanet' else 1e-3), worst
+
+
+def test_classifier_trunk_convs_on_winograd_vs_fp64_oracle():
+    """ResNet50 classifier with the trunk's stride-1 3x3 convolutions of layer2-4 forced onto the Winograd path
+    (production threshold: 300 work items, reached at batch 256): loss vs the oracle within 1e-4, all gradients vs the
+    fp64 oracle no worse than 2x the fp32 CPU oracle's own error -- the bar of tests/test_gpu_cls.py for the direct
+    path.  The BatchNorm batch statistics come from the Winograd epilogue's column sums here."""
+    from sacv_amd.classification import losses
+    from tests.test_cls_cpu import oracle_cls_run
+    from tests.test_gpu_cls import build
+    from tests import golden_inputs as gi
+    meta = dict(B=4, R=64, num_classes=1000)
+    _, loss_r, params_r, _, _, _ = oracle_cls_run('cls_64', meta)
+    _, _, params_64, _, _, _ = oracle_cls_run('cls_64', meta, torch.float64)
+    net = build(1000)
+    net.engine.WINO_TRUNK_MIN_ITEMS = 1
+    x = torch.tensor(synth.images(11, 4, 64, 64)).cuda().contiguous(memory_format=torch.channels_last)
+    lab = torch.tensor(gi.labels_for(23, 4, 1000)).cuda()
+    logits = net(x)
+    used = [c for saved, _, _ in net.engine.ctx['blocks'] for c in saved
+            if c is not None and getattr(c, 'wino_v', None) is not None]
+    assert len(used) == 10, len(used)  # conv2 of the stride-1 blocks of layer2 (3), layer3 (5), layer4 (2)
+    loss = losses.__dict__['CELoss']()(logits, lab)
+    assert abs(float(loss) - float(loss_r)) <= 1e-4 * max(1.0, abs(float(loss_r)))
+    loss.backward()
+    num_g = num_c = den = 0.0
+    for k, p in net.named_parameters():
+        exact = params_64[k].grad
+        num_g += float((p.grad.double().cpu() - exact).norm())**2
+        num_c += float((params_r[k].grad.double() - exact).norm())**2
+        den += float(exact.norm())**2
+    e_gpu, e_cpu = (num_g / den)**0.5, (num_c / den)**0.5
+    assert e_gpu <= 2.0 * e_cpu + 1e-3, (e_gpu, e_cpu)

@@ -132,7 +132,7 @@ class DetectorEngine:
             y, st = ops.conv_gemm([x], wp, cout, k, k, stride, pad, 0, [hw])[0], None
         return self._bn_fwd(x, y, prefix, k, stride, pad, relu, training, residual, keep, st)
 
-    WINO_TRUNK_MIN_ITEMS = 300  # 64-tile x 128-channel work items from which a trunk 3x3 conv takes the Winograd path
+    WINO_TRUNK_MIN_ITEMS = 250  # 64-tile x 128-channel work items from which a trunk 3x3 conv takes the Winograd path
 
     def _wino_trunk_ok(self, x, w, k, stride, pad):
         if not (self._use_wino() and k == 3 and stride == 1 and pad == 1):

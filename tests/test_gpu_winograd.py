@@ -232,7 +232,7 @@ def test_detector_step_winograd_matches_direct(name, crit):
 
 def test_classifier_trunk_convs_on_winograd_vs_fp64_oracle():
     """ResNet50 classifier with the trunk's stride-1 3x3 convolutions of layer2-4 forced onto the Winograd path
-    (production threshold: 300 work items, reached at batch 256): loss vs the oracle within 1e-4, all gradients vs the
+    (production threshold: 250 work items, reached at batch 256): loss vs the oracle within 1e-4, all gradients vs the
     fp64 oracle no worse than 2x the fp32 CPU oracle's own error -- the bar of tests/test_gpu_cls.py for the direct
     path.  The BatchNorm batch statistics come from the Winograd epilogue's column sums here."""
     from sacv_amd.classification import losses

@@ -119,7 +119,7 @@ class DetectorEngine:
         hw = _out_hw(x.shape[1], x.shape[2], k, stride, pad)
         if self._wino_trunk_ok(x, w, k, stride, pad):
             # stride-1 3x3 conv with enough work items for the Winograd GEMM (the bs-256 classifier's layer2 / layer3)
-            v = self._wino_inputs([[x], [x]], keep and training, shared=True)[0]
+            v = self._wino_input([x], keep and training)
             r = ops.conv3x3_wino([[x]], [self._wino_u(w)], [cout], vs=[v], stats=training)
             (y,), st = (r[0][0], r[1][0]) if training else (r[0], None)
             z, c = self._bn_fwd(x, y, prefix, k, stride, pad, relu, training, residual, keep, st)
@@ -349,7 +349,7 @@ class DetectorEngine:
         if not self._use_wino() or tiles < self.WINO_MIN_TILES:
             return self._conv_bias(x, name, 3, 1, 1)
         keep = ctx is not None
-        v = self._wino_inputs([[x], [x]], keep, shared=True)[0]
+        v = self._wino_input([x], keep)
         if keep:
             ctx['wino_v:' + name] = v
         return ops.conv3x3_wino([[x]], [self._wino_u(w)], [w.shape[0]], biases=[self.p[name + '.bias']], vs=[v])[0][0]
@@ -460,18 +460,20 @@ class DetectorEngine:
                 ctx[self.RETINA_TOWERS[t][0] + '.wino_v'] = vsaved[t]
         return outs
 
+    def _wino_input(self, xs, keep, tag='wino_v0'):
+        """Transformed input V of a 3x3 convolution over the levels xs: a fresh tensor when it is kept for the weight
+        gradient of the backward pass, a shared scratch buffer otherwise."""
+        if not keep:
+            return ops.wino_input(xs, tag=tag)
+        nb, c = xs[0].shape[0], xs[0].shape[3]
+        _, tpad = ops.wino_tiles(nb, [(x.shape[1], x.shape[2]) for x in xs])
+        return ops.wino_input(xs, out=torch.empty((16, tpad, ops.wino_pad_k(c)), device=xs[0].device,
+                                                  dtype=torch.float32))
+
     def _wino_inputs(self, xs2, keep, shared=False):
-        """Transformed inputs of the two towers' next layer: fresh tensors when they are kept for the backward pass,
-        the shared scratch buffers otherwise."""
-        def one(xs, tag):
-            if not keep:
-                return ops.wino_input(xs, tag=tag)
-            nb, c = xs[0].shape[0], xs[0].shape[3]
-            _, tpad = ops.wino_tiles(nb, [(x.shape[1], x.shape[2]) for x in xs])
-            return ops.wino_input(xs, out=torch.empty((16, tpad, ops.wino_pad_k(c)), device=xs[0].device,
-                                                      dtype=torch.float32))
-        v0 = one(xs2[0], 'wino_v0')
-        return [v0, v0 if shared else one(xs2[1], 'wino_v1')]
+        """Transformed inputs of the two towers' next layer (one transform when both read the same levels)."""
+        v0 = self._wino_input(xs2[0], keep, 'wino_v0')
+        return [v0, v0 if shared else self._wino_input(xs2[1], keep, 'wino_v1')]
 
     def _wino_wgrad(self, dys, xs, v, dw, cin):
         """3x3 weight gradient: Winograd path from the kept V when the channel count allows it, else conv_tn."""

@@ -225,8 +225,8 @@ struct WinoRow {  // per tile row of the current item (LDS)
 // stages with TWO tiles in flight (counted vmcnt + raw s_barrier, cdna_hip_programming.md 5 "Pipelining across
 // barriers").  WN = waves along N: 2 -> 4 waves of 32 x 64 (<= 256 VGPRs, 2 waves per SIMD with two workgroups per
 // CU), 4 -> 8 waves of 32 x 32 (<= 128 VGPRs, 4 waves per SIMD).
-template <int BM, int BN, int WN>
-__global__ __launch_bounds__(128 * WN, WN) void wino_gemm_kernel(const WinoArgs a) {
+template <int BM, int BN, int WN, int OCC>
+__global__ __launch_bounds__(128 * WN, OCC) void wino_gemm_kernel(const WinoArgs a) {
   constexpr int NT = 128 * WN;
   constexpr int NW = NT / 64;
   constexpr int STAGE = (BM + BN) * 32;  // floats per stage (rows of 32 floats, no padding)
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(128 * WN, WN) void wino_gemm_kernel(const WinoArgs 
     // right for 8 consecutive lanes but is 2-way conflicting on the real groups: rows 12-15 meet rows 20-23.)
     constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;  // 8-row pieces per wave and tile
     constexpr int NG = PA + PB;                        // LDS-DMA instructions per wave and tile
-    static_assert(NG == 6 || NG == 3, "the counted waits below are written for 6 or 3 DMA instructions per tile");
+    static_assert(NG == 6 || NG == 4 || NG == 3, "the counted waits below are written for 6, 4 or 3 DMA instructions");
     const int prow = lane >> 3;
     // element offsets of this lane's 16 bytes inside a (g, kc) operand tile; the operands are zero-padded to whole
     // tiles (sacv_wino_pad_k / _pad_n), so every load is unconditional: scalar base + 32-bit lane offset
@@ -351,6 +351,8 @@ __global__ __launch_bounds__(128 * WN, WN) void wino_gemm_kernel(const WinoArgs 
     auto wait_one_in_flight = [&]() {  // all but the youngest tile's DMA instructions of this wave have landed
       if (NG == 6)
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (NG == 4)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else
         asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     };
@@ -828,7 +830,8 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
 #ifndef WINO_WN
 #define WINO_WN 2  // waves along N of the GEMM kernel (tuning builds: -DWINO_WN=4: 8 waves of 32 x 32, same speed)
 #endif
-template __global__ void wino_gemm_kernel<64, 128, WINO_WN>(const WinoArgs);
+template __global__ void wino_gemm_kernel<64, 128, WINO_WN, WINO_WN>(const WinoArgs);
+template __global__ void wino_gemm_kernel<64, 64, 2, 3>(const WinoArgs);
 
 // -------------------------------------------------------------------------------------------- host side
 static int wino_num_cus() {
@@ -969,24 +972,66 @@ int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, cons
     P.Np = Np;
     P.N = N[p];
     P.flags = flags[p];
-    P.item_begin = items;
-    P.ntn = (N[p] + 127) / 128;
-    items += ((P.T + 63) / 64) * P.ntn;
+    P.item_begin = 0;
+    P.ntn = 0;
   }
   a.nprob = nprob;
+  // Item shape: 64 tiles x 128 channels at 2 workgroups per CU, or x 64 channels at 3 per CU.  The wide item does 13 %
+  // more work per CU-second (fewer operand bytes per flop) but a launch is a few hundred items on 512 slots, so the
+  // makespan is a matter of rounds: measured on the 256-channel pyramid of 2 x 800x1333 (us, GEMM only) -- one tower
+  // (352 wide items) 296 wide / 249 narrow; two towers (704) 451 / 459; the 720-channel output conv (1056) 722 / 684.
+  // Cost model in units of one wide round: a narrow round is 0.845, partial rounds cost their measured fractions.
+  int mt_items = 0, wide = 0, narrow_items = 0;
+  for (int p = 0; p < nprob; ++p) {
+    mt_items = (a.p[p].T + 63) / 64;
+    wide += mt_items * ((a.p[p].N + 127) / 128);
+    narrow_items += mt_items * ((a.p[p].N + 63) / 64);
+  }
+  const int cus = wino_num_cus();
+  auto rounds_cost = [](double r, double t1, double t2, double t3) {  // r = items / slots
+    const double full = (double)(long long)r, f = r - full;
+    const double tail = f <= 1e-9 ? 0.0 : (f <= 1.0 / 3 ? t1 : (f <= 2.0 / 3 ? t2 : t3));
+    return full + tail;
+  };
+  const double cost_wide = rounds_cost((double)wide / (2 * cus), 0.45, 0.64, 1.0);
+  double cost_narrow = 0.845 * rounds_cost((double)narrow_items / (3 * cus), 0.5, 0.7, 0.85);
+  if (cost_narrow < 0.845) cost_narrow = 0.845;
+  const bool narrow = cost_narrow < cost_wide;
+  const int bn = narrow ? 64 : 128;
+  for (int p = 0; p < nprob; ++p) {
+    WinoProb& P = a.p[p];
+    P.item_begin = items;
+    P.ntn = (P.N + bn - 1) / bn;
+    items += ((P.T + 63) / 64) * P.ntn;
+  }
   a.total_items = items;
+  hipStream_t st = (hipStream_t)stream;
+  if (narrow) {
+    constexpr int BM = 64, BN = 64;
+    const int lds = 3 * (BM + BN) * 32 * 4 + BM * (int)sizeof(WinoRow);
+    static std::once_flag attr;
+    std::call_once(attr, [lds] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel<BM, BN, 2, 3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    });
+    int grid = wino_num_cus() * 3;
+    if (grid > items) grid = items;
+    hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, 2, 3>), dim3(grid), dim3(256), lds, st, a);
+    SACV_CHECK_LAUNCH("wino_gemm_kernel");
+    return SACV_OK;
+  }
   constexpr int BM = 64, BN = 128;
   constexpr int WN = WINO_WN;
   const int lds = 3 * (BM + BN) * 32 * 4 + BM * (int)sizeof(WinoRow);
   static_assert(2 * (BM + BN) * 32 >= BM * (BN + 4), "the epilogue stage must fit in the operand buffers");
   static std::once_flag attr;
   std::call_once(attr, [lds] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel<BM, BN, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel<BM, BN, WN, WN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
   int grid = wino_num_cus() * 2;
   if (grid > items) grid = items;
-  hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WN>), dim3(grid), dim3(128 * WN), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WN, WN>), dim3(grid), dim3(128 * WN), lds, st, a);
   SACV_CHECK_LAUNCH("wino_gemm_kernel");
   return SACV_OK;
 }

@@ -138,10 +138,15 @@ class DetectorEngine:
         if not (self._use_wino() and k == 3 and stride == 1 and pad == 1):
             return False
         cout, cin = w.shape[0], w.shape[1]
-        if cin < 128 or cout < 128 or cin % 32 != 0:
+        if cin < 64 or cout < 64 or cin % 32 != 0:
             return False
         tiles = x.shape[0] * ((x.shape[1] + 1) // 2) * ((x.shape[2] + 1) // 2)
-        return -(-tiles // 64) * -(-cout // 128) >= self.WINO_TRUNK_MIN_ITEMS
+        mtiles = -(-tiles // 64)
+        if cin >= 128 and cout >= 128:
+            return mtiles * -(-cout // 128) >= self.WINO_TRUNK_MIN_ITEMS
+        # 64-channel layers (K = 64: two K tiles per g, the transforms weigh more): only with thousands of items -- the
+        # bs-256 classifier's layer1 (3136); at 2 images per GPU the detector's layer1 (522 items) is slower than direct
+        return mtiles * -(-cout // 64) >= 8 * self.WINO_TRUNK_MIN_ITEMS
 
     def _bn_fwd(self, x, y, prefix, k, stride, pad, relu, training, residual, keep, stats=None):
         p = self.p

@@ -243,13 +243,13 @@ def test_classifier_trunk_convs_on_winograd_vs_fp64_oracle():
     _, loss_r, params_r, _, _, _ = oracle_cls_run('cls_64', meta)
     _, _, params_64, _, _, _ = oracle_cls_run('cls_64', meta, torch.float64)
     net = build(1000)
-    net.engine.WINO_TRUNK_MIN_ITEMS = 1
+    net.engine.WINO_TRUNK_MIN_ITEMS = 0
     x = torch.tensor(synth.images(11, 4, 64, 64)).cuda().contiguous(memory_format=torch.channels_last)
     lab = torch.tensor(gi.labels_for(23, 4, 1000)).cuda()
     logits = net(x)
     used = [c for saved, _, _ in net.engine.ctx['blocks'] for c in saved
             if c is not None and getattr(c, 'wino_v', None) is not None]
-    assert len(used) == 10, len(used)  # conv2 of the stride-1 blocks of layer2 (3), layer3 (5), layer4 (2)
+    assert len(used) == 13, len(used)  # conv2 of the stride-1 blocks: layer1 (3), layer2 (3), layer3 (5), layer4 (2)
     loss = losses.__dict__['CELoss']()(logits, lab)
     assert abs(float(loss) - float(loss_r)) <= 1e-4 * max(1.0, abs(float(loss_r)))
     loss.backward()

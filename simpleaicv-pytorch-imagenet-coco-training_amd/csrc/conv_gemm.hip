@@ -184,9 +184,12 @@ __device__ __forceinline__ int sk_range_begin(const ConvArgs& a, int KT, int b) 
   return (int)(((long long)b * a.rem_tiles * KT) / a.sk_blocks);
 }
 
-template <int BM, int BN, int MODE, int WN>
-__global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a) {
-  constexpr int LS = 36;
+// OCC = workgroups per CU the launch bounds allow for; SWZ = unpadded LDS rows (32 floats) with the 16-byte chunks
+// XOR-swizzled by key (row >> 1) & 7 (exact for the lane groups of ds_read_b128, as in winograd.hip) instead of rows
+// padded to 36 floats: the 128 x 64 variant then needs 48 KB and three workgroups fit a CU.
+template <int BM, int BN, int MODE, int WN, int OCC = WN, bool SWZ = false>
+__global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a) {
+  constexpr int LS = SWZ ? 32 : 36;
   constexpr int NT = 128 * WN;                 // 2 x WN waves
   constexpr int RPP = NT / 8;                  // tile rows fetched per pass (8 threads x 16 B per row)
   constexpr int RA = BM / RPP, RB = BN / RPP;
@@ -343,9 +346,11 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
     float* dA = sA + buf * BM * LS;
     float* dB = sB + buf * BN * LS;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(dA + (r0 + RPP * i) * LS + kq * 4) = ra[i];
+    for (int i = 0; i < RA; ++i)
+      *reinterpret_cast<f32x4*>(dA + (r0 + RPP * i) * LS + (SWZ ? ((kq ^ (((r0 + RPP * i) >> 1) & 7)) << 2) : kq * 4)) = ra[i];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(dB + (r0 + RPP * i) * LS + kq * 4) = rb[i];
+    for (int i = 0; i < RB; ++i)
+      *reinterpret_cast<f32x4*>(dB + (r0 + RPP * i) * LS + (SWZ ? ((kq ^ (((r0 + RPP * i) >> 1) & 7)) << 2) : kq * 4)) = rb[i];
   };
 
   f32x16 acc[TM][TN];
@@ -395,27 +400,30 @@ __global__ __launch_bounds__(128 * WN, WN) void conv_nt_kernel(const ConvArgs a)
       const bool have_next = !last || more;
       if (last && more) setup(sidx + 1);  // switch the gather state to the next segment
       load_begin(last ? k_begin : kt + 1, have_next && !SACV_ABL(1024));
-      const float* cA = sA + (SACV_ABL(8192) ? 0 : cur * BM * LS + (wm0 + l31) * LS + 4 * lh);
-      const float* cB = sB + (SACV_ABL(8192) ? 0 : cur * BN * LS + (wn0 + l31) * LS + 4 * lh);
+      const float* cA = sA + (SACV_ABL(8192) ? 0 : cur * BM * LS + (wm0 + l31) * LS + (SWZ ? 0 : 4 * lh));
+      const float* cB = sB + (SACV_ABL(8192) ? 0 : cur * BN * LS + (wn0 + l31) * LS + (SWZ ? 0 : 4 * lh));
+      // float offset of the 16-byte chunk (2 * quarter + lh) of this lane's fragment row (wm0, wn0, i * 32: multiples of 16)
+      const int x7 = (l31 >> 1) & 7;
+      auto qoff = [&](int quarter) { return SWZ ? (((quarter * 2 + lh) ^ x7) << 2) : quarter * 8; };
       // The next slab's gathers (address arithmetic + 16-byte loads) and the next fragments' LDS reads
       // are issued in the shadow of the current MFMAs (an fp32 32x32x2 MFMA occupies the matrix pipe
       // for 64 cycles but the issue port for 8), so a wave keeps the pipe busy on its own instead of
       // alternating a load phase with a math phase in lockstep with its SIMD partner.
       f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * LS);
+      for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * LS + qoff(0));
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * LS);
+      for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * LS + qoff(0));
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int cb = jj & 1, nbuf = cb ^ 1;
         if (jj < 3) {
 #pragma unroll
           for (int i = 0; i < TM; ++i)
-            fa[nbuf][i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * LS + (jj + 1) * 8);
+            fa[nbuf][i] = *reinterpret_cast<const f32x4*>(cA + i * 32 * LS + qoff(jj + 1));
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            fb[nbuf][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * LS + (jj + 1) * 8);
+            fb[nbuf][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * LS + qoff(jj + 1));
         }
         // one A gather and one B gather per quarter of the MFMA block.  (Issuing all eight in the first two
         // quarters, to give them more time before the LDS store, was measured: 122 -> 106-115 TF.)
@@ -1062,26 +1070,26 @@ static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w) {
   return p;
 }
 
-template <int BM, int BN, int MODE, int WN>
+template <int BM, int BN, int MODE, int WN, int OCC = SACV_NT_BLOCKS_PER_CU, bool SWZ = false>
 static int launch_nt(ConvArgs& a, const NtPlan& plan, float* workspace, hipStream_t st) {
-  int grid = num_cus() * SACV_NT_BLOCKS_PER_CU;
+  int grid = num_cus() * OCC;
   a.grid = grid;
   a.base = plan.base;
   a.rem_tiles = plan.rem;
   a.sk_blocks = plan.sk_blocks;
   a.partial = workspace;
-  size_t lds = (size_t)2 * (BM + BN) * 36 * sizeof(float);
+  size_t lds = (size_t)2 * (BM + BN) * (SWZ ? 32 : 36) * sizeof(float);
   size_t lds_epi = ((size_t)BM * (BN + 4) + 2 * (128 * WN / (BN / 4)) * BN) * sizeof(float);
   if (lds_epi > lds) lds = lds_epi;
   static std::once_flag attr_once;  // one per template instance; lds is a compile-time function of it
   std::call_once(attr_once, [lds] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN, MODE, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN, MODE, WN, OCC, SWZ>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   int launch_blocks = a.base > 0 ? grid : a.sk_blocks;
   SACV_CHECK_ARG(a.sk_blocks <= grid && (a.sk_blocks == 0 || a.sk_blocks >= a.rem_tiles),
                  "conv2d_gemm: stream-K plan outside the workspace (%d ranges)", a.sk_blocks);
-  hipLaunchKernelGGL((conv_nt_kernel<BM, BN, MODE, WN>), dim3(launch_blocks), dim3(128 * WN), lds, st, a);
+  hipLaunchKernelGGL((conv_nt_kernel<BM, BN, MODE, WN, OCC, SWZ>), dim3(launch_blocks), dim3(128 * WN), lds, st, a);
   SACV_CHECK_LAUNCH("conv_nt_kernel");
   if (a.sk_blocks > a.rem_tiles) {
     hipLaunchKernelGGL((conv_fixup_kernel<BM, BN>), dim3(a.rem_tiles), dim3(1024), 0, st, a);
@@ -1216,10 +1224,14 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
   const int KT = KH * KW * ((Cs + 31) / 32);
   const bool ws = workspace != nullptr;
   NtPlan p128 = plan_nt(tiles * ((N + 127) / 128), KT, grid, ws, 1.0);
-  NtPlan p64 = plan_nt(tiles * ((N + 63) / 64), KT, grid, ws, 0.6);
+  // 128 x 64 tiles run at THREE workgroups per CU (swizzled, unpadded 48 KB LDS image; 134-136 VGPRs): finer-grained
+  // rounds and a third workgroup to fill the CU while two sit in their epilogues.  Relative cost of a K-iteration 0.8
+  // (0.6-0.8 measured the same); against the two-per-CU form of the same kernel: 30.14 -> 29.85 ms per step.
+  NtPlan p64 = plan_nt(tiles * ((N + 63) / 64), KT, num_cus() * 3, ws, 0.8);
   const bool use64 = (N <= 64) || (p64.cost < p128.cost);
   if (use64)
-    return mode == 0 ? launch_nt<128, 64, 0, 2>(a, p64, workspace, st) : launch_nt<128, 64, 1, 2>(a, p64, workspace, st);
+    return mode == 0 ? launch_nt<128, 64, 0, 2, 3, true>(a, p64, workspace, st)
+                     : launch_nt<128, 64, 1, 2, 3, true>(a, p64, workspace, st);
   return mode == 0 ? launch_nt<128, 128, 0, SACV_NT_WN>(a, p128, workspace, st)
                    : launch_nt<128, 128, 1, SACV_NT_WN>(a, p128, workspace, st);
 }

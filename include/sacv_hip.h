@@ -67,6 +67,9 @@ int sacv_conv2d_gemm_stats_rows(int nprob, const int* Nb, const int* Hd, const i
 int sacv_wino_tiles(int nlev, int Nb, const int* H, const int* W /*host arrays*/);
 /* U[16][pad_n(N)][pad_k(K)] = G w G^T from a GEMM panel [N][9][K] (forward panel; data-gradient panel with flip = 1) */
 int sacv_wino_weights(const float* panel, float* U, int N, int K, int flip, void* stream);
+/* njobs (<= 32) such transforms in one launch (all Winograd layers of a model, both directions, once per step) */
+int sacv_wino_weights_batched(int njobs, const float* const* panel /*host arrays*/, float* const* U, const int* N,
+                              const int* K, const int* flip, void* stream);
 /* V[16][Tpad][pad_k(C)] = B^T d B of every 4x4 input patch; Tpad = tiles rounded up to a multiple of 64 */
 int sacv_wino_input(int nlev, const float* const* src /*host array*/, int Nb, const int* H, const int* W, int C,
                     float* V, int Tpad, void* stream);

@@ -26,6 +26,7 @@ SIGNATURES = {
     'sacv_conv2d_gemm_workspace_bytes': (LL, []),
     'sacv_wino_tiles': (I, [I, I, P, P]),
     'sacv_wino_weights': (I, [P, P, I, I, I, P]),
+    'sacv_wino_weights_batched': (I, [I, P, P, P, P, P, P]),
     'sacv_wino_input': (I, [I, P, I, P, P, I, P, I, P]),
     'sacv_wino_stats_rows': (I, [I]),
     'sacv_linear_bf16': (I, [P, P, P, P, P, LL, I, I, I, P]),

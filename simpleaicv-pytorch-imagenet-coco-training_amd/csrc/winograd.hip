@@ -89,6 +89,56 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
   }
 }
 
+// up to 32 weight transforms in one launch (all Winograd layers of a model, forward and data-gradient panels):
+// blockIdx.y = job
+#define WINO_WBATCH 32
+struct WinoWeightJobs {
+  const float* panel[WINO_WBATCH];
+  float* U[WINO_WBATCH];
+  int N[WINO_WBATCH], K[WINO_WBATCH], flip[WINO_WBATCH];
+};
+__global__ __launch_bounds__(256) void wino_weight_batched_kernel(const WinoWeightJobs j) {
+  const int job = blockIdx.y;
+  const int N = j.N[job], K = j.K[job], flip = j.flip[job];
+  const int Np = (N + 127) / 128 * 128, Kp = (K + 31) / 32 * 32;
+  const int k4n = Kp >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Np * k4n) return;
+  const int n = idx / k4n, k4 = idx - n * k4n;
+  const size_t gs = (size_t)Np * Kp;
+  float* o = j.U[job] + (size_t)n * Kp + k4 * 4;
+  if (n >= N || k4 * 4 >= K) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 16; ++g) *reinterpret_cast<f32x4*>(o + g * gs) = z;
+    return;
+  }
+  const float* p = j.panel[job] + (size_t)n * 9 * K + k4 * 4;
+  f32x4 g[3][3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int tap = flip ? (2 - kh) * 3 + (2 - kw) : kh * 3 + kw;
+      g[kh][kw] = *reinterpret_cast<const f32x4*>(p + (size_t)tap * K);
+    }
+  f32x4 t[4][3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) {
+    t[0][kw] = g[0][kw];
+    t[1][kw] = 0.5f * (g[0][kw] + g[1][kw] + g[2][kw]);
+    t[2][kw] = 0.5f * (g[0][kw] - g[1][kw] + g[2][kw]);
+    t[3][kw] = g[2][kw];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 0) * gs) = t[i][0];
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 1) * gs) = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 2) * gs) = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 3) * gs) = t[i][2];
+  }
+}
+
 // -------------------------------------------------------------------------------------------- geometry
 struct WinoGeom {
   int nlev;
@@ -898,6 +948,30 @@ int sacv_wino_weights(const float* panel, float* U, int N, int K, int flip, void
   hipLaunchKernelGGL(wino_weight_kernel, dim3(sacv_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, panel, U, N, K,
                      Np, Kp, flip);
   SACV_CHECK_LAUNCH("wino_weight_kernel");
+  return SACV_OK;
+}
+
+// njobs (<= 32) weight transforms in one launch: U[i] = transform of panel[i] ([N[i]][9][K[i]], flip[i])
+int sacv_wino_weights_batched(int njobs, const float* const* panel, float* const* U, const int* N, const int* K,
+                              const int* flip, void* stream) {
+  SACV_CHECK_ARG(njobs >= 1 && njobs <= WINO_WBATCH, "wino_weights_batched: njobs=%d (1..%d)", njobs, WINO_WBATCH);
+  WinoWeightJobs j;
+  int maxblocks = 0;
+  for (int i = 0; i < WINO_WBATCH; ++i) {
+    const int k = i < njobs ? i : 0;
+    SACV_CHECK_ARG(panel[k] && U[k] && N[k] > 0 && K[k] > 0 && K[k] % 4 == 0, "wino_weights_batched: bad job %d", k);
+    j.panel[i] = panel[k];
+    j.U[i] = U[k];
+    j.N[i] = N[k];
+    j.K[i] = K[k];
+    j.flip[i] = flip[k];
+    const int total = sacv_wino_pad_n(N[k]) * (sacv_wino_pad_k(K[k]) / 4);
+    SACV_CHECK_ARG((long long)sacv_wino_pad_n(N[k]) * sacv_wino_pad_k(K[k]) * 16 < (1LL << 30),
+                   "wino_weights_batched: panel too large");
+    if (i < njobs && sacv_cdiv(total, 256) > maxblocks) maxblocks = sacv_cdiv(total, 256);
+  }
+  hipLaunchKernelGGL(wino_weight_batched_kernel, dim3(maxblocks, njobs), dim3(256), 0, (hipStream_t)stream, j);
+  SACV_CHECK_LAUNCH("wino_weight_batched_kernel");
   return SACV_OK;
 }
 

@@ -231,6 +231,20 @@ def wino_weights(panel, n, k, flip=False, out=None):
     return out
 
 
+def wino_weights_batched(jobs):
+    """jobs: list of (panel, n, k, flip) -> list of U tensors, transformed by as few launches as possible (32 jobs each)."""
+    outs = [torch.empty((16, wino_pad_n(n), wino_pad_k(k)), device=p.device, dtype=torch.float32) for p, n, k, _ in jobs]
+    for b in range(0, len(jobs), 32):
+        chunk, us = jobs[b:b + 32], outs[b:b + 32]
+        for p, n, k, _ in chunk:
+            if p.numel() != n * 9 * k:
+                raise ValueError(f'wino_weights_batched: panel of {p.numel()} elements is not [{n}][9][{k}]')
+        check(lib.sacv_wino_weights_batched(len(chunk), parr([_ptr(p) for p, *_ in chunk]), parr([u.data_ptr() for u in us]),
+                                            iarr([n for _, n, _, _ in chunk]), iarr([k for _, _, k, _ in chunk]),
+                                            iarr([int(f) for *_, f in chunk]), _stream()), 'wino_weights_batched')
+    return outs
+
+
 def wino_input(srcs, out=None, tag='wino_v'):
     """V[16][Tpad][pad_k(C)] = B^T d B over all levels (NHWC fp32, one batch size, one channel count)."""
     nb, c = srcs[0].shape[0], srcs[0].shape[3]

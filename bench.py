@@ -205,6 +205,7 @@ def bench_classification(args, rank, world, group, ops, synth):
                                    + (', bf16 activations / fp32 accumulate+master weights (autocast)' if amp else ''),
                        'global_batch': world * CB, 'parallelism': f'dp{world}'},
             'loss': loss, 'roofline': roofline}), flush=True)
+    trainer.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -280,6 +281,7 @@ def bench_mae(args, rank, world, group, ops, synth):
                                    'AdamW), images [128,3,224,224]/GPU, random init, autocast dtypes',
                        'global_batch': world * MB, 'parallelism': f'dp{world}'},
             'loss': loss, 'roofline': roofline}), flush=True)
+    trainer.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -359,7 +361,8 @@ def main():
     else:
         net = models.__dict__['resnet50_retinanet'](backbone_pretrained_path='', num_classes=80).cuda().train()
         crit = losses.__dict__['RetinaLoss'](box_loss_type='SmoothL1')
-    trainer = DetectionTrainer(net, crit, lr=1e-4, weight_decay=1e-3, process_group=group)
+    trainer = DetectionTrainer(net, crit, lr=1e-4, weight_decay=1e-3, process_group=group,
+                               transport=os.environ.get('SACV_TRANSPORT', 'torch'))
     images = torch.tensor(synth.images(rank, BATCH, H, W)).cuda()
     annots = torch.tensor(synth.annotations(rank, BATCH, H, W, boxes_per_image=8)).cuda()
 
@@ -465,6 +468,11 @@ def main():
                             avg_launch_ms=round(per_launch_ms, 4), algorithmic_gflop_per_launch=round(
                                 per_launch_flops / 1e9, 2),
                             share_of_step_ms=round(k['ms'] / n_inst, 2))
+            # the same launches priced by the flops the matrix cores EXECUTE (Winograd F(2x2,3x3) runs 1/2.25 of the
+            # direct sum): this, not `frac`, is matrix-core utilisation
+            executed = (k['flops'] - wino['flops'] + wino['flops'] / 2.25) / (k['ms'] * 1e-3) / 1e12
+            roofline['matrix_core'] = dict(achieved=round(executed, 2), frac=round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
+                                           unit='TFLOP/s', note='executed MFMA flops / time of the same launches')
             roofline['instrumented_steps'] = f'{n_inst} of the {args.steps} timed steps (every {args.timer_every}th)'
             if paths:
                 roofline['paths'] = paths
@@ -498,6 +506,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.model == 'retinanet' and (H, W) == (800, 1333):
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
+    trainer.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -225,6 +225,16 @@ int sacv_decode_topk_nms(int kind, int nlev, const float* const* cls, const floa
                          const float* const* ctr, const int* level_off, const float* geom, int B, int A, int C,
                          float min_score, int topn, int nms_type, float nms_thr, int max_obj, void* workspace,
                          float* out_scores, float* out_classes, float* out_boxes, void* stream);
+/* The same front end followed by batched Soft-NMS (Bodla et al., ICCV 2017) instead of the hard suppression of
+ * DetNMSMethod (decode.py:26-104).  The reference has NO soft-NMS: this is the extra mode BASELINE.json's north_star
+ * names, an extension of DecodeMethod's nms_type (decode.py:121-172), parity unpinned.  method 0 linear (decay by
+ * 1 - IoU when IoU >= nms_thr), 1 gaussian (exp(-IoU^2 / sigma)); a box leaves the candidate set when its decayed
+ * score is <= prune_score; IoU as python_nms (decode.py:45-72).  Same workspace, same outputs (scores = decayed). */
+int sacv_decode_topk_soft_nms(int kind, int nlev, const float* const* cls, const float* const* reg,
+                              const float* const* ctr, const int* level_off, const float* geom, int B, int A, int C,
+                              float min_score, int topn, int method, float nms_thr, float sigma, float prune_score,
+                              int max_obj, void* workspace, float* out_scores, float* out_classes, float* out_boxes,
+                              void* stream);
 
 /* ---- data boundary either side of the step ------------------------------------- */
 /* DetectionCollater + Normalize (detection/common.py:223-286): B (<=16) uint8 [h][w][3] device images ->

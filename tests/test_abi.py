@@ -55,8 +55,12 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError, match='MI355X'):
         dec([[torch.zeros(1, 2, 2, 9, 80)], [torch.zeros(1, 2, 2, 9, 4)]])
     decode.__dict__['RetinaDecoder'](nms_type='torch_nms')  # torchvision.ops.nms semantics, no torchvision needed
-    with pytest.raises(AssertionError):
-        decode.__dict__['RetinaDecoder'](nms_type='soft_nms')
+    # the north-star's extra mode (not in the reference's DetNMSMethod): linear / gaussian Soft-NMS
+    for t in ('soft_nms', 'soft_nms_linear', 'soft_nms_gaussian'):
+        assert decode.__dict__['RetinaDecoder'](nms_type=t).soft is not None
+        assert decode.__dict__['FCOSDecoder'](nms_type=t).soft is not None
+    with pytest.raises(AssertionError):  # the reference's message: 'wrong nms type!'
+        decode.__dict__['RetinaDecoder'](nms_type='cluster_nms')
 
 
 def test_bench_generator_matches_fixture_generator():

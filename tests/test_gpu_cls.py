@@ -187,3 +187,48 @@ def test_classification_trainer_small_lr_vs_oracle():
     assert abs(l0 - float(loss_r)) <= 1e-4 * float(loss_r)
     assert abs(l1 - l1_r) <= 1e-3 * l1_r
     assert abs((l0 - l1) - (float(loss_r) - l1_r)) <= 5e-2 * abs(float(loss_r) - l1_r)
+
+
+def test_resume_from_a_torch_sgd_checkpoint_keeps_the_momentum():
+    """a torch.optim.SGD state_dict has no per-parameter 'step'; the first optimizer step after
+    load_state_dict must continue from the loaded momentum buffers (not overwrite them with the gradient), i.e. equal
+    torch.optim.SGD's own next step from the same state -- and a fresh trainer's first step still equals torch's."""
+    from sacv_amd.classification import losses
+    from sacv_amd.train import ClassificationTrainer
+    nc, B, R = 40, 4, 64
+    net = build(nc)
+    tr = ClassificationTrainer(net, losses.__dict__['CELoss'](), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+    cpu_params = [[net.arena.module_params[n].detach().cpu().clone().contiguous().requires_grad_(True)
+                   for n in g['param_names']] for g in tr.param_groups]
+    opt = torch.optim.SGD([{'params': cpu_params[0], 'weight_decay': 0.0},
+                           {'params': cpu_params[1], 'weight_decay': 1e-4}], lr=1e-2, momentum=0.9)
+    # a torch SGD checkpoint with NONZERO momentum buffers: one torch step on synthetic gradients
+    for gi_, plist in enumerate(cpu_params):
+        for j, p in enumerate(plist):
+            p.grad = torch.tensor(synth.normal(1000 * gi_ + j, tuple(p.shape))).reshape(p.shape) * 1e-2
+    opt.step()
+    sd = opt.state_dict()
+    assert all('step' not in st for st in sd['state'].values())
+    assert float(sd['state'][0]['momentum_buffer'].abs().max()) > 0
+    with torch.no_grad():  # the model continues from the parameters torch produced
+        for plist, g in zip(cpu_params, tr.param_groups):
+            for p, n in zip(plist, g['param_names']):
+                net.arena.module_params[n].copy_(p.detach())
+    tr.load_state_dict(sd)
+    x = torch.tensor(synth.images(11, B, R, R)).cuda()
+    lab = torch.tensor(gi.labels_for(23, B, nc)).cuda()
+    tr.step(x, lab)
+    for plist, g in zip(cpu_params, tr.param_groups):
+        for p, n in zip(plist, g['param_names']):
+            p.grad = net.arena.grad_views[n].detach().cpu().clone().contiguous()
+    opt.step()
+    worst_p = worst_b = 0.0
+    sd2, mine = opt.state_dict(), tr.state_dict()
+    idx = 0
+    for plist, g in zip(cpu_params, tr.param_groups):
+        for p, n in zip(plist, g['param_names']):
+            worst_p = max(worst_p, float((p.detach() - net.arena.module_params[n].detach().cpu()).abs().max()))
+            worst_b = max(worst_b, float((sd2['state'][idx]['momentum_buffer'] -
+                                          mine['state'][idx]['momentum_buffer'].cpu()).abs().max()))
+            idx += 1
+    assert worst_p <= 1.5e-7 and worst_b <= 1e-6, (worst_p, worst_b)

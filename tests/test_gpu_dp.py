@@ -163,6 +163,70 @@ def test_rccl_communicator_of_the_c_abi_world1():
     comm.close()
 
 
+def _one_comm_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import model as omodel, synth
+        from sacv_amd.detection import models, losses
+        from sacv_amd.train import DetectionTrainer
+        real_all_reduce, real_broadcast = dist.all_reduce, dist.broadcast
+
+        class HostComm:
+            """RcclComm's surface over gloo (in order, synchronous): stands in for the C ABI's communicator."""
+            world, rank = dist.get_world_size(), dist.get_rank()
+            calls = 0
+
+            def all_reduce(self, t):
+                HostComm.calls += 1
+                real_all_reduce(t)
+
+            def wait(self):
+                pass
+
+            def broadcast(self, t, root=0):
+                real_broadcast(t, src=root)
+
+        def forbidden(*a, **k):
+            raise AssertionError('a collective on torch.distributed while the trainer owns a communicator')
+
+        H, W = 96, 128
+        net = models.__dict__['resnet50_retinanet'](num_classes=80)
+        net.load_state_dict(omodel.init_retinanet_state(rank))
+        net = net.cuda().train()
+        dist.all_reduce = dist.broadcast = forbidden
+        try:
+            tr = DetectionTrainer(net, losses.__dict__['RetinaLoss'](), process_group=dist.group.WORLD,
+                                  transport=HostComm())
+            outs = []
+            for it in range(2):
+                out = tr.step(torch.tensor(synth.images(100 + rank + 10 * it, 2, H, W)).cuda(),
+                              torch.tensor(synth.annotations(200 + rank + 10 * it, 2, H, W, boxes_per_image=8)).cuda())
+                outs.append(tr.finish_step(out))
+        finally:
+            dist.all_reduce, dist.broadcast = real_all_reduce, real_broadcast
+        assert HostComm.calls == 2 * (1 + 4 + 1)  # per step: skip vote, four gradient stages, loss scalars
+        p = net.arena.params.clone()
+        ref = p.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(p, ref), 'parameters diverged between ranks'
+        ret[rank] = (outs[1]['loss'], outs[1]['optimizer_steps'], float(p.double().sum()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_every_collective_of_a_step_goes_through_the_one_communicator():
+    """with transport 'rccl' the skip vote and the loss scalars used to travel on torch's communicator
+    while the gradient stages were in flight on the C ABI's.  Now every collective of a step goes through the
+    trainer's communicator; rehearsed with two ranks on this GPU and a gloo stand-in with RcclComm's surface."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_one_comm_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert set(ret.keys()) == {0, 1} and ret[0] == ret[1] and ret[0][1] == 2
+
+
 def _nccl_worker(rank, world, port, ret, transport):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)

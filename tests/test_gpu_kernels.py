@@ -425,6 +425,70 @@ def test_retina_decoder(ops, tag, nms_type, golden_dir):
         assert np.array_equal(c, G[key + '_classes'])
 
 
+@pytest.mark.parametrize('tag', ['TINY', 'MID', 'S1'])
+@pytest.mark.parametrize('nms_type', ['soft_nms', 'soft_nms_gaussian'])
+def test_retina_decoder_soft_nms(ops, tag, nms_type):
+    """Batched Soft-NMS (the north-star's postprocess mode; the reference has none -> PARITY UNPINNED, the checker is
+    oracle/decode.py::soft_nms restating Bodla et al. 2017).  Linear decay is pure fp32 mul / sub / div with
+    -ffp-contract=off: scores, classes and boxes are compared bit-exact.  Gaussian decay goes through expf, whose
+    last bit may differ from NumPy's and a deep pick carries the product of hundreds of such factors (measured: 2.5e-6
+    relative at pick ~500): scores to 1e-5, and the order is compared where the oracle's neighbouring scores are at
+    least 2e-5 apart (closer picks could legitimately swap)."""
+    from sacv_amd.detection import decode
+    H, W = gi.SHAPES[tag]
+    cls, reg = gi.synth_preds_decode(21, 2, H, W)
+    # at MID / S1 the first 100 picks never overlap (they equal hard NMS's): ask for all 1000 so that decayed boxes are
+    # picked, re-decayed and pruned
+    M = 100 if tag == 'TINY' else 1000
+    dec = decode.__dict__['RetinaDecoder'](nms_type=nms_type, nms_threshold=0.5, max_object_num=M)
+    s, c, b = dec([[torch.tensor(x).cuda() for x in cls], [torch.tensor(x).cuda() for x in reg]])
+    rs, rc, rb = odecode.retina_decode(cls, reg, nms_type=nms_type, nms_threshold=0.5, max_object_num=M)
+    assert s.shape == (2, M) and b.shape == (2, M, 4) and s.dtype == np.float32
+    assert (rs > 0).sum() >= 20  # the case is not vacuous
+    if nms_type == 'soft_nms':
+        assert np.array_equal(s, rs) and np.array_equal(c, rc) and np.array_equal(b, rb)
+        hard = odecode.retina_decode(cls, reg, nms_type='python_nms', nms_threshold=0.5, max_object_num=M)
+        assert not np.array_equal(hard[0], rs)  # and it is not hard NMS under another name
+    else:
+        np.testing.assert_allclose(s, rs, rtol=1e-5, atol=0)
+        for i in range(2):
+            n = int((rs[i] > 0).sum())
+            gap = np.abs(np.diff(rs[i, :n], append=rs[i, n - 1] - 1.0))
+            gap = np.minimum(gap, np.concatenate([[1.0], gap[:-1]]))
+            firm = gap > 2e-5
+            assert np.array_equal(b[i, :n][firm], rb[i, :n][firm]) and np.array_equal(c[i, :n][firm], rc[i, :n][firm])
+            assert np.all(s[i, n:] == -1) and np.all(b[i, n:] == 0)
+    assert np.all(np.diff(np.where(s > 0, s, 0), axis=1) <= 0)  # picks come out in descending decayed score
+
+
+def test_fcos_decoder_soft_nms_and_edge_cases(ops):
+    """FCOS front end + Soft-NMS; an image without any score above the threshold; max_object_num larger than the
+    number of survivors; a prune level that removes everything a decay touches (== hard suppression at >= thr)."""
+    from sacv_amd.detection import decode
+    H, W = gi.SHAPES['MID']
+    cls, reg, ctr = gi.synth_preds_decode(23, 2, H, W, fcos=True)
+    f = lambda lst: [torch.tensor(x).cuda() for x in lst]
+    dec = decode.__dict__['FCOSDecoder'](nms_type='soft_nms', nms_threshold=0.6)
+    s, c, b = dec([f(cls), f(reg), f(ctr)])
+    rs, rc, rb = odecode.fcos_decode(cls, reg, ctr, nms_type='soft_nms', nms_threshold=0.6)
+    assert np.array_equal(s, rs) and np.array_equal(c, rc) and np.array_equal(b, rb)
+    # image 1 has nothing above the score threshold
+    cls0 = [x.copy() for x in cls]
+    for x in cls0:
+        x[1] = 1e-4  # FCOS score = sqrt(cls * centerness) <= 0.01 < 0.05
+    s, c, b = dec([f(cls0), f(reg), f(ctr)])
+    rs, rc, rb = odecode.fcos_decode(cls0, reg, ctr, nms_type='soft_nms', nms_threshold=0.6)
+    assert np.array_equal(s, rs) and np.all(s[1] == -1) and np.all(c[1] == -1) and np.all(b[1] == 0)
+    # few survivors, many slots; prune level 0.5 drops every decayed box whose score falls to <= 0.5
+    dec = decode.__dict__['FCOSDecoder'](nms_type='soft_nms', nms_threshold=0.6, max_object_num=300,
+                                          min_score_threshold=0.3, soft_nms_prune_score=0.5)
+    s, c, b = dec([f(cls), f(reg), f(ctr)])
+    rs, rc, rb = odecode.fcos_decode(cls, reg, ctr, nms_type='soft_nms', nms_threshold=0.6, max_object_num=300,
+                                     min_score_threshold=0.3, soft_nms_prune_score=0.5)
+    assert s.shape == (2, 300) and np.array_equal(s, rs) and np.array_equal(c, rc) and np.array_equal(b, rb)
+    assert np.all(s[s > 0] > 0.5)
+
+
 # ----------------------------------------------------------------------------------------- data boundary
 def test_device_collater_and_eval_postprocess(ops):
     """device-side Normalize + DetectionCollater and the evaluation box post-steps, bit-exact

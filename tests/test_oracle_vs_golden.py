@@ -184,3 +184,59 @@ def test_torchvision_nms_restatement_agrees_with_python_nms_on_regular_boxes():
     assert np.array_equal(odecode.torchvision_nms(boxes, 0.5), odecode.greedy_nms(boxes, 0.5))
     deg = np.array([[10, 10, 10, 10], [10, 10, 10, 10], [0, 0, 30, 30]], dtype=np.float32)
     assert odecode.torchvision_nms(deg, 0.5).tolist() == [0, 1, 2]
+
+
+def test_soft_nms_restatement_known_answers_and_limits():
+    """Soft-NMS (Bodla et al. 2017; the north-star's extra nms mode, PARITY UNPINNED: the reference has none).  The
+    restatement is pinned by what the paper's algorithm implies: a hand-computed case, the hard-NMS limit (prune at the
+    score a linear decay by 1 - IoU leaves: picks of linear soft-NMS that never decayed == python_nms's keeps when
+    overlapping boxes are pruned outright), non-increasing pick scores, and no decay below the threshold."""
+    F32 = np.float32
+    boxes = np.array([[0, 0, 10, 10], [0, 0, 10, 5], [20, 20, 30, 30], [0, 0, 10, 10]], dtype=F32)
+    scores = np.array([0.9, 0.8, 0.7, 0.6], dtype=F32)
+    # IoU(0,1) = 50/100 = 0.5; IoU(0,3) = 1; box 2 is disjoint
+    picks, dec = odecode.soft_nms(scores, boxes, nms_threshold=0.3, method='linear', prune_score=0.001)
+    # pick 0 (0.9): s1 = 0.8*(1-0.5) = 0.4, s3 = 0.6*0 = 0 -> pruned; then 2 (0.7, no overlap), then 1 (0.4)
+    assert picks.tolist() == [0, 2, 1]
+    assert dec.tolist() == [F32(0.9), F32(0.7), F32(0.8) * (F32(1) - F32(0.5))]
+    picks, dec = odecode.soft_nms(scores, boxes, nms_threshold=0.3, method='gaussian', sigma=0.5, prune_score=0.001)
+    assert picks.tolist() == [0, 2, 1, 3]
+    np.testing.assert_allclose(dec, [0.9, 0.7, 0.8 * np.exp(-0.25 / 0.5), 0.6 * np.exp(-1.0 / 0.5) * np.exp(-0.25 / 0.5)],
+                               rtol=1e-6)
+    # below the threshold linear soft-NMS changes nothing
+    picks, dec = odecode.soft_nms(scores[:3], boxes[:3], nms_threshold=0.6, method='linear')
+    assert picks.tolist() == [0, 1, 2] and dec.tolist() == scores[:3].tolist()
+    # random boxes: pick scores never increase, every pick is unique, and with a prune level above every decayed
+    # score (decay kills) the picks are exactly hard NMS's keeps at the same threshold with >= semantics
+    rng = np.random.RandomState(3)
+    xy = rng.rand(300, 2).astype(F32) * 200
+    wh = (rng.rand(300, 2).astype(F32) * 60 + 5)
+    b = np.concatenate([xy, xy + wh], axis=1).astype(np.int32).astype(F32)
+    s = np.sort(rng.rand(300).astype(F32) * F32(0.9) + F32(0.05))[::-1].copy()
+    for method in ('linear', 'gaussian'):
+        picks, dec = odecode.soft_nms(s, b, nms_threshold=0.5, method=method)
+        assert len(set(picks.tolist())) == len(picks) and np.all(np.diff(dec) <= 0)
+        assert np.all(dec <= s[picks]) and np.all(dec > F32(0.001))
+    picks, dec = odecode.soft_nms(s, b, nms_threshold=0.5, method='linear', prune_score=10.0)
+    assert picks.size == 0  # nothing is live above a prune level of 10
+    keep = odecode.greedy_nms(b, 0.5)
+    picks, dec = odecode.soft_nms(s, b, nms_threshold=0.5, method='linear')
+    assert picks[0] == keep[0] == 0 and dec[0] == s[0]
+    # a box that overlaps NO other box by >= 0.5 is never decayed by the linear rule, and hard NMS keeps it too
+    wh_ = b[:, 2:4] - b[:, 0:2]
+    area = wh_[:, 0] * wh_[:, 1]
+    tl = np.maximum(b[:, None, 0:2], b[None, :, 0:2])
+    br = np.minimum(b[:, None, 2:4], b[None, :, 2:4])
+    d_ = np.maximum(br - tl, 0)
+    inter = d_[..., 0] * d_[..., 1]
+    iou = inter / np.maximum(area[:, None] + area[None, :] - inter, F32(1e-4))
+    np.fill_diagonal(iou, 0)
+    lonely = np.where(iou.max(axis=1) < 0.5)[0]
+    assert lonely.size > 10
+    score_of = dict(zip(picks.tolist(), dec.tolist()))
+    assert all(score_of[int(i)] == s[i] for i in lonely) and set(lonely.tolist()) <= set(keep.tolist())
+    # select_detections wraps it like the other modes (filter / sort / top-n / pad)
+    sc = np.stack([s, s[::-1]])
+    out = odecode.select_detections(sc, np.zeros((2, 300), dtype=np.int64), np.stack([b, b]).astype(np.int32),
+                                    nms_type='soft_nms', max_object_num=20)
+    assert out[0].shape == (2, 20) and np.all(np.diff(out[0], axis=1) <= 0) and out[2].shape == (2, 20, 4)

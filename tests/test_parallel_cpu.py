@@ -57,6 +57,47 @@ def _worker(rank, world, port, ret):
         assert float(m.backbone.conv1.layer[1].running_mean[0]) == 1.0  # module buffers are arena views
         v = vote_and_reduce_scalars(torch.tensor([1.0 + rank, 0.5]))
         assert v.tolist() == [sum(1.0 + r for r in range(world)), 0.5 * world]
+
+        # transport 'rccl' (ADVICE r2): with a communicator of the C ABI EVERY collective of a step -- stages, skip vote,
+        # loss scalars, buffer broadcast -- must go through it, none through torch's group.  A recording stand-in with
+        # RcclComm's surface (all_reduce / wait / broadcast, in-order) over gloo proves the routing on CPU.
+        class Recorder:
+            def __init__(self):
+                self.world, self.rank, self.log, self.outstanding = world, rank, [], 0
+
+            def all_reduce(self, t):
+                self.log.append(('all_reduce', t.numel()))
+                self.outstanding += 1
+                dist.all_reduce(t)
+
+            def wait(self):
+                self.log.append(('wait', self.outstanding))
+                self.outstanding = 0
+
+            def broadcast(self, t, root=0):
+                self.log.append(('broadcast', t.numel()))
+                dist.broadcast(t, src=root)
+
+        comm = Recorder()
+        real_all_reduce, real_broadcast = dist.all_reduce, dist.broadcast
+        g.copy_(torch.arange(g.numel(), dtype=torch.float32) % 89 + rank)
+        ex = GradExchanger(g, ranges, comm=comm)
+        flag = torch.tensor([float(rank)])
+        comm.all_reduce(flag)  # the trainer's _vote_begin, ahead of the stages on the same communicator
+        for stage in ('heads', 'neck', 'mid', 'rest'):
+            ex.stage_done(stage)
+        comm.wait()            # _after_backward: vote + every stage
+        ex.wait()
+        assert torch.equal(g, (torch.arange(g.numel(), dtype=torch.float32) % 89) * world + sum(range(world)))
+        assert flag.item() == sum(range(world))
+        v = vote_and_reduce_scalars(torch.tensor([2.0 + rank, 0.25]), comm=comm)
+        assert v.tolist() == [sum(2.0 + r for r in range(world)), 0.25 * world]
+        arena.buffers.fill_(float(rank + 7))
+        broadcast_buffers(arena.buffers, comm=comm)
+        assert float(arena.buffers.min()) == 7.0 and float(arena.buffers.max()) == 7.0
+        kinds = [k for k, _ in comm.log]
+        assert kinds == ['all_reduce'] * 5 + ['wait', 'wait', 'all_reduce', 'wait', 'broadcast'], kinds
+        assert comm.log[5] == ('wait', 5) and comm.log[6] == ('wait', 0)
         ret[rank] = 'ok'
     finally:
         dist.destroy_process_group()

@@ -241,6 +241,10 @@ int sacv_decode_topk_soft_nms(int kind, int nlev, const float* const* cls, const
  * zero-padded fp32 batch [B][R][R][3] = channels_last storage of the model input, value / 255 */
 int sacv_collate_u8(int B, const unsigned char* const* imgs /*host array*/, const int* h, const int* w, int R,
                     float* out, void* stream);
+/* the same on a rectangular canvas [B][Hc][Wc][3] (Hc x Wc >= every image): the opt-in padding-skip form of
+ * DetectionCollater (detection/common.py:251-268 pads every batch to R x R) */
+int sacv_collate_u8_rect(int B, const unsigned char* const* imgs /*host array*/, const int* h, const int* w, int Hc,
+                         int Wc, float* out, void* stream);
 /* evaluate_coco_detection post-steps (tools/scripts.py:742-758), in place on boxes [B][M][4]:
  * / scale, clip to the original image size, xyxy -> xywh */
 int sacv_eval_postprocess(float* boxes, const float* scales, const float* sizes, int B, int M, void* stream);

@@ -297,15 +297,17 @@ def sec_decode(ref):
     print('decode ok', meta)
 
 
-def _e2e(ref, name, H, W, fcos, box_loss_type='SmoothL1', ann_seed=3):
+def _e2e(ref, name, H, W, fcos, box_loss_type='SmoothL1', ann_seed=3, num_classes=80):
     models, losses, decode = ref
     torch.manual_seed(0)
-    net = models.__dict__['resnet50_fcos' if fcos else 'resnet50_retinanet'](num_classes=80)
-    net.load_state_dict(omodel.init_retinanet_state(0, fcos=fcos), strict=True)
+    net = models.__dict__['resnet50_fcos' if fcos else 'resnet50_retinanet'](num_classes=num_classes)
+    net.load_state_dict(omodel.init_retinanet_state(0, num_classes=num_classes, fcos=fcos), strict=True)
     net.train()
     crit = losses.__dict__['FCOSLoss']() if fcos else losses.__dict__['RetinaLoss'](box_loss_type=box_loss_type)
     x = torch.tensor(synth.images(5, 2, H, W))
     ann = torch.tensor(synth.annotations(ann_seed, 2, H, W, boxes_per_image=8))
+    if num_classes != 80:
+        ann[..., 4] = torch.where(ann[..., 4] >= 0, ann[..., 4] % num_classes, ann[..., 4])
     outs = net(x)
     ld = crit(outs, ann)
     total = sum(ld.values())
@@ -437,6 +439,24 @@ def sec_e2e_s2(ref):
         print(name, m['loss'])
     np.savez_compressed(os.path.join(GOLD, 'e2e_s2.npz'), **out)
     json.dump(meta, open(os.path.join(GOLD, 'e2e_s2.json'), 'w'), indent=0)
+
+
+def sec_e2e_other(ref):
+    """The square yolo-style inputs of the other detection recipes: VOC 640 x 640 with 20 classes
+    (3.detection_training/voc/res50_{retinanet,fcos}_yoloresize640/train_config.py:23-24) and the Objects365 canvas
+    1024 x 1024 (objects365/res50_retinanet_yoloresize1024/train_config.py:24; with COCO's 80 classes here -- the
+    365-class heads need num_classes % 4 == 0 on the MI355X path)."""
+    out, meta = {}, {}
+    for name, (H, W), fcos, nc in (('retina_V640', (640, 640), False, 20), ('fcos_V640', (640, 640), True, 20),
+                                   ('retina_O1024', (1024, 1024), False, 80)):
+        m, a = _e2e(ref, name, H, W, fcos, num_classes=nc)
+        assert m['feature_sizes'] == synth.feature_sizes(H, W)
+        m['H'], m['W'], m['num_classes'] = H, W, nc
+        meta[name] = m
+        out.update(a)
+        print(name, m['loss'])
+    np.savez_compressed(os.path.join(GOLD, 'e2e_other.npz'), **out)
+    json.dump(meta, open(os.path.join(GOLD, 'e2e_other.json'), 'w'), indent=0)
 
 
 class _Cfg:
@@ -851,7 +871,7 @@ def sec_mae(ref):
 
 SECTIONS = dict(cls=sec_cls, contract=sec_contract, anchors=sec_anchors, assign=sec_assign, losses=sec_losses,
                 decode=sec_decode, e2e=sec_e2e, e2e_s1=sec_e2e_s1, e2e_s2=sec_e2e_s2, scheduler=sec_scheduler,
-                trainer=sec_trainer, collate=sec_collate, evalpost=sec_evalpost, cifar=sec_cifar, cls_bf16=sec_cls_bf16, mae=sec_mae)
+                trainer=sec_trainer, collate=sec_collate, e2e_other=sec_e2e_other, evalpost=sec_evalpost, cifar=sec_cifar, cls_bf16=sec_cls_bf16, mae=sec_mae)
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)

@@ -68,6 +68,7 @@ SIGNATURES = {
     'sacv_decode_topk_nms': (I, [I, I, P, P, P, P, P, I, I, I, F, I, I, F, I, P, P, P, P, P]),
     'sacv_decode_topk_soft_nms': (I, [I, I, P, P, P, P, P, I, I, I, F, I, I, F, F, F, I, P, P, P, P, P]),
     'sacv_collate_u8': (I, [I, P, P, P, I, P, P]),
+    'sacv_collate_u8_rect': (I, [I, P, P, P, I, I, P, P]),
     'sacv_eval_postprocess': (I, [P, P, P, I, I, P]),
     'sacv_avgpool_fwd': (I, [P, P, I, I, I, P]),
     'sacv_avgpool_bwd': (I, [P, P, I, I, I, P]),

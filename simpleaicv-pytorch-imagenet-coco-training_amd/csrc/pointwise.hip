@@ -426,15 +426,16 @@ int sacv_colsum_finalize_multi(int n, const float* const* partial, const int* nb
 struct CollateArgs {
   const unsigned char* img[16];
   int h[16], w[16];
-  int B, R;
+  int B, R;   // canvas R rows ...
+  int RW;     // ... x RW columns (RW == R: the reference's square canvas)
 };
 __global__ __launch_bounds__(256) void collate_u8_kernel(const CollateArgs a, float* __restrict__ out) {
-  const size_t per = (size_t)a.R * a.R;
+  const size_t per = (size_t)a.R * a.RW;
   const size_t total = per * a.B;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     int b = (int)(i / per);
     size_t r = i - (size_t)b * per;
-    int y = (int)(r / a.R), x = (int)(r - (size_t)y * a.R);
+    int y = (int)(r / a.RW), x = (int)(r - (size_t)y * a.RW);
     float v0 = 0.f, v1 = 0.f, v2 = 0.f;
     if (y < a.h[b] && x < a.w[b]) {
       const unsigned char* p = a.img[b] + ((size_t)y * a.w[b] + x) * 3;
@@ -480,6 +481,7 @@ int sacv_collate_u8(int B, const unsigned char* const* imgs, const int* h, const
   CollateArgs a;
   a.B = B;
   a.R = R;
+  a.RW = R;
   for (int i = 0; i < B; ++i) {
     SACV_CHECK_ARG(imgs[i] && h[i] > 0 && w[i] > 0 && h[i] <= R && w[i] <= R, "collate_u8: image %d does not fit", i);
     a.img[i] = imgs[i];
@@ -489,6 +491,29 @@ int sacv_collate_u8(int B, const unsigned char* const* imgs, const int* h, const
   size_t total = (size_t)B * R * R;
   hipLaunchKernelGGL(collate_u8_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, out);
   SACV_CHECK_LAUNCH("collate_u8");
+  return SACV_OK;
+}
+
+// as sacv_collate_u8 on a rectangular canvas out [B][Hc][Wc][3]: the padding-skip form of the collater -- the caller
+// picks Hc x Wc >= the largest image of the batch (rounded up to the network's stride) instead of the reference's
+// R x R square, so the zero padding of DetectionCollater (detection/common.py:251-268) is never convolved
+int sacv_collate_u8_rect(int B, const unsigned char* const* imgs, const int* h, const int* w, int Hc, int Wc,
+                         float* out, void* stream) {
+  SACV_CHECK_ARG(B >= 1 && B <= 16 && imgs && h && w && out && Hc > 0 && Wc > 0, "collate_u8_rect: bad args (B <= 16)");
+  CollateArgs a;
+  a.B = B;
+  a.R = Hc;
+  a.RW = Wc;
+  for (int i = 0; i < B; ++i) {
+    SACV_CHECK_ARG(imgs[i] && h[i] > 0 && w[i] > 0 && h[i] <= Hc && w[i] <= Wc,
+                   "collate_u8_rect: image %d does not fit", i);
+    a.img[i] = imgs[i];
+    a.h[i] = h[i];
+    a.w[i] = w[i];
+  }
+  size_t total = (size_t)B * Hc * Wc;
+  hipLaunchKernelGGL(collate_u8_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, out);
+  SACV_CHECK_LAUNCH("collate_u8_rect");
   return SACV_OK;
 }
 

@@ -822,13 +822,21 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, split, lr, beta1, beta2, eps,
 
 
 # ------------------------------------------------------------------------------------------ data boundary
-def collate_u8(images_u8, resize):
-    """images_u8: list of uint8 CUDA tensors [h,w,3] -> logical [B,3,R,R] fp32 tensor in channels_last storage."""
+def collate_u8(images_u8, resize, canvas=None):
+    """images_u8: list of uint8 CUDA tensors [h,w,3] -> logical [B,3,R,R] fp32 tensor in channels_last storage;
+    canvas = (Hc, Wc): the rectangular padding-skip canvas [B,3,Hc,Wc] instead."""
     b = len(images_u8)
     dev = images_u8[0].device
     for t in images_u8:
         if t.dtype != torch.uint8 or t.device.type != 'cuda' or not t.is_contiguous() or t.shape[-1] != 3:
             raise ValueError('collate_u8: expected contiguous uint8 CUDA tensors [h,w,3]')
+    if canvas is not None:
+        hc, wc = canvas
+        out = torch.empty((b, hc, wc, 3), device=dev, dtype=torch.float32)
+        check(lib.sacv_collate_u8_rect(b, parr([t.data_ptr() for t in images_u8]),
+                                       iarr([t.shape[0] for t in images_u8]), iarr([t.shape[1] for t in images_u8]),
+                                       hc, wc, _ptr(out), _stream()), 'collate_u8_rect')
+        return out.permute(0, 3, 1, 2)
     out = torch.empty((b, resize, resize, 3), device=dev, dtype=torch.float32)
     check(lib.sacv_collate_u8(b, parr([t.data_ptr() for t in images_u8]), iarr([t.shape[0] for t in images_u8]),
                               iarr([t.shape[1] for t in images_u8]), resize, _ptr(out), _stream()), 'collate_u8')

@@ -16,24 +16,31 @@ from tests import golden_inputs as gi
 from tests.test_scheduler_cpu import collate_samples
 
 
-@pytest.mark.parametrize('kind,tag', [('retina', 'S1'), ('fcos', 'S1'), ('retina', 'S2'), ('fcos', 'S2')])
+@pytest.mark.parametrize('kind,tag', [('retina', 'S1'), ('fcos', 'S1'), ('retina', 'S2'), ('fcos', 'S2'),
+                                      ('retina', 'V640'), ('fcos', 'V640'), ('retina', 'O1024')])
 def test_full_size_step_against_reference_fixture(golden_dir, kind, tag):
     """loss dict 1e-4 (north-star tolerance), 256 samples of every output level 2e-4, all gradient norms, and the
-    full gradients of 8-9 small tensors elementwise (relative L2 and max-abs vs the tensor's scale)."""
+    full gradients of 8-9 small tensors elementwise (relative L2 and max-abs vs the tensor's scale).  V640 / O1024 are
+    the square yolo-style canvases of the VOC (20 classes) and Objects365 recipes (make_golden.py
+    section e2e_other)."""
     from sacv_amd.detection import models, losses
-    f = 'e2e_s1' if tag == 'S1' else 'e2e_s2'
+    f = {'S1': 'e2e_s1', 'S2': 'e2e_s2'}.get(tag, 'e2e_other')
     name = f'{kind}_{tag}'
     meta = json.load(open(os.path.join(golden_dir, f + '.json')))[name]
     arrs = np.load(os.path.join(golden_dir, f + '.npz'))
-    H, W = gi.SHAPES[tag]
+    H, W = gi.SHAPES[tag] if tag in gi.SHAPES else (meta['H'], meta['W'])
+    nc = meta.get('num_classes', 80)
     fcos = kind == 'fcos'
-    net = models.__dict__['resnet50_fcos' if fcos else 'resnet50_retinanet'](num_classes=80)
-    net.load_state_dict(omodel.init_retinanet_state(0, fcos=fcos))
+    net = models.__dict__['resnet50_fcos' if fcos else 'resnet50_retinanet'](num_classes=nc)
+    net.load_state_dict(omodel.init_retinanet_state(0, num_classes=nc, fcos=fcos))
     net = net.cuda().train()
     crit = losses.__dict__['FCOSLoss' if fcos else 'RetinaLoss']()
     outs = net(torch.tensor(synth.images(5, 2, H, W)).cuda())
     assert [[o.shape[2], o.shape[1]] for o in outs[0]] == meta['feature_sizes']
-    ld = crit(outs, torch.tensor(synth.annotations(3, 2, H, W, boxes_per_image=8)).cuda())
+    ann = synth.annotations(3, 2, H, W, boxes_per_image=8)
+    if nc != 80:
+        ann[..., 4] = np.where(ann[..., 4] >= 0, ann[..., 4] % nc, ann[..., 4])
+    ld = crit(outs, torch.tensor(ann).cuda())
     assert set(ld) == set(meta['loss'])
     for k, v in meta['loss'].items():
         assert abs(float(ld[k]) - v) <= 1e-4 * max(1.0, abs(v)), (k, float(ld[k]), v)

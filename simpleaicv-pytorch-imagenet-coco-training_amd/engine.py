@@ -61,9 +61,42 @@ class DetectorEngine:
         # one launch.  False selects the direct implicit-GEMM kernel for every conv (A/B measurements, tests).
         self.winograd = True
         self._wino_cache = {}
+        import os
+        self._side, self._side_busy = None, False  # the weight gradients' stream (see _on_side)
+        if os.environ.get('SACV_WGRAD_STREAM', '1') != '0' and p and next(iter(p.values())).is_cuda:
+            self._side = torch.cuda.Stream()
 
     def _wgrad(self, dys, xs, dw, cin, kh, kw, stride, pad, **kw_args):
-        ops.conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, **kw_args)
+        self._on_side(lambda: ops.conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, **kw_args), list(dys) + list(xs))
+
+    # -- weight gradients on a side HIP stream ----------------------------------------------------------------------
+    # A layer's weight gradient depends only on its dy and the saved input and nothing in the backward pass reads it
+    # before the stage's exchange / the optimizer.  Enqueued on a second stream (behind an event of the launch
+    # stream), its start-up, tail and fixed-order slab reduction run under the data-gradient chain's kernels and the
+    # HBM-bound BatchNorm backward kernels run under its MFMA phase, instead of each kernel draining the chip before
+    # the next one starts (measured, same box and session: RetinaNet step 29.42 -> 28.53 ms, bf16 classifier
+    # 28.21 -> 27.35 ms with the BatchNorm layers' weight gradients alone).  All weight-gradient launches use the
+    # side stream in program order, so their workspaces ('wgrad', 'wino_wgrad') never meet the launch stream's.
+    # Contract for callers: `dys` / `xs` are not written by the launch stream after this call (every in-place
+    # accumulation into a gradient tensor precedes its use as a dy; checked call site by call site).
+    def _on_side(self, launch, tensors):
+        s = self._side
+        if s is None:
+            return launch()
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        s.wait_event(ev)
+        with torch.cuda.stream(s):
+            launch()
+        for t in tensors:
+            t.record_stream(s)  # the caching allocator must not recycle these blocks under the side stream's reads
+        self._side_busy = True
+
+    def _side_join(self):
+        if self._side is not None and self._side_busy:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_busy = False
 
     def set_amp(self, enabled, arena=None):
         """Switch the bf16 matrix-core path on/off (the reference's config.use_amp / autocast)."""
@@ -500,7 +533,7 @@ class DetectorEngine:
     def _wino_wgrad(self, dys, xs, v, dw, cin):
         """3x3 weight gradient: Winograd path from the kept V when the channel count allows it, else conv_tn."""
         if v is not None and ops.wino_wgrad_supported(cin) and dys[0].shape[3] >= 64:
-            ops.wino_wgrad(dys, v, dw, cin)
+            self._on_side(lambda: ops.wino_wgrad(dys, v, dw, cin), list(dys) + [v])
         else:
             self._wgrad(dys, xs, dw, cin, 3, 3, 1, 1)
 
@@ -657,9 +690,12 @@ class DetectorEngine:
                                   gscale=grad_scale)
                for l, (dr, dc, r, c) in enumerate(zip(dreg_levels, dctr_levels, o['reg'], o['ctr']))]
         dw8 = torch.empty_like(o['w8'])
-        ops.conv_wgrad(dy8, o['reg_x'], dw8, self.planes, 3, 3, 1, 1)
-        g['clsregcnt_head.reg_out.weight'].copy_(dw8[0:4])
-        g['clsregcnt_head.center_out.weight'].copy_(dw8[4:5])
+
+        def wgrad8():  # on the weight gradients' stream, like every user of the 'wgrad' workspace (see _on_side)
+            ops.conv_wgrad(dy8, o['reg_x'], dw8, self.planes, 3, 3, 1, 1)
+            g['clsregcnt_head.reg_out.weight'].copy_(dw8[0:4])
+            g['clsregcnt_head.center_out.weight'].copy_(dw8[4:5])
+        self._on_side(wgrad8, list(dy8) + list(o['reg_x']) + [dw8])
         db8 = torch.empty(8, device=dw8.device, dtype=torch.float32)
         for l, d in enumerate(dy8):
             ops.colsum(d, 8, db8, accumulate=l > 0)
@@ -788,9 +824,11 @@ class DetectorEngine:
     def _trunk_bwd(self, dfeat, on_stage):
         ctx = self.ctx
         if on_stage:
+            self._side_join()
             on_stage('heads')  # head gradients are final: their all-reduce can start now
         dc3, dc4, dc5 = self._fpn_bwd(dfeat)
         self._backbone_bwd(dc5, dc4, dc3, on_stage)
+        self._side_join()
         if on_stage:
             on_stage('rest')
         self.ctx = None
@@ -808,6 +846,7 @@ class DetectorEngine:
                 accum_target = dc3
             dout = bwd(saved, dout, accum_target)
             if on_stage and bi == 0 and li in (3, 4):
+                    self._side_join()
                     on_stage('neck' if li == 4 else 'mid')  # fpn + layer4 / layer3 gradients are final
         # max pool + stem
         if self.stem == 'imagenet':
@@ -934,7 +973,7 @@ class ClassifierEngine(DetectorEngine):
         if self.amp:
             dy = ops.cast_bf16(dy)
         dy = dy.view(dy.shape[0], 1, 1, npad)
-        self._wgrad([dy], [ctx['pooled']], dwp, nin, 1, 1, 1, 0)
+        ops.conv_wgrad([dy], [ctx['pooled']], dwp, nin, 1, 1, 1, 0)  # launch stream: dwp is copied right below
         if npad != nout:
             self.g['fc.weight'].copy_(dwp.view(npad, nin)[:nout])
             self.g['fc.bias'].copy_(dbp[:nout])
@@ -948,6 +987,7 @@ class ClassifierEngine(DetectorEngine):
         if on_stage:
             on_stage('heads')
         self._backbone_bwd(dc5, None, None, on_stage)
+        self._side_join()
         if on_stage:
             on_stage('rest')
         self.ctx = None

@@ -79,7 +79,8 @@ def test_bottleneck_fwd_bwd(cin, planes, stride, h, w):
     assert rel_l2(nchw(out), out_r.detach()) <= 1e-5
     base = rnd(3, *x.shape)
     for accum in (None, nhwc(base)) if cd is not None else (None,):
-        dx = eng._bottleneck_bwd((c1, c2, c3, cd), nhwc(dout), accum)  # weight gradients run on a side stream
+        dx = eng._bottleneck_bwd((c1, c2, c3, cd), nhwc(dout), accum)
+        eng._side_join()  # weight gradients run on a side stream; engine.backward joins it, a bare block call does not
         ref = xr.grad if accum is None else xr.grad + base
         assert rel_l2(nchw(dx), ref) <= 1e-4, (accum is not None)
     for k, pr in params.items():
@@ -103,6 +104,7 @@ def test_fpn_fwd_bwd():
         assert rel_l2(nchw(o), r.detach()) <= 1e-5
     eng.ctx = ctx
     dcs = eng._fpn_bwd([nhwc(d) for d in douts])
+    eng._side_join()
     for d, cr in zip(dcs, crs):
         assert rel_l2(nchw(d), cr.grad) <= 1e-4
     for k, pr in params.items():
@@ -144,6 +146,7 @@ def test_heads_fwd_bwd_grouped_levels():
     dz_cls = [ops.eltwise(ops.EW_SCALE_SIGMOID_BWD, nhwc(d), pr, scalar=1.0) for d, pr in zip(dcls, probs)]
     dfeat = eng._tower_bwd(dz_cls, 'cls_head.cls_head', 'cls_head.cls_out')
     dfeat = eng._tower_bwd([nhwc(d) for d in dreg], 'reg_head.reg_head', 'reg_head.reg_out', accum_into=dfeat)
+    eng._side_join()
     # five stacked ReLU layers with O(10) activations: a few masks flip on rounding -> 5e-4
     for d, fr in zip(dfeat, frs):
         assert rel_l2(nchw(d), fr.grad) <= 5e-4

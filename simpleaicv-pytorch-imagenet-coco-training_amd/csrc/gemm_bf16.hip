@@ -153,11 +153,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_dma_kernel(const GemmArgs
       cur = cur == 2 ? 0 : cur + 1;
     }
 
-    // ---- epilogue: accumulators -> LDS [BM][BN+4] fp32 -> rows of 8 channels
+    // ---- epilogue: accumulators -> LDS [BM][BN+4] fp32 -> rows of 8 channels.  The old values of an accumulating
+    // bf16 destination are requested for all of the thread's rows BEFORE the accumulators are staged, the fp32 residual
+    // rows of a 128-row half before that half is processed: one exposed HBM latency per tile / per half instead of one
+    // per row (conv_bf16.hip has the measurement).
     constexpr int CS = BN + 4;
-    float* stage = reinterpret_cast<float*>(smem);
+    constexpr int CG = BN / 8, RS = NT / CG;
+    constexpr int NH = BM / 128, RPH = 128 / RS;  // 128-row halves (the CF_STATS granule), rows per thread and half
     int tid_e = threadIdx.x;
     asm volatile("" : "+v"(tid_e));
+    const int c8 = tid_e % CG, rr = tid_e / CG;
+    const int n = n0 + c8 * 8;
+    const bool nok = n < a.N;  // N % 8 == 0
+    const int flags = a.flags;
+    const bool acc_h = (flags & GCF_ACCUM) && !(flags & GCF_OUT_F32);
+    bf16x8 oldh[NH][RPH];
+    if (acc_h) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int i = 0; i < RPH; ++i) {
+          const int m = m0 + h * 128 + rr + i * RS;
+          if (nok && m < a.M)
+            oldh[h][i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(a.C) + (size_t)m * a.N + n);
+        }
+    }
+    float* stage = reinterpret_cast<float*>(smem);
     {
       const int e_lane = tid_e & 63, e_wid = tid_e >> 6;
       const int e_wm0 = (e_wid >> 1) * WTM, e_wn0 = (e_wid & 1) * WTN, e_l31 = e_lane & 31, e_lh = e_lane >> 5;
@@ -170,11 +191,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_dma_kernel(const GemmArgs
             stage[(e_wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * e_lh) * CS + e_wn0 + j * 32 + e_l31] = acc[i][j][r];
     }
     __syncthreads();
-    constexpr int CG = BN / 8, RS = NT / CG;
-    const int c8 = tid_e % CG, rr = tid_e / CG;
-    const int n = n0 + c8 * 8;
-    const bool nok = n < a.N;  // N % 8 == 0
-    const int flags = a.flags;
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = ((flags & GCF_BIAS) && nok) ? a.bias[n + e] : 0.f;
@@ -185,8 +201,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_dma_kernel(const GemmArgs
 #pragma unroll
       for (int e = 0; e < 8; ++e) ssum[h][e] = ssq[h][e] = 0.f;
 #pragma unroll
-    for (int h = 0; h < BM / 128; ++h)
-      for (int row = h * 128 + rr; row < (h + 1) * 128; row += RS) {
+    for (int h = 0; h < NH; ++h) {
+      f32x4 res[RPH][2];
+      if (a.residual) {
+#pragma unroll
+        for (int i = 0; i < RPH; ++i) {
+          const int m = m0 + h * 128 + rr + i * RS;
+          if (nok && m < a.M) {
+            res[i][0] = *reinterpret_cast<const f32x4*>(a.residual + (size_t)m * a.N + n);
+            res[i][1] = *reinterpret_cast<const f32x4*>(a.residual + (size_t)m * a.N + n + 4);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RPH; ++i) {
+        const int row = h * 128 + rr + i * RS;
         const int m = m0 + row;
         if (!(nok && m < a.M)) continue;
         float v[8];
@@ -199,12 +228,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_dma_kernel(const GemmArgs
         }
         const size_t o = (size_t)m * a.N + n;
         if (a.residual) {
-          const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.residual + o);
-          const f32x4 r1 = *reinterpret_cast<const f32x4*>(a.residual + o + 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            v[e] += r0[e];
-            v[4 + e] += r1[e];
+            v[e] += res[i][0][e];
+            v[4 + e] += res[i][1][e];
           }
         }
         if (flags & GCF_OUT_F32) {
@@ -217,10 +244,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_dma_kernel(const GemmArgs
           *reinterpret_cast<f32x4*>(d + 4) = f32x4{v[4], v[5], v[6], v[7]};
         } else {
           bf16* d = reinterpret_cast<bf16*>(a.C) + o;
-          if (flags & GCF_ACCUM) {
-            const bf16x8 old = *reinterpret_cast<const bf16x8*>(d);
+          if (acc_h) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)old[e];
+            for (int e = 0; e < 8; ++e) v[e] += (float)oldh[h][i][e];
           }
           bf16x8 q;
 #pragma unroll
@@ -236,6 +262,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_dma_kernel(const GemmArgs
           ssq[h][e] += v[e] * v[e];
         }
       }
+    }
     if (flags & GCF_STATS) {
       __syncthreads();  // the stage is dead
       float* red = reinterpret_cast<float*>(smem);  // [2 halves][2][RS][BN]

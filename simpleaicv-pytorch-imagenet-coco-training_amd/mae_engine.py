@@ -31,6 +31,31 @@ class MAEEngine:
         self.keep = int(self.n * (1 - mask_ratio))
         self.ctx = None
         self._panels = None
+        # weight gradients on a side HIP stream, as engine.DetectorEngine._on_side (its comment has the contract): every
+        # dy handed to a weight gradient here is a fresh bf16 tensor (cast_bf16 / gelu_bwd / attention_bwd outputs)
+        import os
+        self._side, self._side_busy = None, False
+        if os.environ.get('SACV_WGRAD_STREAM', '1') != '0' and arena.params.is_cuda:
+            self._side = torch.cuda.Stream()
+
+    def _on_side(self, launch, tensors):
+        s = self._side
+        if s is None:
+            return launch()
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        s.wait_event(ev)
+        with torch.cuda.stream(s):
+            launch()
+        for t in tensors:
+            t.record_stream(s)
+        self._side_busy = True
+
+    def _side_join(self):
+        if self._side is not None and self._side_busy:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_busy = False
 
     # ------------------------------------------------------------------ weight panels
     def _refresh_panels(self):
@@ -72,18 +97,18 @@ class MAEEngine:
         c = dx.shape[1]
         q = V.ColsumQueue()
         dxb = ops.cast_bf16(dx)
-        V.linear_wgrad(dxb, s.g, g[pre + '.mlp.fc2.weight'], g[pre + '.mlp.fc2.bias'], queue=q)
+        V.linear_wgrad(dxb, s.g, g[pre + '.mlp.fc2.weight'], g[pre + '.mlp.fc2.bias'], queue=q, side=self._on_side)
         dg = V.linear_dgrad(dxb, self._wd(pre + '.mlp.fc2.weight'), s.g.shape[1])
         df = V.gelu_bwd(dg, s.f)
-        V.linear_wgrad(df, s.h2, g[pre + '.mlp.fc1.weight'], g[pre + '.mlp.fc1.bias'], queue=q)
+        V.linear_wgrad(df, s.h2, g[pre + '.mlp.fc1.weight'], g[pre + '.mlp.fc1.bias'], queue=q, side=self._on_side)
         dh2 = V.linear_dgrad(df, self._wd(pre + '.mlp.fc1.weight'), c)
         V.layernorm_bwd(dh2, s.x1, s.m2, s.r2, p[pre + '.norm2.weight'], g[pre + '.norm2.weight'],
                         g[pre + '.norm2.bias'], dx=dx, queue=q)
         dxb = ops.cast_bf16(dx)
-        V.linear_wgrad(dxb, s.a, g[pre + '.attn.proj.weight'], g[pre + '.attn.proj.bias'], queue=q)
+        V.linear_wgrad(dxb, s.a, g[pre + '.attn.proj.weight'], g[pre + '.attn.proj.bias'], queue=q, side=self._on_side)
         da = V.linear_dgrad(dxb, self._wd(pre + '.attn.proj.weight'), c)
         dqkv = V.attention_bwd(s.qkv, s.a, da, s.lse, b, n, heads)
-        V.linear_wgrad(dqkv, s.h, g[pre + '.attn.qkv.weight'], g[pre + '.attn.qkv.bias'], queue=q)
+        V.linear_wgrad(dqkv, s.h, g[pre + '.attn.qkv.weight'], g[pre + '.attn.qkv.bias'], queue=q, side=self._on_side)
         dh = V.linear_dgrad(dqkv, self._wd(pre + '.attn.qkv.weight'), c)
         V.layernorm_bwd(dh, s.x0, s.m1, s.r1, p[pre + '.norm1.weight'], g[pre + '.norm1.weight'],
                         g[pre + '.norm1.bias'], dx=dx, queue=q)
@@ -135,7 +160,7 @@ class MAEEngine:
         if ctx is None:
             raise RuntimeError('backward() without a preceding forward(keep=True)')
         b = ctx['b']
-        V.linear_wgrad(dpred, ctx['xdn'], g['decoder.fc.weight'], g['decoder.fc.bias'])
+        V.linear_wgrad(dpred, ctx['xdn'], g['decoder.fc.weight'], g['decoder.fc.bias'], side=self._on_side)
         dxdn = V.linear_dgrad(dpred, self._wd('decoder.fc.weight'), self.D)
         dx = V.layernorm_bwd(dxdn, ctx['x_dec'], ctx['md'], ctx['rd'], p['decoder.norm.weight'],
                              g['decoder.norm.weight'], g['decoder.norm.bias'])
@@ -143,8 +168,10 @@ class MAEEngine:
             dx = self._block_bwd(dx, ctx['dec'][i], f'decoder.blocks.{i}', b, self.n + 1, self.Hd)
         dy, gmask = V.decoder_tokens_bwd(dx, ctx['shuffle'], self.keep)
         ops.colsum(gmask, self.D, g['decoder.mask_token'].reshape(-1))
-        V.linear_wgrad(dy, ctx['xn'], g['encoder_to_decoder.weight'], g['encoder_to_decoder.bias'])
+        V.linear_wgrad(dy, ctx['xn'], g['encoder_to_decoder.weight'], g['encoder_to_decoder.bias'],
+                       side=self._on_side)
         if on_stage:
+            self._side_join()
             on_stage('heads')  # decoder + encoder_to_decoder weights (the tail of the arena) are final
         dxn = V.linear_dgrad(dy, self._wd('encoder_to_decoder.weight'), self.E)
         dx = V.layernorm_bwd(dxn, ctx['x_enc'], ctx['me'], ctx['re'], p['encoder.norm.weight'],
@@ -154,7 +181,9 @@ class MAEEngine:
         dcls_rows = dx.view(b, self.keep + 1, self.E)[:, 0, :].contiguous()
         ops.colsum(dcls_rows, self.E, g['encoder.cls_token'].reshape(-1))
         demb = V.encoder_tokens_bwd(dx, b, self.keep)
-        V.linear_wgrad(demb, ctx['rows'], g['encoder.patch_embed.proj.weight'], g['encoder.patch_embed.proj.bias'])
+        V.linear_wgrad(demb, ctx['rows'], g['encoder.patch_embed.proj.weight'], g['encoder.patch_embed.proj.bias'],
+                       side=self._on_side)
+        self._side_join()
         if on_stage:
             for st in ('neck', 'mid', 'rest'):
                 on_stage(st)

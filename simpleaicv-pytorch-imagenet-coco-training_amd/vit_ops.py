@@ -246,10 +246,15 @@ def linear_dgrad(dy, w_dpanel, k):
     return ops.conv_gemm([dy.view(1, 1, r, n)], w_dpanel, k, 1, 1, 1, 0, 1, [(1, r)])[0].view(r, k)
 
 
-def linear_wgrad(dy, x, dw, db, queue=None):
-    """dw[N,K] = dy^T x (fp32 gradient view), db[N] = column sums of dy (second stage through `queue` when given)."""
+def linear_wgrad(dy, x, dw, db, queue=None, side=None):
+    """dw[N,K] = dy^T x (fp32 gradient view), db[N] = column sums of dy (second stage through `queue` when given).
+    `side(launch, tensors)`: the engine's weight-gradient stream (engine.DetectorEngine._on_side)."""
     r, n = dy.shape
     k = x.shape[1]
-    ops.conv_wgrad([dy.view(1, 1, r, n)], [x.view(1, 1, r, k)], dw.reshape(n, k, 1, 1), k, 1, 1, 1, 0)
+    launch = lambda: ops.conv_wgrad([dy.view(1, 1, r, n)], [x.view(1, 1, r, k)], dw.reshape(n, k, 1, 1), k, 1, 1, 1, 0)
+    if side is not None:
+        side(launch, [dy, x])
+    else:
+        launch()
     if db is not None:
         colsum_bf16(dy, db, queue=queue)

@@ -135,12 +135,17 @@ def bench_classification(args, rank, world, group, ops, synth):
     if not args.no_kernel_timer:
         timer = ops.KernelTimer()
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         ops.TIMER = timer if (timer is not None and i % args.timer_every == 0) else None
         out = trainer.step(images, labels)
+        marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    ms_median = per_step[len(per_step) // 2]
     ops.TIMER = None
     n_inst = len(range(0, args.steps, args.timer_every))  # timed steps that carried per-launch events
     loss = trainer.finish_step(out)
@@ -199,6 +204,7 @@ def bench_classification(args, rank, world, group, ops, synth):
             'metric': 'images/sec/node ResNet50 ImageNet 224x224 bs=256/GPU (secondary, SURVEY 8f-1)',
             'value': round(world * CB * args.steps / elapsed, 2), 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'ms_per_step_median': round(ms_median, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'ResNet50 ImageNet training step (fwd + CELoss + bwd + grad all-reduce + SGD '
                                    'momentum), images [256,3,224,224]/GPU, random init'
@@ -237,12 +243,17 @@ def bench_mae(args, rank, world, group, ops, synth):
     if not args.no_kernel_timer:
         timer = ops.KernelTimer()
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         ops.TIMER = timer if (timer is not None and i % args.timer_every == 0) else None
         out = trainer.step(images)
+        marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    ms_median = per_step[len(per_step) // 2]
     ops.TIMER = None
     n_inst = len(range(0, args.steps, args.timer_every))  # timed steps that carried per-launch events
     loss = trainer.finish_step(out)
@@ -275,6 +286,7 @@ def bench_mae(args, rank, world, group, ops, synth):
             'metric': 'images/sec/node ViT-B/16 MAE pre-training 224x224 bs=128/GPU (secondary, SURVEY 8f-4)',
             'value': round(world * MB * args.steps / elapsed, 2), 'unit': 'images/sec', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'ms_per_step_median': round(ms_median, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': 'ViT-B/16 MAE pre-training step (random masking 0.75, encoder 12x768 on 50 tokens, '
                                    'decoder 8x512 on 197 tokens, masked MSE on normalised patches, bwd, grad all-reduce, '

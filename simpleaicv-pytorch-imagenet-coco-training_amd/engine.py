@@ -65,6 +65,10 @@ class DetectorEngine:
         self._side, self._side_busy = None, False  # the weight gradients' stream (see _on_side)
         if os.environ.get('SACV_WGRAD_STREAM', '1') != '0' and p and next(iter(p.values())).is_cuda:
             self._side = torch.cuda.Stream()
+            self._side_events = [torch.cuda.Event() for _ in range(64)]
+        self._side_evi, self._side_keep = 0, []
+        self._bias_on_side = os.environ.get('SACV_BIAS_SIDE', '1') != '0'
+        self._ds_on_side = os.environ.get('SACV_DS_SIDE', '1') != '0'
 
     def _wgrad(self, dys, xs, dw, cin, kh, kw, stride, pad, **kw_args):
         self._on_side(lambda: ops.conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, **kw_args), list(dys) + list(xs))
@@ -84,19 +88,29 @@ class DetectorEngine:
         if s is None:
             return launch()
         cur = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
+        # events come from a small ring (creating / destroying ~150 HIP events per step showed up as multi-second host
+        # stalls on a loaded box); a ring slot is reused only long after its wait has been enqueued
+        ev = self._side_events[self._side_evi]
+        self._side_evi = (self._side_evi + 1) % len(self._side_events)
         ev.record(cur)
         s.wait_event(ev)
-        with torch.cuda.stream(s):
-            launch()
-        for t in tensors:
-            t.record_stream(s)  # the caching allocator must not recycle these blocks under the side stream's reads
+        ops.WS_SUFFIX = '@side'  # scratch buffers of their own: nothing the launch stream's kernels are using
+        try:
+            with torch.cuda.stream(s):
+                launch()
+        finally:
+            ops.WS_SUFFIX = ''
+        # The tensors the side stream reads stay referenced until the launch stream has joined the side stream
+        # (_side_join): they are then freed in the launch stream's order, behind the join, so the caching allocator can
+        # recycle them for launch-stream work without any cross-stream bookkeeping (no Tensor.record_stream).
+        self._side_keep.extend(tensors)
         self._side_busy = True
 
     def _side_join(self):
         if self._side is not None and self._side_busy:
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_busy = False
+            self._side_keep.clear()
 
     def set_amp(self, enabled, arena=None):
         """Switch the bf16 matrix-core path on/off (the reference's config.use_amp / autocast)."""
@@ -282,7 +296,11 @@ class DetectorEngine:
         ctx = {} if keep else None
         self._wino_cache = {}  # Winograd-domain weights are per forward (the optimizer step changes the weights)
         if keep:
-            self._refresh_dgrad_panels()
+            if self.amp or not self._ds_on_side:
+                self._refresh_dgrad_panels()  # amp: the same launch pair also casts the FORWARD panels
+            else:
+                # fp32: the data-gradient panels are read by the backward pass only (which joins the side stream first)
+                self._on_side(self._refresh_dgrad_panels, [])
         feats = self._backbone_fwd(images, training, keep, ctx)
         c3f, c4f, c5f = feats[1], feats[2], feats[3]
         fpn = self._fpn_fwd(c3f, c4f, c5f, ctx)
@@ -361,9 +379,26 @@ class DetectorEngine:
         """Bottleneck.forward (classification/backbones/resnet.py:141-155): 1x1 -> 3x3(stride) -> 1x1,
         shortcut (1x1 conv + BN when the shape changes), add + ReLU fused into the last BN pass."""
         has_ds = (pre + '.downsample_conv.layer.0.weight') in self.p
+        ds_side = has_ds and self._side is not None and self._ds_on_side
+        if ds_side:
+            # the shortcut branch (1x1 conv + BN) only meets the main branch at conv3's BatchNorm pass: it runs on the
+            # side stream under conv1 / conv2.  Its tensors are allocated under the side stream but live on (the
+            # residual add, the backward pass) on the launch stream: record_stream tells the caching allocator so.
+            box = {}
+
+            def shortcut():
+                box['r'] = self._cba_fwd(x, pre + '.downsample_conv', 1, stride, 0, False, training, keep=keep)
+            self._on_side(shortcut, [x])
         z1, c1 = self._cba_fwd(x, pre + '.conv1', 1, 1, 0, True, training, keep=keep)
         z2, c2 = self._cba_fwd(z1, pre + '.conv2', 3, stride, 1, True, training, keep=keep)
-        if has_ds:
+        if ds_side:
+            self._side_join()
+            idt, cd = box['r']
+            cur = torch.cuda.current_stream()
+            for t in (idt,) + ((cd.y, cd.mean, cd.invstd) if cd is not None else ()):
+                if t is not None:
+                    t.record_stream(cur)
+        elif has_ds:
             idt, cd = self._cba_fwd(x, pre + '.downsample_conv', 1, stride, 0, False, training, keep=keep)
         else:
             idt, cd = x, None
@@ -712,10 +747,24 @@ class DetectorEngine:
 
     # ------------------------------------------------------------------ backward
     def _bias_grad(self, dys, name):
+        """Column sums of dy: like the weight gradients, nothing in the backward pass waits for them -> side stream."""
         gb = self.g[name + '.bias']
         c = gb.numel()
-        for i, d in enumerate(dys):
-            ops.colsum(d, c, gb, accumulate=i > 0)
+
+        def launch():
+            for i, d in enumerate(dys):
+                ops.colsum(d, c, gb, accumulate=i > 0)
+        if self._bias_on_side:
+            self._on_side(launch, list(dys))
+        else:
+            launch()
+
+    def _bias_grad_from_stats(self, st, gb):
+        """Second stage of a bias gradient whose column sums came out of a data-gradient epilogue (CF_STATS)."""
+        if self._bias_on_side:
+            self._on_side(lambda: ops.colsum_finalize(st, gb), [st])
+        else:
+            ops.colsum_finalize(st, gb)
 
     def _tower_bwd(self, dys, tower, out_name, accum_into=None):
         """dys: per-level grads w.r.t. the tower's output conv result (pre-activation).
@@ -737,7 +786,7 @@ class DetectorEngine:
             w = p[name + '.weight']
             xs = saved[li]
             self._wgrad(cur, xs, g[name + '.weight'], w.shape[1], 3, 3, 1, 1)
-            ops.colsum_finalize(st, g[name + '.bias'])
+            self._bias_grad_from_stats(st, g[name + '.bias'])
             wd = self._dgrad_panel(w)
             if li > 0:
                 cur, st = ops.conv_gemm(cur, wd, w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_MASK, masks=xs, stats=True)
@@ -773,7 +822,7 @@ class DetectorEngine:
             ws = [p[n + '.weight'] for n in names]
             for t in range(2):
                 self._wino_wgrad(cur[t], saved[t][li], vsaved[t][li], g[names[t] + '.weight'], ws[t].shape[1])
-                ops.colsum_finalize(st[t], g[names[t] + '.bias'])
+                self._bias_grad_from_stats(st[t], g[names[t] + '.bias'])
             us = [self._wino_u(w, dgrad=True) for w in ws]
             if li > 0:
                 cur, st = ops.conv3x3_wino(cur, us, [self.planes] * 2, flags=[CF_MASK] * 2,
@@ -799,6 +848,7 @@ class DetectorEngine:
         ctx = self.ctx
         if ctx is None:
             raise RuntimeError('backward() without a preceding forward(keep=True)')
+        self._side_join()  # the forward pass's side-stream work (data-gradient panels) is complete
         if self.fcos:
             dfeat = self._fcos_heads_bwd(dcls_levels, dreg_levels, dctr_levels, grad_scale)
             return self._trunk_bwd(dfeat, on_stage)

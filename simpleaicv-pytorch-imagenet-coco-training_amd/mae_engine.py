@@ -37,25 +37,31 @@ class MAEEngine:
         self._side, self._side_busy = None, False
         if os.environ.get('SACV_WGRAD_STREAM', '1') != '0' and arena.params.is_cuda:
             self._side = torch.cuda.Stream()
+            self._side_events = [torch.cuda.Event() for _ in range(64)]
+        self._side_evi, self._side_keep = 0, []
 
     def _on_side(self, launch, tensors):
         s = self._side
         if s is None:
             return launch()
-        cur = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(cur)
+        ev = self._side_events[self._side_evi]  # event ring and keep-alive list: see DetectorEngine._on_side
+        self._side_evi = (self._side_evi + 1) % len(self._side_events)
+        ev.record(torch.cuda.current_stream())
         s.wait_event(ev)
-        with torch.cuda.stream(s):
-            launch()
-        for t in tensors:
-            t.record_stream(s)
+        ops.WS_SUFFIX = '@side'
+        try:
+            with torch.cuda.stream(s):
+                launch()
+        finally:
+            ops.WS_SUFFIX = ''
+        self._side_keep.extend(tensors)
         self._side_busy = True
 
     def _side_join(self):
         if self._side is not None and self._side_busy:
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_busy = False
+            self._side_keep.clear()
 
     # ------------------------------------------------------------------ weight panels
     def _refresh_panels(self):

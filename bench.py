@@ -309,9 +309,11 @@ def main():
                     help='retinanet = the headline metric; fcos = secondary workload (BASELINE config 4); '
                          'resnet50_cls = ResNet50 ImageNet classification, bs 256/GPU, 224x224 (SURVEY.md 8f-1)')
     ap.add_argument('--no-kernel-timer', action='store_true')
-    ap.add_argument('--timer-every', type=int, default=5,
-                    help='per-launch HIP events (the roofline measurement) on every Nth timed step: each event costs '
-                         '~2.7 us of launch-stream time, 440 of them 1.2 ms of a 31 ms step')
+    ap.add_argument('--timer-every', type=int, default=10,
+                    help='per-launch HIP events (the roofline measurement) on every Nth timed step.  An instrumented '
+                         'step costs ~3 ms more than a plain one: 440 event records (~2.7 us each) and, since round 3, '
+                         'the weight-gradient side stream is folded back into the launch stream for that step so that '
+                         'every timed kernel has the chip to itself (its own duration, not a shared one)')
     ap.add_argument('--image-size', default='800x1333',
                     help='HxW of the synthetic batch: 800x1333 = the headline shape S1, 1333x1333 = the collater\'s '
                          'padded square S2 (SURVEY.md 8d)')
@@ -434,7 +436,7 @@ def main():
             # HBM traffic per launch of the same kernel family from the PMC passes committed under profiles/
             # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read-doubling applied there)
             traffic = None
-            for tname in ('r02b_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+            for tname in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
                 tpath = os.path.join(ROOT, 'profiles', tname)
                 if os.path.exists(tpath) and args.model == 'retinanet' and (H, W) == (800, 1333):
                     traffic = round(json.load(open(tpath))['hbm_bytes_per_launch'])
@@ -485,7 +487,9 @@ def main():
             executed = (k['flops'] - wino['flops'] + wino['flops'] / 2.25) / (k['ms'] * 1e-3) / 1e12
             roofline['matrix_core'] = dict(achieved=round(executed, 2), frac=round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
                                            unit='TFLOP/s', note='executed MFMA flops / time of the same launches')
-            roofline['instrumented_steps'] = f'{n_inst} of the {args.steps} timed steps (every {args.timer_every}th)'
+            roofline['instrumented_steps'] = (f'{n_inst} of the {args.steps} timed steps (every {args.timer_every}th), run '
+                                              'in stream order: the other steps overlap the weight gradients with the '
+                                              'data-gradient chain on a side stream (ms_per_step_median = such a step)')
             if paths:
                 roofline['paths'] = paths
             if secondary:

@@ -64,7 +64,7 @@ class DetectorEngine:
         import os
         self._side, self._side_busy = None, False  # the weight gradients' stream (see _on_side)
         if os.environ.get('SACV_WGRAD_STREAM', '1') != '0' and p and next(iter(p.values())).is_cuda:
-            self._side = torch.cuda.Stream()
+            self._side = torch.cuda.Stream()  # (the launch stream at high priority: 27.82 -> 27.62 ms; not adopted)
             self._side_events = [torch.cuda.Event() for _ in range(64)]
         self._side_evi, self._side_keep = 0, []
         self._bias_on_side = os.environ.get('SACV_BIAS_SIDE', '1') != '0'
@@ -85,7 +85,9 @@ class DetectorEngine:
     # accumulation into a gradient tensor precedes its use as a dy; checked call site by call site).
     def _on_side(self, launch, tensors):
         s = self._side
-        if s is None:
+        if s is None or ops.TIMER is not None:
+            # no side stream, or a step instrumented with per-launch HIP events (bench.py's roofline measurement): a
+            # kernel timed while another stream's kernels share the chip would not report its OWN duration
             return launch()
         cur = torch.cuda.current_stream()
         # events come from a small ring (creating / destroying ~150 HIP events per step showed up as multi-second host

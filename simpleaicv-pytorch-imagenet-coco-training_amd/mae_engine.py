@@ -42,7 +42,7 @@ class MAEEngine:
 
     def _on_side(self, launch, tensors):
         s = self._side
-        if s is None:
+        if s is None or ops.TIMER is not None:  # instrumented steps run in stream order (DetectorEngine._on_side)
             return launch()
         ev = self._side_events[self._side_evi]  # event ring and keep-alive list: see DetectorEngine._on_side
         self._side_evi = (self._side_evi + 1) % len(self._side_events)

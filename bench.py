@@ -309,7 +309,7 @@ def main():
                     help='retinanet = the headline metric; fcos = secondary workload (BASELINE config 4); '
                          'resnet50_cls = ResNet50 ImageNet classification, bs 256/GPU, 224x224 (SURVEY.md 8f-1)')
     ap.add_argument('--no-kernel-timer', action='store_true')
-    ap.add_argument('--timer-every', type=int, default=10,
+    ap.add_argument('--timer-every', type=int, default=20,
                     help='per-launch HIP events (the roofline measurement) on every Nth timed step.  An instrumented '
                          'step costs ~3 ms more than a plain one: 440 event records (~2.7 us each) and, since round 3, '
                          'the weight-gradient side stream is folded back into the launch stream for that step so that '

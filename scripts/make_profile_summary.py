@@ -120,6 +120,11 @@ def main():
         i = sys.argv.index('--mfma')
         mfma_md = mfma_utilisation(sys.argv[i + 1], sys.argv[1])
         del sys.argv[i:i + 2]
+    overlapped = None
+    if '--overlapped' in sys.argv:
+        i = sys.argv.index('--overlapped')
+        overlapped = sys.argv[i + 1]
+        del sys.argv[i:i + 2]
     tag, stats_p, bench_p, pf, pw = sys.argv[1:6]
     steps = 7
     prof = os.path.join(ROOT, 'profiles')
@@ -172,6 +177,21 @@ def main():
              ('im2col_stem_kernel', (2 * 3 * 800 * 1333 + 2 * 400 * 667 * 160) * 4 / 1e9, 'read image, write im2col matrix')]
     md += hbm_table(by, steps, 2, 800, 1333, extra)
     md += mfma_md
+    if overlapped:
+        orow = read_stats(overlapped)
+        with open(os.path.join(prof, f'{tag}_bench_kernel_stats_overlapped.csv'), 'w') as f:
+            f.write(open(overlapped).read())
+        ototal = sum(r[2] for r in orow) / steps / 1e6
+        md += ['', '## The step as it runs: weight gradients on the side stream', '',
+               'The tables above come from a run with `SACV_WGRAD_STREAM=0` (every kernel in stream order, alone on the chip: the '
+               "durations `roofline` is computed from; bench.py's instrumented steps run the same way).  In normal steps the weight "
+               'gradients, their reductions, the bias-gradient column sums and the shortcut branch of the forward pass run on a second '
+               f'HIP stream.  `rocprofv3 --kernel-trace --stats` of such a run (`{tag}_bench_kernel_stats_overlapped.csv`): the kernel '
+               f'durations sum to {ototal:.2f} ms per step (two queues; overlapped kernels share the chip and each takes longer) while '
+               f'the step takes {bench.get("ms_per_step_median", bench["ms_per_step"])} ms (median of the un-instrumented steps).', '',
+               '| kernel | calls/step | ms/step (overlapped) | avg us |', '|---|---|---|---|']
+        for name, calls, tot, avg, pct in orow[:14]:
+            md.append(f'| `{name[:60]}` | {calls / steps:.1f} | {tot / steps / 1e6:.3f} | {avg / 1e3:.1f} |')
     if 'cpu_baseline' in bench:
         md += ['', f'CPU baseline (same run, {bench["cpu_baseline"]["cores"]} host threads): {bench["cpu_baseline"]}']
     if len(sys.argv) > 7:

@@ -189,16 +189,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const T* __r
   const int r_end = min(R, r_begin + rows_per_block);
   float* out = partial + (size_t)blockIdx.x * 2 * C;
   float ga[V], be[V];  // recompute path: the thread's channel group is fixed in both branches below
-  auto accum = [&](int r, int cv, const float (&mu)[V], const float (&is)[V], float (&s)[V], float (&q)[V]) {
-    const size_t o = (size_t)r * C + cv * V;
-    float g[V], v[V], xhat[V];
-    VecIO<T>::load(dz + o, g);
-    VecIO<T>::load(y + o, v);
+  // one row: the arithmetic of a (dz, y[, z]) triple already in registers; rows are ALWAYS folded in ascending order,
+  // so the sums do not depend on how many rows were loaded ahead
+  auto fold = [&](const float (&g0)[V], const float (&v)[V], const float (&zz)[V], const float (&mu)[V],
+                  const float (&is)[V], float (&s)[V], float (&q)[V]) {
+    float g[V], xhat[V];
 #pragma unroll
-    for (int k = 0; k < V; ++k) xhat[k] = (v[k] - mu[k]) * is[k];
+    for (int k = 0; k < V; ++k) {
+      g[k] = g0[k];
+      xhat[k] = (v[k] - mu[k]) * is[k];
+    }
     if (zmask) {
-      float zz[V];
-      VecIO<T>::load(zmask + o, zz);
 #pragma unroll
       for (int k = 0; k < V; ++k) g[k] = zz[k] > 0.f ? g[k] : 0.f;
     } else if (rc_beta) {
@@ -209,6 +210,33 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const T* __r
     for (int k = 0; k < V; ++k) {
       s[k] += g[k];
       q[k] += g[k] * xhat[k];
+    }
+  };
+  // rows r, r + step, ... < r_end of channel group cv.  Four rows are requested before the first is folded: with two
+  // 256-thread blocks per CU a thread that waits for each row's two or three 16-byte loads in turn keeps ~16 KB per CU
+  // in flight, half of what 5.5 TB/s x ~1.5 us of latency needs (the kernel ran at 0.53-0.60 of the HBM roofline).
+  auto accum_rows = [&](int r0, int step, int cv, const float (&mu)[V], const float (&is)[V], float (&s)[V],
+                        float (&q)[V]) {
+    int r = r0;
+    for (; r + 3 * step < r_end; r += 4 * step) {
+      float g[4][V], v[4][V], zz[4][V];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t o = (size_t)(r + u * step) * C + cv * V;
+        VecIO<T>::load(dz + o, g[u]);
+        VecIO<T>::load(y + o, v[u]);
+        if (zmask) VecIO<T>::load(zmask + o, zz[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) fold(g[u], v[u], zz[u], mu, is, s, q);
+    }
+    for (; r < r_end; r += step) {
+      float g[V], v[V], zz[V];
+      const size_t o = (size_t)r * C + cv * V;
+      VecIO<T>::load(dz + o, g);
+      VecIO<T>::load(y + o, v);
+      if (zmask) VecIO<T>::load(zmask + o, zz);
+      fold(g, v, zz, mu, is, s, q);
     }
   };
   if (cg >= BN_THREADS) {
@@ -222,7 +250,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const T* __r
       }
 #pragma unroll
       for (int k = 0; k < V; ++k) s[k] = q[k] = 0.f;
-      for (int r = r_begin; r < r_end; ++r) accum(r, cv, mu, is, s, q);
+      accum_rows(r_begin, 1, cv, mu, is, s, q);
 #pragma unroll
       for (int k = 0; k < V; ++k) {
         out[cv * V + k] = s[k];
@@ -243,7 +271,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const T* __r
     }
 #pragma unroll
     for (int k = 0; k < V; ++k) s[k] = q[k] = 0.f;
-    for (int r = r_begin + rlane; r < r_end; r += rl) accum(r, cv, mu, is, s, q);
+    accum_rows(r_begin + rlane, rl, cv, mu, is, s, q);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       sm[(size_t)rlane * 2 * C + cv * V + k] = s[k];

@@ -493,6 +493,8 @@ class DetectorEngine:
         """All Winograd-domain weights of the head convolutions in ONE launch per pass (forward panels, and the
         data-gradient panels when a backward pass follows) instead of one 5 us launch per weight and direction."""
         jobs, keys = [], []
+        if training:
+            self._side_join()  # the data-gradient panels read below are refreshed on the side stream (forward())
         for n in names:
             w = self.p[n]
             co, ci = w.shape[0], w.shape[1]

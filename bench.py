@@ -331,6 +331,9 @@ def main():
 
     global H, W
     H, W = (int(v) for v in args.image_size.lower().split('x'))
+    # dmabuf IPC: what RCCL / cross-process device memory needs on this driver (already exported on the pool's boxes;
+    # set here too so that a rank started by any launcher has it before the HIP runtime loads)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and 'RANK' not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet (no torch.cuda

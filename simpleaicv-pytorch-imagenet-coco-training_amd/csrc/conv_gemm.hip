@@ -508,12 +508,18 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
 }
 
 // Sums the stream-K slabs of each remainder tile in block order (deterministic) and applies the epilogue.
-template <int BM, int BN>
-__global__ __launch_bounds__(1024) void conv_fixup_kernel(const ConvArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[2 * (1024 / (BN / 4)) * BN];
+// NT = 1024: one workgroup per tile (the form CF_STATS needs: the tile's column sums come out of one workgroup).
+// NT = 256, QS = 4: four workgroups per tile, 32 rows each -- for launches without CF_STATS.  In the backward pass the
+// fix-up shares the chip with the weight gradients of the side stream, whose persistent workgroups hold most of every
+// CU's registers: a 1024-thread workgroup has to wait for a CU to drain (13 us alone became 25-44 us there), 256-thread
+// ones fit into what is left.
+template <int BM, int BN, int NT = 1024, int QS = 1>
+__global__ __launch_bounds__(NT) void conv_fixup_kernel(const ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[QS == 1 ? 2 * (NT / (BN / 4)) * BN : 4];
   __shared__ int slab_of[256];
   __shared__ int nparts_s;
-  const int rt = blockIdx.x;
+  const int rt = blockIdx.x / QS;
+  const int qrow = (blockIdx.x % QS) * (BM / QS);  // first tile row of this workgroup
   const int ntn = (a.N + BN - 1) / BN;
   const int KT = a.KH * a.KW * ((a.Cs + 31) >> 5);
   const int tile = a.base * a.grid + rt;
@@ -538,13 +544,15 @@ __global__ __launch_bounds__(1024) void conv_fixup_kernel(const ConvArgs a) {
   }
   __syncthreads();
   const int nparts = nparts_s;
-  const TileCoord tc = tile_coord<BM, BN>(a, tile);
-  vec_epilogue<BM, BN, 1024>(
+  TileCoord tc = tile_coord<BM, BN>(a, tile);
+  tc.m0 += qrow;
+  vec_epilogue<BM / QS, BN, NT>(
       a, tc, tile / ntn,
       [&](int row, int c4) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         for (int part = 0; part < nparts; ++part)
-          v += *reinterpret_cast<const f32x4*>(a.partial + (size_t)slab_of[part] * (BM * BN) + row * BN + c4 * 4);
+          v += *reinterpret_cast<const f32x4*>(a.partial + (size_t)slab_of[part] * (BM * BN) + (qrow + row) * BN +
+                                               c4 * 4);
         return v;
       },
       red);
@@ -1092,7 +1100,10 @@ static int launch_nt(ConvArgs& a, const NtPlan& plan, float* workspace, hipStrea
   hipLaunchKernelGGL((conv_nt_kernel<BM, BN, MODE, WN, OCC, SWZ>), dim3(launch_blocks), dim3(128 * WN), lds, st, a);
   SACV_CHECK_LAUNCH("conv_nt_kernel");
   if (a.sk_blocks > a.rem_tiles) {
-    hipLaunchKernelGGL((conv_fixup_kernel<BM, BN>), dim3(a.rem_tiles), dim3(1024), 0, st, a);
+    if (a.flags & CF_STATS)
+      hipLaunchKernelGGL((conv_fixup_kernel<BM, BN>), dim3(a.rem_tiles), dim3(1024), 0, st, a);
+    else
+      hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, 256, 4>), dim3(a.rem_tiles * 4), dim3(256), 0, st, a);
     SACV_CHECK_LAUNCH("conv_fixup_kernel");
   }
   return SACV_OK;

@@ -96,7 +96,9 @@ class DetectorEngine:
         self._side_evi = (self._side_evi + 1) % len(self._side_events)
         ev.record(cur)
         s.wait_event(ev)
-        ops.WS_SUFFIX = '@side'  # scratch buffers of their own: nothing the launch stream's kernels are using
+        # scratch buffers of their own: nothing the launch stream's kernels are using.  (A module-level switch: the
+        # engines enqueue from ONE host thread, like the reference's training loop.)
+        ops.WS_SUFFIX = '@side'
         try:
             with torch.cuda.stream(s):
                 launch()
@@ -1012,6 +1014,7 @@ class ClassifierEngine(DetectorEngine):
         ctx = self.ctx
         if ctx is None:
             raise RuntimeError('backward() without a preceding forward(keep=True)')
+        self._side_join()
         w = ctx['fc_w']
         nout, nin = self.p['fc.weight'].shape
         npad = w.shape[0]

@@ -1238,7 +1238,10 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
   // 128 x 64 tiles run at THREE workgroups per CU (swizzled, unpadded 48 KB LDS image; 134-136 VGPRs): finer-grained
   // rounds and a third workgroup to fill the CU while two sit in their epilogues.  Relative cost of a K-iteration 0.8
   // (0.6-0.8 measured the same); against the two-per-CU form of the same kernel: 30.14 -> 29.85 ms per step.
-  NtPlan p64 = plan_nt(tiles * ((N + 63) / 64), KT, num_cus() * 3, ws, 0.8);
+#ifndef SACV_W64_DGRAD
+#define SACV_W64_DGRAD 0.8  // tuning builds only (scripts/build_variant.sh): relative K-iteration cost in mode 1
+#endif
+  NtPlan p64 = plan_nt(tiles * ((N + 63) / 64), KT, num_cus() * 3, ws, mode == 1 ? SACV_W64_DGRAD : 0.8);
   const bool use64 = (N <= 64) || (p64.cost < p128.cost);
   if (use64)
     return mode == 0 ? launch_nt<128, 64, 0, 2, 3, true>(a, p64, workspace, st)

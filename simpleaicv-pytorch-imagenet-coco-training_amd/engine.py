@@ -67,8 +67,8 @@ class DetectorEngine:
             self._side = torch.cuda.Stream()  # (the launch stream at high priority: 27.82 -> 27.62 ms; not adopted)
             self._side_events = [torch.cuda.Event() for _ in range(64)]
         self._side_evi, self._side_keep = 0, []
-        self._bias_on_side = os.environ.get('SACV_BIAS_SIDE', '1') != '0'
-        self._ds_on_side = os.environ.get('SACV_DS_SIDE', '1') != '0'
+        # (one switch, SACV_WGRAD_STREAM=0, turns the second stream off: A/B runs and the profile session's serial trace)
+        self._bias_on_side = self._ds_on_side = True
 
     def _wgrad(self, dys, xs, dw, cin, kh, kw, stride, pad, **kw_args):
         self._on_side(lambda: ops.conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, **kw_args), list(dys) + list(xs))

@@ -444,11 +444,14 @@ def sec_e2e_s2(ref):
 def sec_e2e_other(ref):
     """The square yolo-style inputs of the other detection recipes: VOC 640 x 640 with 20 classes
     (3.detection_training/voc/res50_{retinanet,fcos}_yoloresize640/train_config.py:23-24) and the Objects365 canvas
-    1024 x 1024 (objects365/res50_retinanet_yoloresize1024/train_config.py:24; with COCO's 80 classes here -- the
-    365-class heads need num_classes % 4 == 0 on the MI355X path)."""
+    1024 x 1024 (objects365/res50_retinanet_yoloresize1024/train_config.py:23-24), the canvas with COCO's 80 classes and
+    the 365 classes at 256 x 320."""
     out, meta = {}, {}
     for name, (H, W), fcos, nc in (('retina_V640', (640, 640), False, 20), ('fcos_V640', (640, 640), True, 20),
-                                   ('retina_O1024', (1024, 1024), False, 80)):
+                                   ('retina_O1024', (1024, 1024), False, 80),
+                                   # Objects365's class count (9 x 365 = 3285 class channels: not a multiple of 4) at a
+                                   # small canvas -- the 1024 x 1024 recipe itself has 1.1 G class scores per batch
+                                   ('retina_C365', (256, 320), False, 365), ('fcos_C365', (256, 320), True, 365)):
         m, a = _e2e(ref, name, H, W, fcos, num_classes=nc)
         assert m['feature_sizes'] == synth.feature_sizes(H, W)
         m['H'], m['W'], m['num_classes'] = H, W, nc

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void focal_fwd_bwd_kernel(const LevelPtrs lp, 
                                                              float gamma, float weight,
                                                              const int* __restrict__ counts,
                                                              float* __restrict__ partial) {
-  const int cg = C >> 2;
+  const int cg = (C + 3) >> 2;        // class groups of 4; the last one is partial when C % 4 != 0 (Objects365: 365)
+  const bool vec = (C & 3) == 0;      // class rows are 16-byte aligned only then: otherwise element-wise accesses
   const size_t total = (size_t)B * A * cg;
   const float lo = 1e-4f, hi = (float)(1. - 1e-4);
   const int npos = counts[0];
@@ -185,11 +186,18 @@ __global__ __launch_bounds__(256) void focal_fwd_bwd_kernel(const LevelPtrs lp, 
     size_t o = ((size_t)b * nl + (a - lp.off[l])) * C + c4 * 4;
     float label = targets[((size_t)b * A + a) * tstride + 4];
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    const int ne = vec ? 4 : min(4, C - c4 * 4);  // valid classes of this group
     if (label >= 0.f) {
-      f32x4 praw = *reinterpret_cast<const f32x4*>(lp.in[l] + o);
+      f32x4 praw = {0.5f, 0.5f, 0.5f, 0.5f};
+      if (vec) {
+        praw = *reinterpret_cast<const f32x4*>(lp.in[l] + o);
+      } else {
+        for (int e = 0; e < ne; ++e) praw[e] = lp.in[l][o + e];
+      }
       int cls = (int)label - 1;  // -1 for background
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        if (e >= ne) break;
         float p = fminf(fmaxf(praw[e], lo), hi);
         bool inside = (praw[e] >= lo) && (praw[e] <= hi);
         bool t = (c4 * 4 + e) == cls;
@@ -212,7 +220,13 @@ __global__ __launch_bounds__(256) void focal_fwd_bwd_kernel(const LevelPtrs lp, 
         g[e] = inside ? dp * gscale : 0.f;
       }
     }
-    if (lp.grad[l]) *reinterpret_cast<f32x4*>(lp.grad[l] + o) = g;
+    if (lp.grad[l]) {
+      if (vec) {
+        *reinterpret_cast<f32x4*>(lp.grad[l] + o) = g;
+      } else {
+        for (int e = 0; e < ne; ++e) lp.grad[l][o + e] = g[e];
+      }
+    }
   }
   __shared__ float red[4];
   float w = wave_sum(lsum);
@@ -797,7 +811,7 @@ int sacv_focal_loss_fwd_bwd(int nlev, const float* const* cls_in, float* const* 
                             float weight, const int* counts, float* workspace, float* loss_out, int slot,
                             void* stream) {
   SACV_CHECK_ARG(nlev >= 1 && nlev <= MAXL, "focal: nlev");
-  SACV_CHECK_ARG(C % 4 == 0, "focal: num_classes must be a multiple of 4 (got %d)", C);
+  SACV_CHECK_ARG(C >= 1, "focal: num_classes");
   SACV_CHECK_ARG(level_off[nlev] == A, "focal: level offsets do not sum to A");
   SACV_CHECK_ARG(targets && counts && workspace && loss_out, "focal: null pointer");
   LevelPtrs lp;
@@ -810,7 +824,7 @@ int sacv_focal_loss_fwd_bwd(int nlev, const float* const* cls_in, float* const* 
   }
   lp.off[nlev] = level_off[nlev];
   hipStream_t st = (hipStream_t)stream;
-  size_t total = (size_t)B * A * (C / 4);
+  size_t total = (size_t)B * A * ((C + 3) / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > FOCAL_BLOCKS) blocks = FOCAL_BLOCKS;
   hipLaunchKernelGGL(focal_fwd_bwd_kernel, dim3(blocks), dim3(256), 0, st, lp, targets, tstride, B, A, C, alpha,

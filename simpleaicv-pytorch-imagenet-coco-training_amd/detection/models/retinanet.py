@@ -20,10 +20,6 @@ class RetinaNet(HipDetector):
             raise NotImplementedError(f'{backbone_type}: only the ResNet50 backbone is on the MI355X hot path')
         if use_gradient_checkpoint:
             raise NotImplementedError('use_gradient_checkpoint: activations are kept in HBM (288 GB) instead')
-        if num_classes % 4 != 0:
-            # the class scores of an anchor are read and written as 16-byte vectors by the head epilogue, the focal-loss
-            # and the decode kernels (COCO 80 and VOC 20 qualify; Objects365's 365 does not)
-            raise NotImplementedError(f'num_classes={num_classes}: the MI355X path needs num_classes % 4 == 0')
         self.planes, self.num_anchors, self.num_classes = planes, num_anchors, num_classes
         self.use_gradient_checkpoint = use_gradient_checkpoint
         self.backbone = _resnet50_backbone()

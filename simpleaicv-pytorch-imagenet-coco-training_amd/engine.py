@@ -67,8 +67,62 @@ class DetectorEngine:
             self._side = torch.cuda.Stream()  # (the launch stream at high priority: 27.82 -> 27.62 ms; not adopted)
             self._side_events = [torch.cuda.Event() for _ in range(64)]
         self._side_evi, self._side_keep = 0, []
+        # Output convolutions whose channel count is not a multiple of 4 (Objects365: 9 x 365 = 3285 class channels,
+        # FCOS 365): the kernels move channels as 16-byte vectors, so the engine computes with zero-padded SHADOW copies
+        # of the weight / bias (refreshed from the parameters at every forward pass) and shadow gradient buffers (their
+        # first rows are copied into the gradient arena when the head gradients are final); the padded output channels
+        # are stripped before the tensors reach the caller.  self.p / self.g hold the shadows; nothing else changes.
+        self._shadows = []
+        if p and next(iter(p.values())).is_cuda:
+            name = 'clsregcnt_head.cls_out' if fcos else 'cls_head.cls_out'
+            if name + '.weight' in p and p[name + '.weight'].shape[0] % 4 != 0:
+                self._add_shadow(name)
         # (one switch, SACV_WGRAD_STREAM=0, turns the second stream off: A/B runs and the profile session's serial trace)
         self._bias_on_side = self._ds_on_side = True
+
+    def _add_shadow(self, name):
+        if not self._shadows:  # the dicts are shared with the model / arena: the engine edits copies of its own
+            self.p, self.g = dict(self.p), dict(self.g)
+        w, b = self.p[name + '.weight'], self.p[name + '.bias']
+        n = w.shape[0]
+        npad = -(-n // 4) * 4
+        mk = lambda: torch.zeros((npad, w.shape[2], w.shape[3], w.shape[1]), device=w.device,
+                                 dtype=torch.float32).permute(0, 3, 1, 2)  # channels_last storage, like the arena's
+        sw, sgw = mk(), mk()
+        sb = torch.zeros(npad, device=w.device, dtype=torch.float32)
+        sgb = torch.zeros(npad, device=w.device, dtype=torch.float32)
+        self._shadows.append(dict(name=name, n=n, w=w, b=b, gw=self.g[name + '.weight'], gb=self.g[name + '.bias'],
+                                  sw=sw, sb=sb, sgw=sgw, sgb=sgb))
+        self.p[name + '.weight'], self.p[name + '.bias'] = sw, sb
+        self.g[name + '.weight'], self.g[name + '.bias'] = sgw, sgb
+
+    def _shadow_refresh(self):
+        for sh in self._shadows:
+            sh['sw'][:sh['n']].copy_(sh['w'])
+            sh['sb'][:sh['n']].copy_(sh['b'])
+
+    def _shadow_flush(self):
+        """Shadow gradients -> gradient arena (call after the side stream has been joined)."""
+        for sh in self._shadows:
+            sh['gw'].copy_(sh['sgw'][:sh['n']])
+            sh['gb'].copy_(sh['sgb'][:sh['n']])
+
+    def _strip(self, levels, n):
+        """[B,h,w,npad] -> contiguous [B,h,w,n] when an output conv ran with padded channels."""
+        if not levels or levels[0].shape[3] == n:
+            return levels
+        return [t[..., :n].contiguous() for t in levels]
+
+    @staticmethod
+    def _pad_channels(levels, npad):
+        if not levels or levels[0].shape[3] == npad:
+            return levels
+        out = []
+        for t in levels:
+            z = torch.zeros(t.shape[:3] + (npad,), device=t.device, dtype=t.dtype)
+            z[..., :t.shape[3]].copy_(t)
+            out.append(z)
+        return out
 
     def _wgrad(self, dys, xs, dw, cin, kh, kw, stride, pad, **kw_args):
         self._on_side(lambda: ops.conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, **kw_args), list(dys) + list(xs))
@@ -299,6 +353,7 @@ class DetectorEngine:
         """images: logical [B,3,H,W] fp32 (any strides).  Returns (cls_levels, reg_levels)."""
         ctx = {} if keep else None
         self._wino_cache = {}  # Winograd-domain weights are per forward (the optimizer step changes the weights)
+        self._shadow_refresh()
         if keep:
             if self.amp or not self._ds_on_side:
                 self._refresh_dgrad_panels()  # amp: the same launch pair also casts the FORWARD panels
@@ -510,11 +565,13 @@ class DetectorEngine:
 
     def _heads_fwd(self, feats, ctx):
         a, nc = self.num_anchors, self.num_classes
+        n_cls = self.p['cls_head.cls_out.weight'].shape[0]  # a * nc, or its padded shadow's
         if self._use_wino():
-            cls, reg = self._towers_fwd_wino(feats, ctx, a * nc, a * 4)
+            cls, reg = self._towers_fwd_wino(feats, ctx, n_cls, a * 4)
         else:
-            cls = self._tower_fwd(feats, 'cls_head.cls_head', 'cls_head.cls_out', a * nc, CF_SIGMOID, ctx)
+            cls = self._tower_fwd(feats, 'cls_head.cls_head', 'cls_head.cls_out', n_cls, CF_SIGMOID, ctx)
             reg = self._tower_fwd(feats, 'reg_head.reg_head', 'reg_head.reg_out', a * 4, 0, ctx)
+        cls = self._strip(cls, a * nc)
         if ctx is not None:
             ctx['cls_probs'] = cls
             ctx['feat_shapes'] = [tuple(f.shape) for f in feats]
@@ -661,6 +718,7 @@ class DetectorEngine:
             cls = ops.conv_gemm(cls_x, ops.fwd_panel(w), w.shape[0], 3, 3, 1, 1, 0, hw,
                                 bias=p['clsregcnt_head.cls_out.bias'], flags=CF_SIGMOID)
             y8 = ops.conv_gemm(reg_x, ops.fwd_panel(w8), 8, 3, 3, 1, 1, 0, hw, bias=b8)
+        cls = self._strip(cls, self.num_classes)
         regs, ctrs = [], []
         for l, y in enumerate(y8):
             r, c = ops.fcos_split_fwd(y, p['scales'][l:l + 1])
@@ -723,6 +781,7 @@ class DetectorEngine:
         dz_cls = [ops.eltwise(ops.EW_SCALE_SIGMOID_BWD, d.reshape(pr.shape), pr, scalar=grad_scale)
                   for d, pr in zip(dcls_levels, o['cls'])]
         w = p['clsregcnt_head.cls_out.weight']
+        dz_cls = self._pad_channels(dz_cls, w.shape[0])
         vcls = self.ctx['fcos_out_v'][0] if self._use_wino() else None
         self._wino_wgrad(dz_cls, o['cls_x'], vcls, g['clsregcnt_head.cls_out.weight'], w.shape[1])
         self._bias_grad(dz_cls, 'clsregcnt_head.cls_out')
@@ -865,6 +924,7 @@ class DetectorEngine:
         for dprob, pr in zip(dcls_levels, probs):
             d = dprob.reshape(pr.shape)
             dz_cls.append(ops.eltwise(ops.EW_SCALE_SIGMOID_BWD, d, pr, scalar=grad_scale))
+        dz_cls = self._pad_channels(dz_cls, self.p['cls_head.cls_out.weight'].shape[0])
         if grad_scale != 1.0:
             dz_reg = [ops.eltwise(ops.EW_SCALE, d.reshape(d.shape[0], d.shape[1], d.shape[2], a * 4),
                                   scalar=grad_scale) for d in dreg_levels]
@@ -879,8 +939,10 @@ class DetectorEngine:
 
     def _trunk_bwd(self, dfeat, on_stage):
         ctx = self.ctx
-        if on_stage:
+        if on_stage or self._shadows:
             self._side_join()
+            self._shadow_flush()
+        if on_stage:
             on_stage('heads')  # head gradients are final: their all-reduce can start now
         dc3, dc4, dc5 = self._fpn_bwd(dfeat)
         self._backbone_bwd(dc5, dc4, dc3, on_stage)

@@ -17,12 +17,14 @@ from tests.test_scheduler_cpu import collate_samples
 
 
 @pytest.mark.parametrize('kind,tag', [('retina', 'S1'), ('fcos', 'S1'), ('retina', 'S2'), ('fcos', 'S2'),
-                                      ('retina', 'V640'), ('fcos', 'V640'), ('retina', 'O1024')])
+                                      ('retina', 'V640'), ('fcos', 'V640'), ('retina', 'O1024'),
+                                      ('retina', 'C365'), ('fcos', 'C365')])
 def test_full_size_step_against_reference_fixture(golden_dir, kind, tag):
     """loss dict 1e-4 (north-star tolerance), 256 samples of every output level 2e-4, all gradient norms, and the
     full gradients of 8-9 small tensors elementwise (relative L2 and max-abs vs the tensor's scale).  V640 / O1024 are
     the square yolo-style canvases of the VOC (20 classes) and Objects365 recipes (make_golden.py
-    section e2e_other)."""
+    section e2e_other); C365 = Objects365's 365 classes (3285 / 365 class channels, not a multiple of 4: the engine's
+    padded shadow weights) at 256 x 320."""
     from sacv_amd.detection import models, losses
     f = {'S1': 'e2e_s1', 'S2': 'e2e_s2'}.get(tag, 'e2e_other')
     name = f'{kind}_{tag}'
@@ -71,8 +73,11 @@ def test_full_size_step_against_reference_fixture(golden_dir, kind, tag):
         mx = np.abs(got - want).max() / (np.abs(want).max() + 1e-30)
         print(f'  {pname}: rel-L2 {l2:.2e} max-abs/scale {mx:.2e}')
         # the stem's BatchNorm gradients sit behind the whole backward pass (53 batch-statistics layers): the
-        # reference's own fp32 arithmetic is percents away from fp64 there (tests/test_gpu_e2e.py); 5e-2 elementwise
-        if not (l2 <= 5e-2 and mx <= 5e-2):
+        # reference's own fp32 arithmetic is percents away from fp64 there (tests/test_gpu_e2e.py); 5e-2 elementwise.
+        # C365 runs on the 256 x 320 canvas: layer4 has 2 x 8 x 10 = 160 values per channel, a single element of its
+        # BatchNorm gradient moves by up to 9 % of the tensor's scale between two fp32 summation orders (measured;
+        # rel-L2 stays below 1e-2): the max-abs bound is 1.5e-1 there
+        if not (l2 <= 5e-2 and mx <= (1.5e-1 if tag == 'C365' else 5e-2)):
             bad.append((pname, l2, mx))
         checked += 1
     assert checked >= 8 and not bad, bad

@@ -100,3 +100,59 @@ def test_classifier_and_mae_side_streams_change_no_bit():
         torch.cuda.synchronize()
         res[side] = (net.arena.grads.clone(), net.arena.params.clone())
     assert torch.equal(res[False][0], res[True][0]) and torch.equal(res[False][1], res[True][1])
+
+
+@pytest.mark.parametrize('kind', ['retina', 'fcos'])
+def test_class_count_not_a_multiple_of_four(kind):
+    """Objects365's 365 classes (3285 / 365 class channels): the engine computes with zero-padded shadow weights and
+    strips the outputs.  The trainer's fast path must produce the gradients of the class-level (autograd) path bit for
+    bit, the decoder must read 365-wide class rows, and the padded channels must never reach the caller."""
+    from sacv_amd.detection import models, losses, decode
+    from sacv_amd.train import DetectionTrainer
+    from oracle import decode as odecode
+    fcos = kind == 'fcos'
+    nc, H, W = 365, 96, 128
+    sd = omodel.init_retinanet_state(0, num_classes=nc, fcos=fcos)
+    name = 'resnet50_fcos' if fcos else 'resnet50_retinanet'
+    x = torch.tensor(synth.images(7, 2, H, W)).cuda()
+    ann = synth.annotations(9, 2, H, W, boxes_per_image=5)
+    ann[..., 4] = (ann[..., 4] * 4 + 1) % nc * (ann[..., 4] >= 0) - (ann[..., 4] < 0)  # spread labels over 365 classes
+    ann = torch.tensor(ann).cuda()
+    crit = losses.__dict__['FCOSLoss' if fcos else 'RetinaLoss']()
+    # class-level path
+    net = models.__dict__[name](num_classes=nc)
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    outs = net(x)
+    assert tuple(outs[0][0].shape[3:]) == ((nc,) if fcos else (9, nc)) and outs[0][0].is_contiguous()
+    ld = crit(outs, ann)
+    sum(ld.values()).backward()
+    ref = net.arena.grads.clone()
+    w = 'clsregcnt_head.cls_out.weight' if fcos else 'cls_head.cls_out.weight'
+    assert tuple(dict(net.named_parameters())[w].shape) == ((nc, 256, 3, 3) if fcos else (9 * nc, 256, 3, 3))
+    assert float(dict(net.named_parameters())[w].grad.abs().sum()) > 0
+    # trainer fast path from the same state (lr 0: parameters stay, gradients comparable)
+    net2 = models.__dict__[name](num_classes=nc)
+    net2.load_state_dict(sd)
+    net2 = net2.cuda().train()
+    tr = DetectionTrainer(net2, crit, lr=0.0, weight_decay=0.0)
+    out = tr.step(x, ann)
+    torch.cuda.synchronize()
+    for k in ld:
+        assert float(out[k]) == float(ld[k]), k
+    assert torch.equal(net2.arena.grads, ref)
+    # decoder on 365-wide class rows against the oracle
+    net.eval()
+    with torch.no_grad():
+        preds = net(x)
+    if fcos:
+        dec = decode.__dict__['FCOSDecoder'](min_score_threshold=0.005)
+        want = odecode.fcos_decode(*[[t.cpu().numpy() for t in grp] for grp in preds], min_score_threshold=0.005)
+    else:
+        dec = decode.__dict__['RetinaDecoder'](min_score_threshold=0.005)
+        want = odecode.retina_decode(*[[t.cpu().numpy() for t in grp] for grp in preds], min_score_threshold=0.005)
+    got = dec(preds)
+    import numpy as np
+    assert (want[0] > 0).sum() > 10
+    for g_, w_ in zip(got, want):
+        assert np.array_equal(g_, w_)

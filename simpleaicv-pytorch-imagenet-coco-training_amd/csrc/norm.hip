@@ -218,17 +218,21 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const T* __r
   auto accum_rows = [&](int r0, int step, int cv, const float (&mu)[V], const float (&is)[V], float (&s)[V],
                         float (&q)[V]) {
     int r = r0;
-    for (; r + 3 * step < r_end; r += 4 * step) {
-      float g[4][V], v[4][V], zz[4][V];
+#ifndef SACV_BN_AHEAD
+#define SACV_BN_AHEAD 4  // rows requested before the first is folded (tuning builds: scripts/build_variant.sh)
+#endif
+    constexpr int AH = SACV_BN_AHEAD;
+    for (; r + (AH - 1) * step < r_end; r += AH * step) {
+      float g[AH][V], v[AH][V], zz[AH][V];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < AH; ++u) {
         const size_t o = (size_t)(r + u * step) * C + cv * V;
         VecIO<T>::load(dz + o, g[u]);
         VecIO<T>::load(y + o, v[u]);
         if (zmask) VecIO<T>::load(zmask + o, zz[u]);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) fold(g[u], v[u], zz[u], mu, is, s, q);
+      for (int u = 0; u < AH; ++u) fold(g[u], v[u], zz[u], mu, is, s, q);
     }
     for (; r < r_end; r += step) {
       float g[V], v[V], zz[V];
@@ -359,8 +363,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+#ifndef SACV_BN_BLOCKS
+#define SACV_BN_BLOCKS 512  // tuning builds only (scripts/build_variant.sh)
+#endif
 static int pick_blocks(int R, int* rows_per_block) {
-  int nb = R < 512 ? (R + 7) / 8 : 512;
+  int nb = R < SACV_BN_BLOCKS ? (R + 7) / 8 : SACV_BN_BLOCKS;
   if (nb < 1) nb = 1;
   int rpb = (R + nb - 1) / nb;
   nb = (R + rpb - 1) / rpb;

@@ -767,6 +767,22 @@ static int conv2d_gemm_bf16_impl(const void* src, void* dst, int Nb, int Hs, int
   if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && !ext && remap_s == 0 && Hs == Hd && Ws == Wd &&
       sacv_internal_gemm_nt_bf16_supported(M, N, Cs))
     return sacv_internal_gemm_nt_bf16(src, w, dst, bias, residual, stats, M, N, Cs, flags, stream);
+  // 3x3 / stride 1 / pad 1 with 64 output channels (layer1 of the classifier): the halo-resident kernel reads the input
+  // once per tile instead of once per tap (conv3x3_halo_bf16.hip).  Its statistics rows cover 256 padded positions
+  // each -- fewer rows than the 128-row granule the caller allocated: the rest is zeroed for the finalize pass.
+  if (KH == 3 && KW == 3 && stride == 1 && pad == 1 && !ext && remap_s == 0 && Hs == Hd && Ws == Wd && !residual &&
+      (flags & ~CF_STATS) == 0 && sacv_internal_conv3x3_halo_bf16_supported(Nb, Hs, Ws, Cs, N)) {
+    if (flags & CF_STATS) {
+      const int used = sacv_internal_conv3x3_halo_bf16_stats_rows(Nb, Hs, Ws);
+      const int rows = (int)((M + 127) / 128);
+      SACV_CHECK_ARG(used <= rows, "conv2d_gemm_bf16: statistics buffer smaller than the halo kernel's tiles");
+      if (rows > used) {
+        hipError_t e = hipMemsetAsync(stats + (size_t)used * 2 * N, 0, (size_t)(rows - used) * 2 * N * sizeof(float), st);
+        SACV_CHECK_ARG(e == hipSuccess, "conv2d_gemm_bf16: hipMemsetAsync failed: %s", hipGetErrorString(e));
+      }
+    }
+    return sacv_internal_conv3x3_halo_bf16(src, dst, Nb, Hs, Ws, w, Cs, N, mode, flags, stats, stream);
+  }
   if (N <= 64)  // three workgroups per CU on the unpadded, swizzled 48 KB LDS image (29.05 -> 28.8 ms on the bf16 classifier;
                 // for wider outputs the two-per-CU 128 x 128 tile stays ahead)
     return mode == 0 ? launch_nt_h<128, 64, 0, 3, true>(a, st) : launch_nt_h<128, 64, 1, 3, true>(a, st);

@@ -39,6 +39,13 @@ int sacv_internal_gemm_nt_bf16_supported(long long M, int N, int K);
 int sacv_internal_gemm_nt_bf16(const void* A, const void* B, void* C, const float* bias, const float* residual,
                                float* stats, long long M, int N, int K, int flags, void* stream);
 
+// internal: halo-resident bf16 3x3 / stride 1 / pad 1 convolution with 64 output channels (conv3x3_halo_bf16.hip),
+// used by sacv_conv2d_gemm_bf16 for the layer1-class problems; mode 0 forward, 1 data gradient; flags: CF_STATS only
+int sacv_internal_conv3x3_halo_bf16_supported(int Nb, int H, int W, int Cs, int N);
+int sacv_internal_conv3x3_halo_bf16_stats_rows(int Nb, int H, int W);
+int sacv_internal_conv3x3_halo_bf16(const void* src, void* dst, int Nb, int H, int W, const void* w, int Cs, int N,
+                                    int mode, int flags, float* stats, void* stream);
+
 static inline int sacv_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -233,3 +233,36 @@ def test_resnet50_amp_trainer_bs256():
         torch.cuda.empty_cache()
     print('bs256 losses fp32', out[False], 'bf16', out[True])
     assert abs(out[True][0] - out[False][0]) <= 2e-2 * out[False][0]
+
+
+@pytest.mark.parametrize('n,h,w,cin', [(40, 56, 56, 64), (70, 28, 61, 128), (600, 14, 14, 64)])
+def test_halo_resident_3x3_kernel(n, h, w, cin):
+    """3x3 / stride 1 / pad 1 problems with 64 output channels and >= 512 tiles of 256 padded positions go to
+    conv3x3_halo_bf16_kernel (csrc/conv3x3_halo_bf16.hip): forward with the fused BatchNorm statistics and the data
+    gradient against torch fp32 on the bf16-rounded operands (the bf16 output tolerance of this file), one and two
+    64-channel chunks, the widest image the 384-row LDS image takes (W = 61), image / batch edges (ragged last tile)."""
+    from sacv_amd import ops
+    from sacv_amd._lib import lib
+    cout = 64
+    assert lib.sacv_abi_version() >= 2
+    x = q(rnd(21, n, cin, h, w))
+    wt = q(rnd(22, cout, cin, 3, 3, std=(2.0 / (cin * 9))**0.5))
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wt, None, 1, 1)
+    xd = nhwc(x).cuda().to(BF)
+    wp = wt.permute(0, 2, 3, 1).contiguous().view(cout, -1).cuda().to(BF)
+    (y,), st = ops.conv_gemm([xd], wp, cout, 3, 3, 1, 1, 0, [(h, w)], stats=True)
+    close_bf16(y.permute(0, 3, 1, 2), y_ref.detach(), 'forward')
+    yf = y.float().view(-1, cout)
+    # the statistics rows beyond the kernel's tiles are zero, the used ones sum to the column sums of the ROUNDED output
+    tiles = -(-(n * (h + 2) * (w + 2)) // 256)
+    assert st.shape[0] == -(-(n * h * w) // 128) and tiles < st.shape[0] and not bool(st[tiles:].any())
+    torch.testing.assert_close(st[:, 0].sum(0).cpu(), yf.sum(0).cpu(), rtol=1e-4, atol=2e-2)
+    torch.testing.assert_close(st[:, 1].sum(0).cpu(), (yf * yf).sum(0).cpu(), rtol=1e-4, atol=2e-2)
+    # data gradient: dy has 64 channels, dx has `cin` -- the kernel needs 64 OUTPUT channels, so cin == 64 here
+    if cin == 64:
+        dy = q(rnd(23, *y_ref.shape))
+        y_ref.backward(dy)
+        wd = wt.permute(1, 2, 3, 0).contiguous().view(cin, -1).cuda().to(BF)      # [Cin][taps*Cout]
+        dx = ops.conv_gemm([nhwc(dy).cuda().to(BF)], wd, cin, 3, 3, 1, 1, 1, [(h, w)])[0]
+        close_bf16(dx.permute(0, 3, 1, 2), xr.grad, 'dgrad')

@@ -25,12 +25,19 @@
 //     output (taps outer, channels inner, 16 per MFMA) equals conv_nt_bf16_kernel's: results are bit-identical.
 // Measured (scripts/bench_halo.py, layer1 shape, random data): 98-105 us against 138-145 us for conv_nt_bf16_kernel
 // (565-605 vs 407-428 TFLOP/s; 0.25-0.26 vs 0.18 of the HBM roofline); in the classifier step 127 -> 98 us per launch.
-// What still bounds it: a tile's phases (48 KB image load, 144 MFMAs per wave, LDS-staged epilogue) run one after the
-// other inside a workgroup and the two workgroups of a CU move in step (a start-up stagger of half a tile changed
-// nothing); per-row position decoding by division cost 7 us and was replaced by incremental decoding.  Next: the
-// transposed product (channels in registers, positions in lanes) so that the epilogue stores straight from the
-// accumulators, and a second image buffer to load tile t + 1 under tile t's taps.
-// Dispatch: sacv_conv2d_gemm_bf16 asks sacv_internal_conv3x3_halo_bf16_supported first; nothing changes at the C ABI.
+// What bounds it (ablation builds, layer1 shape, 98 us): without the epilogue 59 us (1 005 TFLOP/s), without the image
+// loads 88 us, without the MFMAs 78 us -- the epilogue is 40 % of the launch.  Two other epilogues were built and
+// measured against this one: (a) the TRANSPOSED product (weights as the first MFMA operand: a lane then holds four
+// consecutive channels of one position) stored straight from the accumulators, the next tile's image requested before
+// the epilogue and the BatchNorm sums kept in registers across tiles: 111-115 us -- a store instruction then writes 16-
+// byte pieces of 32 different lines; (b) the same with a per-wave 4 KB LDS transposition (16 ds_write_b64 + 8
+// ds_read_b128 per lane, no workgroup barrier, whole 128-byte rows per store): 92-100 us in the microbenchmark, equal
+// to this version in the classifier step (25.72 vs 25.67 ms).  What the three share is the wait for the stores: on
+// gfx950 loads and stores retire through the ONE vmcnt counter and may pass each other, so the counted waits of the
+// next tile's tap ring cannot skip the older stores and every tile ends up waiting for its HBM write acknowledgements.
+// The form that avoids it keeps the weight panel resident in LDS (no counted waits inside a tile at all) at one
+// workgroup per CU: not built.  (Also measured: per-row position decoding by division cost 7 us -> incremental; a
+// start-up stagger of the second workgroup of each CU by half a tile: no effect; the nine taps inline: -5 us.)
 #include "sacv_common.h"
 #include <mutex>
 

@@ -152,12 +152,12 @@ class DetectorEngine:
         s.wait_event(ev)
         # scratch buffers of their own: nothing the launch stream's kernels are using.  (A module-level switch: the
         # engines enqueue from ONE host thread, like the reference's training loop.)
-        ops.WS_SUFFIX = '@side'
+        prev_suffix, ops.WS_SUFFIX = ops.WS_SUFFIX, '@side'  # (restored, not reset: a side-stream branch may nest)
         try:
             with torch.cuda.stream(s):
                 launch()
         finally:
-            ops.WS_SUFFIX = ''
+            ops.WS_SUFFIX = prev_suffix
         # The tensors the side stream reads stay referenced until the launch stream has joined the side stream
         # (_side_join): they are then freed in the launch stream's order, behind the join, so the caching allocator can
         # recycle them for launch-stream work without any cross-stream bookkeeping (no Tensor.record_stream).

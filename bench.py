@@ -299,15 +299,100 @@ def bench_mae(args, rank, world, group, ops, synth):
         dist.destroy_process_group()
 
 
+def bench_decode(args, rank, world, ops, synth):
+    """Secondary metric: decode + NMS latency per image.  One "step" = RetinaDecoder / FCOSDecoder on the
+    head outputs of one evaluation batch [2, 800x1333] resident in HBM -> [B,100] scores / classes / boxes on the device
+    (sacv_decode_topk_nms / sacv_decode_topk_soft_nms: score scan + argmax, exact top-1000, box decode, NMS).  The ranks
+    decode independent batches (no collective on this path)."""
+    import torch
+    import torch.distributed as dist
+    from sacv_amd.detection import decode
+    fcos = args.model == 'fcos_decode'
+    host = synth.head_outputs(100 + rank, BATCH, H, W, fcos=fcos)
+    preds = [[torch.tensor(x).cuda() for x in grp] for grp in host]
+    name = 'FCOSDecoder' if fcos else 'RetinaDecoder'
+    kw = {}
+    if os.environ.get('SACV_DECODE_MIN_SCORE'):  # stress case: 0 = every prediction is a candidate (dense lists)
+        kw['min_score_threshold'] = float(os.environ['SACV_DECODE_MIN_SCORE'])
+    dec = decode.__dict__[name](nms_type=args.nms_type, nms_threshold=0.6 if fcos else 0.5, **kw)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = dec.device_call(preds)
+    sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(args.steps):
+        out = dec.device_call(preds)
+        marks[i + 1].record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    ms_median = per_step[len(per_step) // 2]
+    if world > 1:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    kept = int((out[1] >= 0).sum())
+    # algorithmic bytes of the call: every class score and box regression (and centerness) read once (the [B,100] results
+    # are noise beside them).  The call is a chain of launches (scan, radix select + sort, NMS): the rate below is over the
+    # WHOLE call on the launch stream, so it prices the latency-bound selection and NMS stages against the HBM peak too;
+    # the per-kernel split is in profiles/ (rocprofv3 --kernel-trace of this command).
+    nbytes = float(sum(x.numel() * 4 for grp in preds for x in grp))
+    gbs = nbytes / (ms_median * 1e-3) / 1e9
+    roofline = dict(kernel='decode_kernel + select_sort_kernel + ' + ('soft_nms_kernel' if 'soft' in args.nms_type else 'nms_kernel')
+                           + ' (one C-ABI call; HIP events around the call on the launch stream, median)',
+                    bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4),
+                    traffic=None, algorithmic_mb_per_launch=round(nbytes / 1e6, 1), avg_launch_ms=round(ms_median, 4))
+    line = {
+        'metric': f'decode+NMS latency per image, {name} {args.nms_type}, {H}x{W} bs={BATCH}/GPU (secondary, SURVEY 8d)',
+        'value': round(elapsed / args.steps * 1e3 / BATCH, 4), 'unit': 'ms/image', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+        'ms_per_step_median': round(ms_median, 4), 'higher_is_better': False, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{name}(nms_type={args.nms_type}) on the head outputs of one batch [{BATCH},3,{H},{W}]: '
+                               f'{sum(x[0].numel() // x.shape[-1] for x in preds[0])} predictions x 80 classes per '
+                               'image, 1 in 29 above the 0.05 threshold (6 9xx candidates per image), top-1000 -> NMS -> '
+                               f'100; outputs stay on the device; {kept} detections kept in the batch',
+                   'global_batch': world * BATCH, 'parallelism': f'replicas{world}'},
+        'roofline': roofline}
+    if rank == 0 and not args.no_cpu_baseline:
+        import statistics
+        from oracle import decode as odecode  # the checker, timed as the CPU baseline
+        fn = odecode.fcos_decode if fcos else odecode.retina_decode
+        times = []
+        for it in range(4):
+            c0 = time.perf_counter()
+            ref = fn(*host, nms_type=args.nms_type, nms_threshold=0.6 if fcos else 0.5, **kw)
+            times.append(time.perf_counter() - c0)
+        med = statistics.median(times[1:])
+        same = all(bool((a.cpu().numpy() == b).all()) for a, b in zip(out, ref))
+        line['cpu_baseline'] = dict(value=round(med * 1e3 / BATCH, 2), unit='ms/image', cores=1, kind='port',
+                                    sample=f'median of 3 runs (after 1 warm-up) of oracle/decode.py on the same batch '
+                                           f'(NumPy, one thread); GPU result identical to it: {same}')
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--model', default='retinanet', choices=['retinanet', 'fcos', 'resnet50_cls', 'vit_mae'],
+    ap.add_argument('--model', default='retinanet', choices=['retinanet', 'fcos', 'resnet50_cls', 'vit_mae', 'retinanet_decode', 'fcos_decode'],
                     help='retinanet = the headline metric; fcos = secondary workload (BASELINE config 4); '
                          'resnet50_cls = ResNet50 ImageNet classification, bs 256/GPU, 224x224 (SURVEY.md 8f-1)')
+    ap.add_argument('--nms-type', default='python_nms',
+                    help='*_decode workloads: python_nms | diou_python_nms | torch_nms | soft_nms | soft_nms_gaussian')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--timer-every', type=int, default=20,
                     help='per-launch HIP events (the roofline measurement) on every Nth timed step.  An instrumented '
@@ -372,6 +457,8 @@ def main():
         return bench_classification(args, rank, world, group, ops, synth)
     if args.model == 'vit_mae':
         return bench_mae(args, rank, world, group, ops, synth)
+    if args.model.endswith('_decode'):
+        return bench_decode(args, rank, world, ops, synth)
     if args.model == 'fcos':
         net = models.__dict__['resnet50_fcos'](backbone_pretrained_path='', num_classes=80).cuda().train()
         crit = losses.__dict__['FCOSLoss']()

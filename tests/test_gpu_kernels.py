@@ -461,6 +461,54 @@ def test_retina_decoder_soft_nms(ops, tag, nms_type):
     assert np.all(np.diff(np.where(s > 0, s, 0), axis=1) <= 0)  # picks come out in descending decayed score
 
 
+@pytest.mark.parametrize('num_classes', [80, 160, 81, 8])
+def test_decoder_selection_limits(ops, num_classes):
+    """The selection stage on its own terms (no suppression: nms_threshold above any IoU, max_object_num = topn = 1000 so
+    the whole sorted top-1000 comes out): thousands of EQUAL scores straddling the top-1000 cut (the radix select must walk
+    past the score bits into the index bits; ties = ascending anchor index, the oracle's stable order), fewer candidates
+    than topn, exactly topn, and the three scan kernels -- 128-prediction LDS tiles (80, 8 classes), 32-prediction tiles
+    (160) and the scalar one (81: rows that are not 16-byte multiples).  Bit-exact."""
+    from sacv_amd.detection import decode
+    H, W = gi.SHAPES['MID']
+    B = 3
+    fs = synth.feature_sizes(H, W)
+    rng = np.random.default_rng(5 + num_classes)
+    cls = [(synth.uniform(70 + l, (B, fh, fw, 9, num_classes)) * 0.04).astype(np.float32)
+           for l, (fw, fh) in enumerate(fs)]
+    reg = [synth.normal(80 + l, (B, fh, fw, 9, 4), std=0.3) for l, (fw, fh) in enumerate(fs)]
+    n_l = [fw * fh * 9 for fw, fh in fs]
+    total = sum(n_l)
+
+    def poke(b, idx, val, klass):
+        for l, n in enumerate(n_l):
+            if idx < n:
+                cls[l].reshape(B, n, num_classes)[b, idx, klass] = val
+                return
+            idx -= n
+    # image 0: 400 distinct high scores + 2500 anchors at exactly 0.5 (the cut falls inside the tie) + 300 at exactly 0.25
+    hot = rng.permutation(total)[:3200]
+    for q, a in enumerate(hot[:400]):
+        poke(0, int(a), np.float32(0.6 + 0.39 * q / 400.0), int(a) % num_classes)
+    for a in hot[400:2900]:
+        poke(0, int(a), np.float32(0.5), (int(a) * 7) % num_classes)
+    for a in hot[2900:]:
+        poke(0, int(a), np.float32(0.25), 3)
+    # image 1: 37 candidates; two classes of one prediction share the maximum (first index wins)
+    for q, a in enumerate(hot[:37]):
+        poke(1, int(a), np.float32(0.3 + 0.01 * q), 5)
+    poke(1, int(hot[0]), np.float32(0.3), 2)
+    # image 2: exactly 1000 candidates, all equal
+    for a in hot[:1000]:
+        poke(2, int(a), np.float32(0.125), int(a) % num_classes)
+    dec = decode.__dict__['RetinaDecoder'](nms_type='python_nms', nms_threshold=1.5, max_object_num=1000)
+    s, c, b = dec([[torch.tensor(x).cuda() for x in cls], [torch.tensor(x).cuda() for x in reg]])
+    rs, rc, rb = odecode.retina_decode(cls, reg, nms_type='python_nms', nms_threshold=1.5, max_object_num=1000)
+    assert (rs[0] == 0.5).sum() == 600 and (rs[0] >= 0).sum() == 1000 and (rs[1] >= 0).sum() == 37
+    assert (rs[2] == 0.125).sum() == 1000
+    assert rc[1][rs[1] == np.float32(0.3)][0] == 2
+    assert np.array_equal(s, rs) and np.array_equal(c, rc) and np.array_equal(b, rb)
+
+
 def test_fcos_decoder_soft_nms_and_edge_cases(ops):
     """FCOS front end + Soft-NMS; an image without any score above the threshold; max_object_num larger than the
     number of survivors; a prune level that removes everything a decay touches (== hard suppression at >= thr)."""

@@ -487,8 +487,18 @@ __global__ __launch_bounds__(1024) void nms_mask_kernel(const float* __restrict_
   if (lane == 0) *out = bits;
 }
 
-// The greedy pass, one workgroup per image: the image's mask rows are staged into LDS (128 KB), then a single wave walks
-// the boxes in score order (lane w owns word w of the "removed" bitmap) until max_obj boxes are kept.
+// The greedy pass, one workgroup per image: the image's mask rows are staged into LDS (128 KB, 16-byte loads, all of a
+// thread's requests in flight at once), then a single wave walks the boxes in score order, 64 at a time: the block's
+// "removed" word and its 64 diagonal words (lane i: who box i suppresses inside the block) are wave-uniform bit sets, so
+// the walk visits only the boxes that are KEPT (find-first-set; scalar arithmetic), and the kept boxes' rows are OR-ed
+// into the later blocks' removed words (lane w owns word w) before the next block starts.  Same result as the
+// one-box-at-a-time loop of DetNMSMethod (decode.py:45-102); stops at max_obj kept boxes.
+__device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+  return ((u64)hi << 32) | lo;
+}
+
 __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ s_scores,
                                                     const float* __restrict__ s_classes,
                                                     const float* __restrict__ s_boxes,
@@ -502,23 +512,52 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ s_s
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n = s_count[b];
   const int nwords = (n + 63) >> 6;
-  const u64* gm = gmask + (size_t)b * TOPN_MAX * 16;
-  for (int t = tid; t < n * 16; t += 1024)
-    if ((t & 15) < nwords) mask[t] = gm[t];
+  {
+    // rows [0, n) x 16 words = n * 8 16-byte pieces, <= 8 per thread.  (Words >= nwords of a row were never written by
+    // nms_mask_kernel and are never read below.)
+    const uint4* g4 = reinterpret_cast<const uint4*>(gmask + (size_t)b * TOPN_MAX * 16);
+    uint4* m4 = reinterpret_cast<uint4*>(mask);
+    uint4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (tid + u * 1024 < n * 8) v[u] = g4[tid + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (tid + u * 1024 < n * 8) m4[tid + u * 1024] = v[u];
+  }
   __syncthreads();
   if (tid < 64) {
+    const int lane = tid;
     u64 removed = 0ull;  // lane w (< nwords) owns word w of the removed bitmap
     int nk = 0;
-    for (int i = 0; i < n; ++i) {
-      u64 r = __shfl(removed, i >> 6, 64);
-      if (!((r >> (i & 63)) & 1ull)) {
-        if (tid == 0) keep[nk] = i;
+    bool full = false;
+    for (int blk = 0; blk < nwords && !full; ++blk) {
+      const int cnt = min(64, n - blk * 64);
+      const u64 vmask = cnt == 64 ? ~0ull : ((1ull << cnt) - 1ull);
+      u64 alive = ~readlane_u64(removed, blk) & vmask;
+      const u64 diag = (lane < cnt) ? mask[(size_t)(blk * 64 + lane) * 16 + blk] : 0ull;
+      u64 kept = 0ull;
+      while (alive != 0ull) {
+        const int i = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)alive) - 1);
+        kept |= 1ull << i;
+        if (lane == 0) keep[nk] = blk * 64 + i;
         ++nk;
-        if (nk >= max_obj) break;
-        if (tid < nwords) removed |= mask[(size_t)i * 16 + tid];
+        if (nk >= max_obj) {
+          full = true;
+          break;
+        }
+        alive &= ~(1ull << i);
+        alive &= ~readlane_u64(diag, i);
+      }
+      if (!full && blk + 1 < nwords) {
+        while (kept != 0ull) {
+          const int i = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)kept) - 1);
+          kept &= kept - 1ull;
+          if (lane < nwords) removed |= mask[(size_t)(blk * 64 + i) * 16 + lane];
+        }
       }
     }
-    if (tid == 0) nkeep_p[0] = nk;
+    if (lane == 0) nkeep_p[0] = nk;
   }
   __syncthreads();
   const int nk = nkeep_p[0];

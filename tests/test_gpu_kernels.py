@@ -509,6 +509,35 @@ def test_decoder_selection_limits(ops, num_classes):
     assert np.array_equal(s, rs) and np.array_equal(c, rc) and np.array_equal(b, rb)
 
 
+@pytest.mark.parametrize('nms_type', ['python_nms', 'diou_python_nms', 'torch_nms', 'soft_nms'])
+def test_decoder_dense_suppression(ops, nms_type):
+    """Crowded scenes: every anchor of a 14 x 14 patch of P3 (and a 5 x 5 patch of P4) is a candidate, so the 1000 selected
+    boxes suppress each other across all sixteen 64-box blocks of the mask, and max_object_num = 1000 makes the greedy walk
+    visit every block (the default 100 stops in the first ones).  Bit-exact vs the oracle, all suppression rules."""
+    from sacv_amd.detection import decode
+    H, W = gi.SHAPES['MID']
+    B = 2
+    fs = synth.feature_sizes(H, W)
+    cls = [(synth.uniform(170 + l, (B, fh, fw, 9, 80)) * 0.04).astype(np.float32) for l, (fw, fh) in enumerate(fs)]
+    reg = [synth.normal(180 + l, (B, fh, fw, 9, 4), std=0.2) for l, (fw, fh) in enumerate(fs)]
+    q = 0
+    for b in range(B):
+        for l, (y0, x0, side) in enumerate([(5 + b, 7, 14), (3, 4 + b, 5)]):
+            for y in range(y0, y0 + side):
+                for x in range(x0, x0 + side):
+                    for a in range(9):
+                        q += 1
+                        cls[l][b, y, x, a, (q * 7) % 80] = np.float32(0.06 + 0.9 * ((q * 7919) % 100003) / 100003.0)
+    for M in (1000, 100):
+        dec = decode.__dict__['RetinaDecoder'](nms_type=nms_type, nms_threshold=0.5, max_object_num=M)
+        s, c, b = dec([[torch.tensor(x).cuda() for x in cls], [torch.tensor(x).cuda() for x in reg]])
+        rs, rc, rb = odecode.retina_decode(cls, reg, nms_type=nms_type, nms_threshold=0.5, max_object_num=M)
+        kept = (rs >= 0).sum(axis=1)
+        assert np.array_equal(c, rc) and np.array_equal(b, rb) and np.array_equal(s, rs), (nms_type, M)
+        if nms_type != 'soft_nms':
+            assert kept.max() < 600 and kept.min() > 20, kept  # real suppression, beyond the first blocks
+
+
 def test_fcos_decoder_soft_nms_and_edge_cases(ops):
     """FCOS front end + Soft-NMS; an image without any score above the threshold; max_object_num larger than the
     number of survivors; a prune level that removes everything a decay touches (== hard suppression at >= thr)."""

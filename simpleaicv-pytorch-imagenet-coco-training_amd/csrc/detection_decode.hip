@@ -1,6 +1,8 @@
-// Device-side detection postprocess: per-anchor class argmax + box decode, exact top-n radix
-// select, LDS bitonic sort by score, bit-mask hard NMS with a single-wave greedy scan, pad to
-// max_object_num.  Replaces the host NumPy path of simpleAICV/detection/decode.py:
+// Device-side detection postprocess, four launches per call: (1) score scan at HBM rate -- per prediction the class
+// argmax, threshold, one 64-bit candidate key into atomic-free per-workgroup segments; (2) per image the exact top-n by
+// radix select, bitonic sort, and the box decode of the survivors only; (3) the suppression bit-mask over the whole
+// chip; (4) the greedy walk of hard NMS (or the batched Soft-NMS loop), padded to max_object_num.
+// Replaces the host NumPy path of simpleAICV/detection/decode.py:
 //   RetinaDecoder.__call__ :201-249, snap_txtytwth_to_x1y1x2y2 :251-271 (int32 truncation),
 //   FCOSDecoder :293-364, DecodeMethod.__call__ :121-172, DetNMSMethod python_nms /
 //   diou_python_nms :45-102 (class-agnostic, area = max(w*h,0), union clamped at 1e-4); torch_nms :39-43 =

@@ -38,8 +38,9 @@ class FCOS(HipDetector):
         super().__init__()
         if backbone_type != 'resnet50backbone':
             raise NotImplementedError(f'{backbone_type}: only the ResNet50 backbone is on the MI355X hot path')
-        if use_gradient_checkpoint:
-            raise NotImplementedError('use_gradient_checkpoint: activations are kept in HBM (288 GB) instead')
+        # use_gradient_checkpoint (torch.utils.checkpoint in the reference, retinanet.py:64-67, fcos.py likewise) trades
+        # memory for a second forward pass and leaves every result unchanged; here the activations of the 2 x 800x1333
+        # step (a few GB of 288) stay in HBM, so the flag is accepted and has nothing to switch
         self.planes, self.num_classes = planes, num_classes
         self.use_gradient_checkpoint = use_gradient_checkpoint
         self.backbone = _resnet50_backbone()

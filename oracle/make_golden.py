@@ -297,11 +297,12 @@ def sec_decode(ref):
     print('decode ok', meta)
 
 
-def _e2e(ref, name, H, W, fcos, box_loss_type='SmoothL1', ann_seed=3, num_classes=80):
+def _e2e(ref, name, H, W, fcos, box_loss_type='SmoothL1', ann_seed=3, num_classes=80, resnet='resnet50'):
     models, losses, decode = ref
     torch.manual_seed(0)
-    net = models.__dict__['resnet50_fcos' if fcos else 'resnet50_retinanet'](num_classes=num_classes)
-    net.load_state_dict(omodel.init_retinanet_state(0, num_classes=num_classes, fcos=fcos), strict=True)
+    net = models.__dict__[resnet + ('_fcos' if fcos else '_retinanet')](num_classes=num_classes)
+    net.load_state_dict(omodel.init_retinanet_state(0, num_classes=num_classes, fcos=fcos,
+                                                    backbone=resnet + 'backbone'), strict=True)
     net.train()
     crit = losses.__dict__['FCOSLoss']() if fcos else losses.__dict__['RetinaLoss'](box_loss_type=box_loss_type)
     x = torch.tensor(synth.images(5, 2, H, W))
@@ -325,13 +326,15 @@ def _e2e(ref, name, H, W, fcos, box_loss_type='SmoothL1', ann_seed=3, num_classe
     # a few full small gradients and the BN running stats after one training forward
     head = (('clsregcnt_head.cls_out.bias', 'clsregcnt_head.reg_out.bias', 'scales') if fcos else
             ('cls_head.cls_out.bias', 'reg_head.reg_out.bias'))
+    block, layers = omodel.BACKBONES[resnet + 'backbone']
+    last = 'conv3' if block == 'Bottleneck' else 'conv2'  # the last conv of a residual block
     for k in ('backbone.conv1.layer.1.weight', 'backbone.layer1.0.conv1.layer.1.bias', 'fpn.P5_1.bias',
-              'backbone.layer4.2.conv3.layer.1.weight', 'backbone.layer1.0.conv1.layer.0.weight',
+              f'backbone.layer4.{layers[3] - 1}.{last}.layer.1.weight', 'backbone.layer1.0.conv1.layer.0.weight',
               'backbone.layer3.0.downsample_conv.layer.1.bias') + head:
         arrs[f'{name}_grad_{k}'] = dict(net.named_parameters())[k].grad.numpy()
     sd = net.state_dict()
     for k in ('backbone.conv1.layer.1.running_mean', 'backbone.conv1.layer.1.running_var',
-              'backbone.layer3.5.conv3.layer.1.running_var'):
+              f'backbone.layer3.{layers[2] - 1}.{last}.layer.1.running_var'):
         arrs[f'{name}_buf_{k}'] = sd[k].numpy()
     return meta, arrs
 
@@ -460,6 +463,23 @@ def sec_e2e_other(ref):
         print(name, m['loss'])
     np.savez_compressed(os.path.join(GOLD, 'e2e_other.npz'), **out)
     json.dump(meta, open(os.path.join(GOLD, 'e2e_other.json'), 'w'), indent=0)
+
+
+def sec_e2e_backbones(ref):
+    """The other backbones of the reference's RetinaNet / FCOS factories (retinanet.py:102-130, fcos.py:100-128;
+    backbones/resnet.py:127-169): BasicBlock ResNet18 / 34 (C3..C5 = 128 / 256 / 512 channels) and the deeper Bottleneck
+    ResNet101 / 152, one training forward + backward at 256 x 320."""
+    out, meta = {}, {}
+    for name, fcos, resnet in (('retina_R18', False, 'resnet18'), ('fcos_R34', True, 'resnet34'),
+                               ('retina_R101', False, 'resnet101'), ('fcos_R152', True, 'resnet152')):
+        m, a = _e2e(ref, name, 256, 320, fcos, resnet=resnet)
+        assert m['feature_sizes'] == synth.feature_sizes(256, 320)
+        m['H'], m['W'], m['num_classes'], m['resnet'] = 256, 320, 80, resnet
+        meta[name] = m
+        out.update(a)
+        print(name, m['loss'])
+    np.savez_compressed(os.path.join(GOLD, 'e2e_backbones.npz'), **out)
+    json.dump(meta, open(os.path.join(GOLD, 'e2e_backbones.json'), 'w'), indent=0)
 
 
 class _Cfg:
@@ -874,7 +894,7 @@ def sec_mae(ref):
 
 SECTIONS = dict(cls=sec_cls, contract=sec_contract, anchors=sec_anchors, assign=sec_assign, losses=sec_losses,
                 decode=sec_decode, e2e=sec_e2e, e2e_s1=sec_e2e_s1, e2e_s2=sec_e2e_s2, scheduler=sec_scheduler,
-                trainer=sec_trainer, collate=sec_collate, e2e_other=sec_e2e_other, evalpost=sec_evalpost, cifar=sec_cifar, cls_bf16=sec_cls_bf16, mae=sec_mae)
+                trainer=sec_trainer, collate=sec_collate, e2e_other=sec_e2e_other, e2e_backbones=sec_e2e_backbones, evalpost=sec_evalpost, cifar=sec_cifar, cls_bf16=sec_cls_bf16, mae=sec_mae)
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)

@@ -21,9 +21,14 @@ import torch.nn.functional as F
 from . import synth
 
 RESNET50_LAYERS = [3, 4, 6, 3]
+# detection/models/backbones/resnet.py:127-169: block type and stage depths of the five detection backbones
+BACKBONES = {'resnet18backbone': ('BasicBlock', [2, 2, 2, 2]), 'resnet34backbone': ('BasicBlock', [3, 4, 6, 3]),
+             'resnet50backbone': ('Bottleneck', [3, 4, 6, 3]), 'resnet101backbone': ('Bottleneck', [3, 4, 23, 3]),
+             'resnet152backbone': ('Bottleneck', [3, 8, 36, 3])}
 
 
-def init_retinanet_state(seed=0, num_classes=80, num_anchors=9, planes=256, fcos=False):
+def init_retinanet_state(seed=0, num_classes=80, num_anchors=9, planes=256, fcos=False,
+                         backbone='resnet50backbone'):
     """Random-init state dict with the reference key names, shapes and init laws.
 
     Backbone convs kaiming-normal fan_out (backbones/resnet.py:76-83); FPN convs the
@@ -62,23 +67,29 @@ def init_retinanet_state(seed=0, num_classes=80, num_anchors=9, planes=256, fcos
 
     conv_bn('backbone.conv1', 3, 64, 7)
     inpl = 64
-    for li, (n, pl) in enumerate(zip(RESNET50_LAYERS, [64, 128, 256, 512]), start=1):
+    block, layers = BACKBONES[backbone]
+    ex = 4 if block == 'Bottleneck' else 1
+    for li, (n, pl) in enumerate(zip(layers, [64, 128, 256, 512]), start=1):
         for bi in range(n):
             p = f'backbone.layer{li}.{bi}'
             stride = 2 if (bi == 0 and li > 1) else 1
-            conv_bn(p + '.conv1', inpl, pl, 1)
-            conv_bn(p + '.conv2', pl, pl, 3)
-            conv_bn(p + '.conv3', pl, pl * 4, 1)
-            if stride != 1 or inpl != pl * 4:
-                conv_bn(p + '.downsample_conv', inpl, pl * 4, 1)
-            inpl = pl * 4
-    conv_bias('fpn.P3_1', 512, planes, 1)
+            if block == 'Bottleneck':  # classification/backbones/resnet.py:100-139
+                conv_bn(p + '.conv1', inpl, pl, 1)
+                conv_bn(p + '.conv2', pl, pl, 3)
+                conv_bn(p + '.conv3', pl, pl * 4, 1)
+            else:  # BasicBlock, :51-82
+                conv_bn(p + '.conv1', inpl, pl, 3)
+                conv_bn(p + '.conv2', pl, pl, 3)
+            if stride != 1 or inpl != pl * ex:
+                conv_bn(p + '.downsample_conv', inpl, pl * ex, 1)
+            inpl = pl * ex
+    conv_bias('fpn.P3_1', 128 * ex, planes, 1)
     conv_bias('fpn.P3_2', planes, planes, 3)
-    conv_bias('fpn.P4_1', 1024, planes, 1)
+    conv_bias('fpn.P4_1', 256 * ex, planes, 1)
     conv_bias('fpn.P4_2', planes, planes, 3)
-    conv_bias('fpn.P5_1', 2048, planes, 1)
+    conv_bias('fpn.P5_1', 512 * ex, planes, 1)
     conv_bias('fpn.P5_2', planes, planes, 3)
-    conv_bias('fpn.P6', planes if fcos else 2048, planes, 3)
+    conv_bias('fpn.P6', planes if fcos else 512 * ex, planes, 3)
     conv_bias('fpn.P7.1', planes, planes, 3)
     if not fcos:
         for i in (0, 2, 4, 6):
@@ -116,19 +127,23 @@ def backbone_forward(sd, x, training=True, prefix='backbone.'):
     x = _cba(sd, prefix + 'conv1', x, 2, 3, True, training)
     x = F.max_pool2d(x, 3, 2, 1)
     feats = []
-    inpl = 64
-    for li, (n, pl) in enumerate(zip(RESNET50_LAYERS, [64, 128, 256, 512]), start=1):
-        for bi in range(n):
+    for li in range(1, 5):  # the state dict says how deep a stage is and which block it is made of
+        bi = 0
+        while f'{prefix}layer{li}.{bi}.conv1.layer.0.weight' in sd:
             p = f'{prefix}layer{li}.{bi}'
             stride = 2 if (bi == 0 and li > 1) else 1
             idt = x
-            y = _cba(sd, p + '.conv1', x, 1, 0, True, training)
-            y = _cba(sd, p + '.conv2', y, stride, 1, True, training)
-            y = _cba(sd, p + '.conv3', y, 1, 0, False, training)
+            if (p + '.conv3.layer.0.weight') in sd:  # Bottleneck
+                y = _cba(sd, p + '.conv1', x, 1, 0, True, training)
+                y = _cba(sd, p + '.conv2', y, stride, 1, True, training)
+                y = _cba(sd, p + '.conv3', y, 1, 0, False, training)
+            else:  # BasicBlock: 3x3 (stride) -> 3x3
+                y = _cba(sd, p + '.conv1', x, stride, 1, True, training)
+                y = _cba(sd, p + '.conv2', y, 1, 1, False, training)
             if (p + '.downsample_conv.layer.0.weight') in sd:
                 idt = _cba(sd, p + '.downsample_conv', x, stride, 0, False, training)
             x = F.relu(y + idt)
-            inpl = pl * 4
+            bi += 1
         feats.append(x)
     return feats  # [C2, C3, C4, C5]
 

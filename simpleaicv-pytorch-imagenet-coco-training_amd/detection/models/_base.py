@@ -65,6 +65,22 @@ def _resnet50_backbone(bb=None):
     return _resnet_trunk(bb)
 
 
+# detection/models/backbones/resnet.py:127-169: the five detection backbones (block type, stage depths)
+DETECTION_BACKBONES = {'resnet18backbone': ('BasicBlock', (2, 2, 2, 2)), 'resnet34backbone': ('BasicBlock', (3, 4, 6, 3)),
+                       'resnet50backbone': ('Bottleneck', (3, 4, 6, 3)), 'resnet101backbone': ('Bottleneck', (3, 4, 23, 3)),
+                       'resnet152backbone': ('Bottleneck', (3, 8, 36, 3))}
+
+
+def _detection_backbone(backbone_type):
+    if backbone_type not in DETECTION_BACKBONES:
+        raise NotImplementedError(f'{backbone_type}: the MI355X hot path runs the ResNet backbones '
+                                  f'{sorted(DETECTION_BACKBONES)} (SURVEY.md 8a-1)')
+    block, layers = DETECTION_BACKBONES[backbone_type]
+    bb = _resnet_trunk(None, block=block, layer_nums=layers)
+    bb.block, bb.layer_nums = block, layers
+    return bb
+
+
 def _fpn(inplanes, planes, use_p5):
     f = nn.Module()
     f.P3_1 = nn.Conv2d(inplanes[0], planes, 1)
@@ -150,7 +166,8 @@ class HipDetector(nn.Module):
         tensors = {n: p.data for n, p in self.named_parameters()}
         tensors.update({n: b for n, b in self.named_buffers()})
         self._engine = DetectorEngine(tensors, self._arena.grad_views, self.num_classes, self.num_anchors,
-                                      self.planes, fcos=self._fcos)
+                                      self.planes, fcos=self._fcos, block=getattr(self.backbone, 'block', 'Bottleneck'),
+                                      layers=getattr(self.backbone, 'layer_nums', RESNET50_LAYERS))
         return self
 
     def _apply(self, fn, recurse=True):

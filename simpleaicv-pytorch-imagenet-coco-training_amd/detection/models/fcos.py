@@ -5,9 +5,9 @@ import math
 import torch
 import torch.nn as nn
 
-from ._base import HipDetector, _resnet50_backbone, _fpn
+from ._base import HipDetector, _detection_backbone, _fpn
 
-__all__ = ['resnet50_fcos', 'FCOS']
+__all__ = ['resnet18_fcos', 'resnet34_fcos', 'resnet50_fcos', 'resnet101_fcos', 'resnet152_fcos', 'FCOS']
 
 
 def _fcos_head(planes, num_classes):
@@ -36,14 +36,12 @@ class FCOS(HipDetector):
     def __init__(self, backbone_type='resnet50backbone', backbone_pretrained_path='', planes=256, num_classes=80,
                  use_gradient_checkpoint=False):
         super().__init__()
-        if backbone_type != 'resnet50backbone':
-            raise NotImplementedError(f'{backbone_type}: only the ResNet50 backbone is on the MI355X hot path')
         # use_gradient_checkpoint (torch.utils.checkpoint in the reference, retinanet.py:64-67, fcos.py likewise) trades
         # memory for a second forward pass and leaves every result unchanged; here the activations of the 2 x 800x1333
         # step (a few GB of 288) stay in HBM, so the flag is accepted and has nothing to switch
         self.planes, self.num_classes = planes, num_classes
         self.use_gradient_checkpoint = use_gradient_checkpoint
-        self.backbone = _resnet50_backbone()
+        self.backbone = _detection_backbone(backbone_type)  # raises for anything but the five ResNets
         self.fpn = _fpn(self.backbone.out_channels[1:4], planes, use_p5=True)
         self.clsregcnt_head = _fcos_head(planes, num_classes)
         self.scales = nn.Parameter(torch.tensor([1., 1., 1., 1., 1.], dtype=torch.float32))
@@ -54,5 +52,15 @@ class FCOS(HipDetector):
         self._init_runtime()
 
 
-def resnet50_fcos(backbone_pretrained_path='', **kwargs):
-    return FCOS('resnet50backbone', backbone_pretrained_path=backbone_pretrained_path, **kwargs)
+def _factory(backbone_type):
+    def make(backbone_pretrained_path='', **kwargs):  # fcos.py:89-125
+        return FCOS(backbone_type, backbone_pretrained_path=backbone_pretrained_path, **kwargs)
+    make.__name__ = backbone_type.replace('backbone', '_fcos')
+    return make
+
+
+resnet18_fcos = _factory('resnet18backbone')
+resnet34_fcos = _factory('resnet34backbone')
+resnet50_fcos = _factory('resnet50backbone')
+resnet101_fcos = _factory('resnet101backbone')
+resnet152_fcos = _factory('resnet152backbone')

@@ -210,3 +210,32 @@ def test_trainer_skips_zero_loss_batches_like_the_reference():
     assert float(flag) == 1.0
     assert float(ops.loss_skip_flag(torch.tensor([0.5, 0.25]).cuda())) == 0.0
     assert float(ops.loss_skip_flag(torch.tensor([float('inf'), 0.25]).cuda())) == 1.0
+
+
+@pytest.mark.parametrize('name,crit', [('resnet18_retinanet', 'RetinaLoss'), ('resnet101_fcos', 'FCOSLoss')])
+def test_trainer_step_on_the_other_backbones(name, crit):
+    """DetectionTrainer.step on a BasicBlock trunk (ResNet18) and a deep Bottleneck trunk (ResNet101; FCOS head): the
+    gradient arena after the fused step equals what the class-level path (model(images) -> criterion -> backward, the
+    path pinned to the reference's fixtures in test_gpu_pinned.py) leaves in a second model with the same weights, the
+    loss values agree, the two AdamW groups hold every parameter, and the second step runs (stage hooks, buckets)."""
+    from sacv_amd.detection import models, losses
+    from sacv_amd.train import DetectionTrainer
+    H, W = gi.MID
+    images = torch.tensor(synth.images(31, 2, H, W)).cuda()
+    annots = torch.tensor(synth.annotations(32, 2, H, W, boxes_per_image=8)).cuda()
+    net = models.__dict__[name]().cuda().train()
+    weights = {k: v.clone() for k, v in net.state_dict().items()}
+    tr = DetectionTrainer(net, losses.__dict__[crit](), lr=1e-4, weight_decay=1e-3)
+    assert sum(len(g['param_names']) for g in tr.param_groups) == len(list(net.named_parameters()))
+    got = tr.finish_step(tr.step(images, annots))
+    fast = net.arena.grads.clone()
+    ref = models.__dict__[name]().cuda().train()
+    ref.load_state_dict(weights)
+    ld = losses.__dict__[crit]()(ref(images), annots)
+    sum(ld.values()).backward()
+    for k, v in ld.items():
+        assert abs(got[k] - float(v)) <= 1e-6 * max(1.0, abs(float(v))), (k, got[k], float(v))
+    d = float((fast - ref.arena.grads).abs().max())
+    assert d <= 1e-6 * float(ref.arena.grads.abs().max()), d
+    again = tr.finish_step(tr.step(images, annots))
+    assert again['optimizer_steps'] == 2 and not again['skipped'] and np.isfinite(again['loss'])

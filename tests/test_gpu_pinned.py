@@ -18,23 +18,27 @@ from tests.test_scheduler_cpu import collate_samples
 
 @pytest.mark.parametrize('kind,tag', [('retina', 'S1'), ('fcos', 'S1'), ('retina', 'S2'), ('fcos', 'S2'),
                                       ('retina', 'V640'), ('fcos', 'V640'), ('retina', 'O1024'),
-                                      ('retina', 'C365'), ('fcos', 'C365')])
+                                      ('retina', 'C365'), ('fcos', 'C365'),
+                                      ('retina', 'R18'), ('fcos', 'R34'), ('retina', 'R101'), ('fcos', 'R152')])
 def test_full_size_step_against_reference_fixture(golden_dir, kind, tag):
     """loss dict 1e-4 (north-star tolerance), 256 samples of every output level 2e-4, all gradient norms, and the
     full gradients of 8-9 small tensors elementwise (relative L2 and max-abs vs the tensor's scale).  V640 / O1024 are
     the square yolo-style canvases of the VOC (20 classes) and Objects365 recipes (make_golden.py
     section e2e_other); C365 = Objects365's 365 classes (3285 / 365 class channels, not a multiple of 4: the engine's
-    padded shadow weights) at 256 x 320."""
+    padded shadow weights) at 256 x 320.  R18 / R34 / R101 / R152: the other backbones of the reference's factories
+    (BasicBlock trunks with 128 / 256 / 512-channel C3..C5; 23- and 36-block stages; section e2e_backbones) at 256 x 320."""
     from sacv_amd.detection import models, losses
-    f = {'S1': 'e2e_s1', 'S2': 'e2e_s2'}.get(tag, 'e2e_other')
+    f = {'S1': 'e2e_s1', 'S2': 'e2e_s2', 'R18': 'e2e_backbones', 'R34': 'e2e_backbones', 'R101': 'e2e_backbones',
+         'R152': 'e2e_backbones'}.get(tag, 'e2e_other')
     name = f'{kind}_{tag}'
     meta = json.load(open(os.path.join(golden_dir, f + '.json')))[name]
     arrs = np.load(os.path.join(golden_dir, f + '.npz'))
     H, W = gi.SHAPES[tag] if tag in gi.SHAPES else (meta['H'], meta['W'])
     nc = meta.get('num_classes', 80)
     fcos = kind == 'fcos'
-    net = models.__dict__['resnet50_fcos' if fcos else 'resnet50_retinanet'](num_classes=nc)
-    net.load_state_dict(omodel.init_retinanet_state(0, num_classes=nc, fcos=fcos))
+    resnet = meta.get('resnet', 'resnet50')
+    net = models.__dict__[resnet + ('_fcos' if fcos else '_retinanet')](num_classes=nc)
+    net.load_state_dict(omodel.init_retinanet_state(0, num_classes=nc, fcos=fcos, backbone=resnet + 'backbone'))
     net = net.cuda().train()
     crit = losses.__dict__['FCOSLoss' if fcos else 'RetinaLoss']()
     outs = net(torch.tensor(synth.images(5, 2, H, W)).cuda())
@@ -51,7 +55,10 @@ def test_full_size_step_against_reference_fixture(golden_dir, kind, tag):
             d = gi.digest(o.detach().cpu().numpy(), 256)
             ref = arrs[f'{name}_out{g_}_l{l}_samples']
             if fcos:  # GroupNorm over few values amplifies fp32 rounding (tests/test_gpu_fcos.py): abs vs the scale
-                assert float(np.abs(d['samples'] - ref).max()) <= 5e-4 * max(1.0, float(np.abs(ref).max())), (g_, l)
+                # (ResNet152 at 256 x 320: the reference's fp32 outputs are 1.4e-3 .. 3.3e-3 of the scale away from the
+                # same graph in fp64 on the regression heads -- CPU oracle, measured; the device 1.4e-3 from the fixture)
+                bound = 5e-3 if tag in ('R101', 'R152') else 5e-4
+                assert float(np.abs(d['samples'] - ref).max()) <= bound * max(1.0, float(np.abs(ref).max())), (g_, l)
             else:
                 np.testing.assert_allclose(d['samples'], ref, rtol=2e-4, atol=5e-6)
     sum(ld.values()).backward()
@@ -77,7 +84,17 @@ def test_full_size_step_against_reference_fixture(golden_dir, kind, tag):
         # C365 runs on the 256 x 320 canvas: layer4 has 2 x 8 x 10 = 160 values per channel, a single element of its
         # BatchNorm gradient moves by up to 9 % of the tensor's scale between two fp32 summation orders (measured;
         # rel-L2 stays below 1e-2): the max-abs bound is 1.5e-1 there
-        if not (l2 <= 5e-2 and mx <= (1.5e-1 if tag == 'C365' else 5e-2)):
+        # R101 / R152 (same small canvas, 101 / 152 batch-statistics layers): the reference's own fp32 gradients are
+        # 5.0e-2 .. 6.7e-2 (rel-L2) and up to 7.6e-2 (max-abs) away from the same graph in fp64 on the early-layer
+        # tensors checked here (measured with the CPU oracle, ResNet101); the device is 4e-2 .. 5e-2 from the fp32
+        # fixture: rel-L2 1e-1, max-abs 1.5e-1 for them
+        # R152 (FCOS): fp32 vs fp64 of the reference graph 6.0e-2 .. 1.3e-1 rel-L2, up to 1.7e-1 max-abs; the device
+        # 6.3e-2 .. 1.2e-1 / 1.3e-1 from the fp32 fixture: 2e-1 / 2.5e-1.  (An elementwise comparison of two fp32
+        # evaluations of a 152-layer batch-statistics graph cannot be tighter than the graph's own rounding noise; the
+        # per-tensor norms above, the outputs and the losses are the sharp checks for these two.)
+        l2_max = {'R101': 1e-1, 'R152': 2e-1}.get(tag, 5e-2)
+        mx_max = {'R101': 1.5e-1, 'R152': 2.5e-1, 'C365': 1.5e-1}.get(tag, 5e-2)
+        if not (l2 <= l2_max and mx <= mx_max):
             bad.append((pname, l2, mx))
         checked += 1
     assert checked >= 8 and not bad, bad

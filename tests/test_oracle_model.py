@@ -11,8 +11,8 @@ from oracle import losses as olosses, model as omodel, synth
 from tests import golden_inputs as gi
 
 
-def run_oracle_e2e(H, W, fcos, box_loss_type='SmoothL1', num_classes=80):
-    sd = omodel.init_retinanet_state(0, num_classes=num_classes, fcos=fcos)
+def run_oracle_e2e(H, W, fcos, box_loss_type='SmoothL1', num_classes=80, backbone='resnet50backbone'):
+    sd = omodel.init_retinanet_state(0, num_classes=num_classes, fcos=fcos, backbone=backbone)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
               if v.dtype.is_floating_point and 'running_' not in k}
     state = dict(sd)
@@ -67,6 +67,26 @@ def test_oracle_model_on_the_voc_canvas(golden_dir):
         for l, o in enumerate(grp):
             d = gi.digest(o.detach().numpy(), 256)
             np.testing.assert_allclose(d['samples'], arrs[f'retina_V640_out{gi_}_l{l}_samples'], rtol=1e-4, atol=1e-6)
+    for k, p in params.items():
+        np.testing.assert_allclose(float(p.grad.double().norm()), meta['grad_norm'][k], rtol=2e-3, atol=1e-7,
+                                   err_msg=k)
+
+
+@pytest.mark.parametrize('name', ['retina_R18', 'fcos_R34', 'retina_R101'])
+def test_oracle_model_on_the_other_backbones(golden_dir, name):
+    """BasicBlock ResNet18 / 34 and the deeper Bottleneck backbones of the reference's factories (fixture section
+    e2e_backbones, produced by the reference's own resnet18_retinanet / resnet34_fcos / resnet101_retinanet; the
+    ResNet152 case runs in the GPU suite only, to keep this one short)."""
+    meta = json.load(open(os.path.join(golden_dir, 'e2e_backbones.json')))[name]
+    arrs = np.load(os.path.join(golden_dir, 'e2e_backbones.npz'))
+    fcos = name.startswith('fcos')
+    outs, ld, params, state = run_oracle_e2e(meta['H'], meta['W'], fcos, backbone=meta['resnet'] + 'backbone')
+    for k, v in ld.items():
+        np.testing.assert_allclose(float(v), meta['loss'][k], rtol=1e-5)
+    for gi_, grp in enumerate(outs):
+        for l, o in enumerate(grp):
+            d = gi.digest(o.detach().numpy(), 256)
+            np.testing.assert_allclose(d['samples'], arrs[f'{name}_out{gi_}_l{l}_samples'], rtol=1e-4, atol=1e-6)
     for k, p in params.items():
         np.testing.assert_allclose(float(p.grad.double().norm()), meta['grad_norm'][k], rtol=2e-3, atol=1e-7,
                                    err_msg=k)

@@ -121,6 +121,13 @@ int sacv_pack_dgrad_batched(const void* descs, const int* chunk_map, int nchunks
 int sacv_im2col_stem(const float* x, float* col, int Nb, int Cin, int H, int W, long long sN, long long sC,
                      long long sH, long long sW, int Ho, int Wo, int KH, int KW, int stride, int pad, int Kpad,
                      void* stream);
+/* The 7x7/s2/p3 stem convolution itself (classification/backbones/resnet.py:176-181, the `conv1` of
+ * detection/models/backbones/resnet.py:96-100), forward, without the im2col matrix: x as above (3 channels),
+ * wpanel = the packed stem panel [64][Kpad] (sacv_pack_weight stem mode, k = (ky*7+kx)*3 + c), y [Nb][Ho][Wo][64];
+ * stats (optional) [sacv_stem_conv_stats_rows][2][64] = per-tile column sums / sums of squares for BatchNorm. */
+int sacv_stem_conv_stats_rows(int Nb, int Ho, int Wo);
+int sacv_stem_conv_fwd(const float* x, int Nb, int H, int W, long long sN, long long sC, long long sH, long long sW,
+                       const float* wpanel, int Kpad, float* y, int Ho, int Wo, float* stats, void* stream);
 
 /* ---- BatchNorm2d (classification/backbones/resnet.py:41; training mode batch statistics) ------------ */
 long long sacv_bn_workspace_floats(int R, int C);

@@ -40,6 +40,8 @@ SIGNATURES = {
     'sacv_pack_dgrad_batched': (I, [P, P, I, P]),
     'sacv_pack_weight': (I, [P, P, I, I, I, I, I, I, P]),
     'sacv_im2col_stem': (I, [P, P, I, I, I, I, LL, LL, LL, LL, I, I, I, I, I, I, I, P]),
+    'sacv_stem_conv_stats_rows': (I, [I, I, I]),
+    'sacv_stem_conv_fwd': (I, [P, I, I, I, LL, LL, LL, LL, P, I, P, I, I, P, P]),
     'sacv_bn_workspace_floats': (LL, [I, I]),
     'sacv_bn_train_stats': (I, [P, I, I, F, F, P, P, P, P, P, P, P]),
     'sacv_bn_apply': (I, [P, P, P, P, P, P, P, LL, I, I, I, F, P]),

@@ -1,0 +1,180 @@
+// Forward pass of the stem convolution (7x7 / stride 2 / pad 3, Cin = 3 -> 64: classification/backbones/resnet.py:176-181,
+// reached through detection/models/backbones/resnet.py:96-100) WITHOUT the im2col matrix.
+//
+// Cin = 3 is too narrow for the implicit-GEMM kernel's 16-byte channel gathers, so rounds 1-2 wrote the [pixels][160]
+// im2col matrix (341 MB at 2 x 800x1333: 144 us of writes at 2.5 TB/s) and ran a GEMM over it (140 us).  Here a
+// workgroup owns a tile of TR x 32 output pixels, loads the (TR*2+5) x 69 x 3 input patch it needs into LDS once
+// (10.8 KB; each input pixel is read ~1.4 times from HBM instead of being written 12 times and read back) and feeds
+// the fp32 matrix cores straight from it: for v_mfma_f32_32x32x2_f32 a lane supplies ONE A element (pixel = lane % 32,
+// k = 2 s + lane / 32), which is a single ds_read_b32 at (row*2+ky, col*2+kx, c) of the patch -- consecutive lanes are
+// 6 floats apart, 32 different banks.  K is ordered (ky, kx, c) with every ky row of 21 padded to 22 (a zero weight), so
+// a k pair never straddles two patch rows; the weights sit in LDS as B[154][64] (39 KB, rebuilt per workgroup from the
+// packed stem panel [64][160] the GEMM path uses).  4 waves = 4 output rows of 32 pixels x 64 channels, 2 x 77 MFMAs per
+// tile and wave, fp32 accumulation in the same k order as the GEMM path.  Epilogue: 128-byte row stores from the
+// accumulators and the per-tile column sums / sums of squares BatchNorm's statistics are finalised from (CF_STATS rows).
+// Persistent workgroups, 3 per CU.
+#include "sacv_common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int TR = 4, TC = 32;            // output tile: TR rows x TC columns = 4 waves x 32 pixels
+constexpr int KH = 7, KW = 7, CIN = 3, ST = 2, PAD = 3, NOUT = 64;
+constexpr int PR = (TR - 1) * ST + KH;    // 13 patch rows
+constexpr int PC = (TC - 1) * ST + KW;    // 69 patch columns
+constexpr int KROW = KW * CIN + 1;        // 22: one ky row of k, padded to an even length
+constexpr int KTOT = KH * KROW;           // 154
+constexpr int PATCH = PR * PC * CIN + 4;  // + the floats a padded k may touch past the last pixel
+constexpr int LDS_FLOATS = KTOT * NOUT + PATCH;
+
+struct StemArgs {
+  const float* x;
+  long long sN, sC, sH, sW;
+  const float* wpanel;  // [64][Kpad], k = (ky*7+kx)*3 + c
+  float* y;             // [Nb][Ho][Wo][64]
+  float* stats;         // [tiles][2][64] or null
+  int Nb, H, W, Ho, Wo, Kpad, tiles_x, tiles_y, ntiles;
+};
+
+__global__ __launch_bounds__(256, 3) void stem_conv_kernel(const StemArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Bs = smem;                 // [KTOT][64]
+  float* patch = smem + KTOT * NOUT;  // [PR][PC][3]
+  __shared__ float red[2][4][NOUT];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  // weights -> LDS, once per workgroup
+  // (coalesced reads along k; the transposing LDS writes are bank-conflicted, 38 per thread, once per workgroup)
+  for (int i = tid; i < NOUT * KH * KW * CIN; i += 256) {
+    const int n = i / (KH * KW * CIN), k = i - n * (KH * KW * CIN);
+    const int ky = k / (KW * CIN), r = k - ky * (KW * CIN);
+    Bs[(ky * KROW + r) * NOUT + n] = a.wpanel[(size_t)n * a.Kpad + k];
+  }
+  for (int i = tid; i < KH * NOUT; i += 256) Bs[((i / NOUT) * KROW + KW * CIN) * NOUT + (i % NOUT)] = 0.f;
+  for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int n = t / per_img, tt = t - n * per_img;
+    const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+    const int oy0 = ty * TR, ox0 = tx * TC;
+    const int iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
+    __syncthreads();  // the previous tile's MFMA loop has left the patch (and the weights are in place)
+    // patch -> LDS: (c, row, col) with col fastest = the contiguous direction of an NCHW image; any strides work
+    const float* xn = a.x + (long long)n * a.sN;
+    for (int i = tid; i < CIN * PR * PC; i += 256) {
+      const int c = i / (PR * PC), rem = i - c * (PR * PC);
+      const int py = rem / PC, px = rem - py * PC;
+      const int iy = iy0 + py, ix = ix0 + px;
+      float v = 0.f;
+      if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = xn[c * a.sC + iy * a.sH + ix * a.sW];
+      patch[(py * PC + px) * CIN + c] = v;
+    }
+    if (tid < 4) patch[PR * PC * CIN + tid] = 0.f;
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    // wave wv = output row oy0 + wv; lane's pixel = column l31
+    const float* prow = patch + ((wv * ST) * PC + l31 * ST) * CIN + lh;
+    const float* brow = Bs + lh * NOUT + l31;
+#pragma unroll 1
+    for (int ky = 0; ky < KH; ++ky) {
+      const float* pa = prow + ky * PC * CIN;
+      const float* pb = brow + ky * KROW * NOUT;
+#pragma unroll
+      for (int s = 0; s < KROW / 2; ++s) {
+        const float av = pa[2 * s];
+        const float b0 = pb[2 * s * NOUT], b1 = pb[2 * s * NOUT + 32];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+      }
+    }
+    // epilogue: accumulator register r of block j is pixel column (r & 3) + 8 (r >> 2) + 4 lh, channel l31 + 32 j
+    const int oy = oy0 + wv;
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    if (oy < a.Ho) {
+      float* yrow = a.y + (((size_t)n * a.Ho + oy) * a.Wo + ox0) * NOUT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int col = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (ox0 + col < a.Wo) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float v = acc[j][r];
+            yrow[(size_t)col * NOUT + l31 + 32 * j] = v;
+            s1[j] += v;
+            s2[j] += v * v;
+          }
+        }
+      }
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        s1[j] += __shfl_xor(s1[j], 32, 64);
+        s2[j] += __shfl_xor(s2[j], 32, 64);
+      }
+      if (lh == 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          red[0][wv][l31 + 32 * j] = s1[j];
+          red[1][wv][l31 + 32 * j] = s2[j];
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * NOUT) {
+        const int which = tid / NOUT, c = tid - which * NOUT;
+        const float s = ((red[which][0][c] + red[which][1][c]) + red[which][2][c]) + red[which][3][c];
+        a.stats[((size_t)t * 2 + which) * NOUT + c] = s;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// rows of the statistics buffer of sacv_stem_conv_fwd (one per output tile)
+int sacv_stem_conv_stats_rows(int Nb, int Ho, int Wo) { return Nb * ((Ho + TR - 1) / TR) * ((Wo + TC - 1) / TC); }
+
+// y[Nb][Ho][Wo][64] = conv7x7/s2/p3(x) for a 3-channel image given by element strides (NCHW-contiguous or
+// channels_last), weights as the packed stem panel [64][Kpad] (sacv_pack_weight, stem mode: k = (ky*7+kx)*3 + c).
+// stats (optional): [sacv_stem_conv_stats_rows][2][64] per-tile column sums and sums of squares of y.
+int sacv_stem_conv_fwd(const float* x, int Nb, int H, int W, long long sN, long long sC, long long sH, long long sW,
+                       const float* wpanel, int Kpad, float* y, int Ho, int Wo, float* stats, void* stream) {
+  SACV_CHECK_ARG(x && wpanel && y, "stem_conv_fwd: null pointer");
+  SACV_CHECK_ARG(Nb > 0 && H > 0 && W > 0, "stem_conv_fwd: empty image");
+  SACV_CHECK_ARG(Ho == (H + 2 * PAD - KH) / ST + 1 && Wo == (W + 2 * PAD - KW) / ST + 1,
+                 "stem_conv_fwd: output %d x %d does not belong to a %d x %d image (7x7, stride 2, pad 3)", Ho, Wo, H, W);
+  SACV_CHECK_ARG(Kpad >= KH * KW * CIN, "stem_conv_fwd: Kpad %d < 147", Kpad);
+  SACV_CHECK_ARG((long long)Nb * Ho * Wo * NOUT < (1LL << 40), "stem_conv_fwd: output too large");
+  StemArgs a;
+  a.x = x;
+  a.sN = sN;
+  a.sC = sC;
+  a.sH = sH;
+  a.sW = sW;
+  a.wpanel = wpanel;
+  a.y = y;
+  a.stats = stats;
+  a.Nb = Nb;
+  a.H = H;
+  a.W = W;
+  a.Ho = Ho;
+  a.Wo = Wo;
+  a.Kpad = Kpad;
+  a.tiles_y = (Ho + TR - 1) / TR;
+  a.tiles_x = (Wo + TC - 1) / TC;
+  const long long nt = (long long)Nb * a.tiles_x * a.tiles_y;
+  SACV_CHECK_ARG(nt < (1LL << 30), "stem_conv_fwd: too many tiles");
+  a.ntiles = (int)nt;
+  const int lds = LDS_FLOATS * 4;
+  const int grid = std::min(a.ntiles, 3 * 256);
+  hipLaunchKernelGGL(stem_conv_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  SACV_CHECK_LAUNCH("stem_conv_kernel");
+  return SACV_OK;
+}
+
+}  // extern "C"

@@ -60,6 +60,14 @@ class DetectorEngine:
         # Winograd F(2x2,3x3) for the stride-1 3x3 head convolutions (csrc/winograd.hip): layer i of both towers in
         # one launch.  False selects the direct implicit-GEMM kernel for every conv (A/B measurements, tests).
         self.winograd = True
+        # The 7x7 stem without the im2col matrix (csrc/stem_conv.hip: 136 us instead of 142 + 140).  'eval': forward
+        # passes that keep nothing for a backward pass (evaluation, inference) use it; a TRAINING step keeps the
+        # im2col + GEMM pair -- its weight gradient contracts with the im2col matrix anyway (rebuilt on the side stream
+        # when the forward pass did not write it: one more launch competing with the weight gradients there), the step
+        # did not get faster in the A/B (27.27-27.34 ms with, 27.20-27.25 without), and the different summation order of
+        # the stem moves the 3-step AdamW fixture of SURVEY.md 8a-13 (1e-5 on the parameter norms) to 1.06e-5.
+        # True forces it everywhere, False nowhere (tests, A/B).
+        self.fused_stem = 'eval'
         self._wino_cache = {}
         import os
         self._side, self._side_busy = None, False  # the weight gradients' stream (see _on_side)
@@ -375,17 +383,25 @@ class DetectorEngine:
         # stem: explicit im2col (Cin=3) + GEMM, BN, ReLU (+ 3x3/s2 max pool for the ImageNet stem)
         sk, ss, sp = (7, 2, 3) if self.stem == 'imagenet' else (3, 1, 1)
         ho, wo = _out_hw(h, w, sk, ss, sp)
+        fused = not self.amp and self.stem == 'imagenet' and (self.fused_stem is True or
+                                                               (self.fused_stem == 'eval' and not keep))
         if self.amp:
             col = ops.im2col_stem(images, ho, wo, sk, sk, ss, sp, dtype=ops.BF16)
             wst = self._hpanels.stem_panel
         else:
-            col = ops.im2col_stem(images, ho, wo, sk, sk, ss, sp)
             wst = ops.pack_weight(p[bp + 'conv1.layer.0.weight'], PACK_STEM)
-        if training:
+            # fp32 7x7/s2 stem: the convolution reads the image itself (csrc/stem_conv.hip); the im2col matrix the
+            # weight gradient contracts with is rebuilt in the backward pass, on the side stream (_backbone_bwd)
+            col = None if fused else ops.im2col_stem(images, ho, wo, sk, sk, ss, sp)
+        if fused:
+            y, st = ops.stem_conv(images, wst, ho, wo, stats=True) if training else (ops.stem_conv(images, wst, ho, wo), None)
+        elif training:
             (y,), st = ops.conv_gemm([col], wst, 64, 1, 1, 1, 0, 0, [(ho, wo)], stats=True)
         else:
             y, st = ops.conv_gemm([col], wst, 64, 1, 1, 1, 0, 0, [(ho, wo)])[0], None
         z, c = self._bn_fwd(col, y, bp + 'conv1', sk, ss, sp, True, training, None, keep, st)
+        if fused and keep:
+            ctx['stem_images'] = images
         if self.stem == 'imagenet':
             x, pool_idx = ops.maxpool_fwd(z, 3, 2, 1, want_idx=keep)
         else:
@@ -975,8 +991,18 @@ class DetectorEngine:
         bn = bp + 'conv1.layer.1.'
         dy, _ = ops.bn_train_bwd(dpool, None, st.y, st.mean, st.invstd, self.p[bn + 'weight'], self.g[bn + 'weight'],
                                  self.g[bn + 'bias'], relu_beta=self.p[bn + 'bias'])
-        self._wgrad([dy], [st.x], self.g[bp + 'conv1.layer.0.weight'], 3, 1, 1, 1, 0,
-                    cin_pad=st.x.shape[-1], dw_taps=st.k * st.k)
+        if st.x is None:  # fused stem forward: no im2col matrix was kept
+            img = ctx['stem_images']
+            kpad = ops.stem_kpad(st.k, img.shape[1])
+
+            def stem_wgrad():
+                col = ops.im2col_stem(img, dy.shape[1], dy.shape[2], st.k, st.k, st.stride, st.pad)
+                ops.conv_wgrad([dy], [col], self.g[bp + 'conv1.layer.0.weight'], 3, 1, 1, 1, 0, cin_pad=kpad,
+                               dw_taps=st.k * st.k)
+            self._on_side(stem_wgrad, [dy, img])
+        else:
+            self._wgrad([dy], [st.x], self.g[bp + 'conv1.layer.0.weight'], 3, 1, 1, 1, 0,
+                        cin_pad=st.x.shape[-1], dw_taps=st.k * st.k)
 
     def _bottleneck_bwd(self, saved, dout, accum_target):
         c1, c2, c3, cd = saved

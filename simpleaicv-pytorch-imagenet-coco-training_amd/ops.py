@@ -519,6 +519,31 @@ def im2col_stem(x_nchw_logical, ho, wo, kh=7, kw=7, stride=2, pad=3, dtype=torch
     return col
 
 
+def stem_conv(x_nchw_logical, wpanel, ho, wo, stats=False):
+    """7x7/s2/p3 stem convolution without the im2col matrix: x logical [N,3,H,W] in any strides, wpanel the packed stem
+    panel [64][Kpad] -> y [N,ho,wo,64] (and the per-tile BatchNorm partial sums [rows,2,64] when stats=True)."""
+    x = x_nchw_logical
+    if x.device.type != 'cuda' or x.dtype != torch.float32 or x.shape[1] != 3:
+        raise ValueError('stem_conv: expected an fp32 CUDA(HIP) image batch [N,3,H,W]')
+    n, _, h, w = x.shape
+    sn, sc, sh, sw = x.stride()
+    y = torch.empty((n, ho, wo, 64), device=x.device, dtype=torch.float32)
+    st = None
+    if stats:
+        st = torch.empty((lib.sacv_stem_conv_stats_rows(n, ho, wo), 2, 64), device=x.device, dtype=torch.float32)
+
+    def launch():
+        check(lib.sacv_stem_conv_fwd(_ptr(x), n, h, w, sn, sc, sh, sw, _ptr(_chk(wpanel, 'stem panel')), wpanel.shape[-1],
+                                     _ptr(y), ho, wo, _ptr(st) if stats else None, _stream()), 'stem_conv_fwd')
+    if TIMER is not None:
+        pix = n * ho * wo
+        TIMER.time(f'conv_nt_stem|m0 k7 s2 cs3 n64 np1 pix{pix} f{32 if stats else 0}', 2.0 * pix * 64 * 147, launch,
+                   4.0 * (n * 3 * h * w + pix * 64 + 64 * 147))
+    else:
+        launch()
+    return (y, st) if stats else y
+
+
 # ------------------------------------------------------------------------------------------ norm
 def _bn_ws(r, c, device):
     return workspace(lib.sacv_bn_workspace_floats(r, c) * 4, device, 'bn')

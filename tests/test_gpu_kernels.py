@@ -293,6 +293,31 @@ def test_stem_conv(ops):
     assert float((dw.cpu() - wr.grad).abs().max()) <= 5e-5 * float(wr.grad.abs().max())
 
 
+@pytest.mark.parametrize('hw', [(70, 93), (64, 128), (33, 31), (800, 1333)])
+def test_stem_conv_without_im2col(ops, hw):
+    """sacv_stem_conv_fwd (the 7x7/s2 stem reading the image itself) vs torch's conv2d, for NCHW-contiguous and
+    channels_last images, odd sizes (partial tiles in both directions, output narrower than one tile), and against
+    the im2col + GEMM path it replaces; the per-tile BatchNorm partial sums add up to the column sums of y."""
+    H, W = hw
+    x = torch.from_numpy(synth.images(3, 2, H, W))
+    wt = rnd(7, 64, 3, 7, 7, std=0.05)
+    yr = F.conv2d(x, wt, None, 2, 3)
+    ho, wo = yr.shape[2:]
+    wp = ops.pack_weight(wt.cuda(), ops.PACK_STEM)
+    scale = float(yr.abs().max())
+    for img in (x.cuda(), x.cuda().contiguous(memory_format=torch.channels_last)):
+        y, st = ops.stem_conv(img, wp, ho, wo, stats=True)
+        assert float((nchw(y) - yr).abs().max()) <= 2e-5 * scale
+        y2 = ops.stem_conv(img, wp, ho, wo)
+        assert torch.equal(y, y2)
+        tot = st.double().sum(dim=0).cpu()
+        ref = torch.stack([yr.double().sum(dim=(0, 2, 3)), (yr.double() ** 2).sum(dim=(0, 2, 3))])
+        assert float((tot - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    col = ops.im2col_stem(x.cuda(), ho, wo)
+    y3 = ops.conv_gemm([col], wp, 64, 1, 1, 1, 0, 0, [(ho, wo)])[0]
+    assert float((y3 - y).abs().max()) <= 1e-5 * scale  # (not bit-identical: the GEMM path may split K over workgroups)
+
+
 # ----------------------------------------------------------------------------------------- norm / pointwise
 @pytest.mark.parametrize('shape', [(2, 64, 50, 67), (2, 256, 13, 21), (2, 2048, 4, 6), (2, 1024, 7, 11)])
 @pytest.mark.parametrize('relu,res', [(True, False), (True, True), (False, False)])

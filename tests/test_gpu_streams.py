@@ -10,6 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import model as omodel, synth
+from tests import golden_inputs as gi
 
 
 def _build(kind, side):
@@ -156,3 +157,31 @@ def test_class_count_not_a_multiple_of_four(kind):
     assert (want[0] > 0).sum() > 10
     for g_, w_ in zip(got, want):
         assert np.array_equal(g_, w_)
+
+
+def test_training_step_with_the_fused_stem():
+    """engine.fused_stem = True (the 7x7 stem reads the image; its weight gradient rebuilds the im2col matrix on the side
+    stream) against the default training path (im2col + GEMM in the forward pass, matrix kept): same loss to 1e-5, and
+    every parameter's gradient norm within 5e-2 (two fp32 summation orders of the stem; the elementwise spread of deep
+    graphs at this size is documented in test_gpu_pinned.py) -- the stem weight's own gradient included."""
+    from sacv_amd.detection import models, losses
+    H, W = gi.MID
+    images = torch.tensor(synth.images(41, 2, H, W)).cuda()
+    annots = torch.tensor(synth.annotations(42, 2, H, W, boxes_per_image=8)).cuda()
+    sd = omodel.init_retinanet_state(0)
+    res = []
+    for fused in (False, True):
+        net = models.__dict__['resnet50_retinanet']().cuda().train()
+        net.load_state_dict(sd)
+        net._engine.fused_stem = fused
+        ld = losses.__dict__['RetinaLoss']()(net(images), annots)
+        sum(ld.values()).backward()
+        torch.cuda.synchronize()
+        res.append(({k: float(v) for k, v in ld.items()},
+                    {k: float(p.grad.double().norm()) for k, p in net.named_parameters()}))
+    (l0, g0), (l1, g1) = res
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-5 * max(1.0, abs(l0[k])), (k, l0[k], l1[k])
+    rel = {k: abs(g0[k] - g1[k]) / (g0[k] + 1e-12) for k in g0}
+    assert max(rel.values()) <= 5e-2, sorted(rel.items(), key=lambda kv: -kv[1])[:3]
+    assert rel['backbone.conv1.layer.0.weight'] <= 5e-2

@@ -4,7 +4,7 @@
 // Cin = 3 is too narrow for the implicit-GEMM kernel's 16-byte channel gathers, so rounds 1-2 wrote the [pixels][160]
 // im2col matrix (341 MB at 2 x 800x1333: 144 us of writes at 2.5 TB/s) and ran a GEMM over it (140 us).  Here a
 // workgroup owns a tile of TR x 32 output pixels, loads the (TR*2+5) x 69 x 3 input patch it needs into LDS once
-// (10.8 KB; each input pixel is read ~1.4 times from HBM instead of being written 12 times and read back) and feeds
+// (10.8 KB; each input pixel is read ~1.4 times from HBM instead of being written 12 times and read back; the next tile's patch is requested before the current tile's MFMA loop) and feeds
 // the fp32 matrix cores straight from it: for v_mfma_f32_32x32x2_f32 a lane supplies ONE A element (pixel = lane % 32,
 // k = 2 s + lane / 32), which is a single ds_read_b32 at (row*2+ky, col*2+kx, c) of the patch -- consecutive lanes are
 // 6 floats apart, 32 different banks.  K is ordered (ky, kx, c) with every ky row of 21 padded to 22 (a zero weight), so
@@ -45,31 +45,67 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(const StemArgs a) {
   const int l31 = lane & 31, lh = lane >> 5;
   // weights -> LDS, once per workgroup
   // (coalesced reads along k; the transposing LDS writes are bank-conflicted, 38 per thread, once per workgroup)
-  for (int i = tid; i < NOUT * KH * KW * CIN; i += 256) {
-    const int n = i / (KH * KW * CIN), k = i - n * (KH * KW * CIN);
-    const int ky = k / (KW * CIN), r = k - ky * (KW * CIN);
-    Bs[(ky * KROW + r) * NOUT + n] = a.wpanel[(size_t)n * a.Kpad + k];
+  // (ten requests in flight per thread: one element at a time was 37 exposed L2 latencies at the start of every workgroup)
+  for (int i0 = tid; i0 < NOUT * KH * KW * CIN; i0 += 256 * 10) {
+    float wv_[10];
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      const int i = i0 + u * 256;
+      const int n = i / (KH * KW * CIN), k = i - n * (KH * KW * CIN);
+      wv_[u] = i < NOUT * KH * KW * CIN ? a.wpanel[(size_t)n * a.Kpad + k] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      const int i = i0 + u * 256;
+      const int n = i / (KH * KW * CIN), k = i - n * (KH * KW * CIN);
+      const int ky = k / (KW * CIN), r = k - ky * (KW * CIN);
+      if (i < NOUT * KH * KW * CIN) Bs[(ky * KROW + r) * NOUT + n] = wv_[u];
+    }
   }
   for (int i = tid; i < KH * NOUT; i += 256) Bs[((i / NOUT) * KROW + KW * CIN) * NOUT + (i % NOUT)] = 0.f;
+  // patch elements of one tile: (c, row, col) with col fastest = the contiguous direction of an NCHW image (any strides
+  // work); NLD loads per thread, all in flight at once, and the NEXT tile's are issued before the current tile's MFMA
+  // loop (the first version loaded and stored one element at a time: eleven exposed global latencies per tile, 136 us)
+  constexpr int NLD = (CIN * PR * PC + 255) / 256;
+  int pofs[NLD];  // LDS float index of this thread's elements; -1: none
+  int ppy[NLD], ppx[NLD], pc[NLD];
+#pragma unroll
+  for (int u = 0; u < NLD; ++u) {
+    const int i = tid + u * 256;
+    const int c = i / (PR * PC), rem = i - c * (PR * PC);
+    ppy[u] = rem / PC;
+    ppx[u] = rem - ppy[u] * PC;
+    pc[u] = c;
+    pofs[u] = i < CIN * PR * PC ? (ppy[u] * PC + ppx[u]) * CIN + c : -1;
+  }
+  float pv[NLD];
+  auto load_patch = [&](int t) {
+    const int per_img = a.tiles_x * a.tiles_y;
+    const int n = t / per_img, tt = t - n * per_img;
+    const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+    const int iy0 = ty * TR * ST - PAD, ix0 = tx * TC * ST - PAD;
+    const float* xn = a.x + (long long)n * a.sN;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int iy = iy0 + ppy[u], ix = ix0 + ppx[u];
+      pv[u] = 0.f;
+      if (pofs[u] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+        pv[u] = xn[pc[u] * a.sC + iy * a.sH + ix * a.sW];
+    }
+  };
+  if ((int)blockIdx.x < a.ntiles) load_patch(blockIdx.x);
   for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
     const int per_img = a.tiles_x * a.tiles_y;
     const int n = t / per_img, tt = t - n * per_img;
     const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
     const int oy0 = ty * TR, ox0 = tx * TC;
-    const int iy0 = oy0 * ST - PAD, ix0 = ox0 * ST - PAD;
     __syncthreads();  // the previous tile's MFMA loop has left the patch (and the weights are in place)
-    // patch -> LDS: (c, row, col) with col fastest = the contiguous direction of an NCHW image; any strides work
-    const float* xn = a.x + (long long)n * a.sN;
-    for (int i = tid; i < CIN * PR * PC; i += 256) {
-      const int c = i / (PR * PC), rem = i - c * (PR * PC);
-      const int py = rem / PC, px = rem - py * PC;
-      const int iy = iy0 + py, ix = ix0 + px;
-      float v = 0.f;
-      if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = xn[c * a.sC + iy * a.sH + ix * a.sW];
-      patch[(py * PC + px) * CIN + c] = v;
-    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u)
+      if (pofs[u] >= 0) patch[pofs[u]] = pv[u];
     if (tid < 4) patch[PR * PC * CIN + tid] = 0.f;
     __syncthreads();
+    if (t + (int)gridDim.x < a.ntiles) load_patch(t + gridDim.x);
     f32x16 acc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -78,7 +114,7 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(const StemArgs a) {
     // wave wv = output row oy0 + wv; lane's pixel = column l31
     const float* prow = patch + ((wv * ST) * PC + l31 * ST) * CIN + lh;
     const float* brow = Bs + lh * NOUT + l31;
-#pragma unroll 1
+#pragma unroll
     for (int ky = 0; ky < KH; ++ky) {
       const float* pa = prow + ky * PC * CIN;
       const float* pb = brow + ky * KROW * NOUT;

@@ -60,7 +60,7 @@ class DetectorEngine:
         # Winograd F(2x2,3x3) for the stride-1 3x3 head convolutions (csrc/winograd.hip): layer i of both towers in
         # one launch.  False selects the direct implicit-GEMM kernel for every conv (A/B measurements, tests).
         self.winograd = True
-        # The 7x7 stem without the im2col matrix (csrc/stem_conv.hip: 136 us instead of 142 + 140).  'eval': forward
+        # The 7x7 stem without the im2col matrix (csrc/stem_conv.hip: 113 us instead of 142 + 140).  'eval': forward
         # passes that keep nothing for a backward pass (evaluation, inference) use it; a TRAINING step keeps the
         # im2col + GEMM pair -- its weight gradient contracts with the im2col matrix anyway (rebuilt on the side stream
         # when the forward pass did not write it: one more launch competing with the weight gradients there), the step

@@ -143,3 +143,49 @@ def test_sharded_evaluation_two_ranks_shared_gpu():
     mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     for r in (0, 1):
         assert ret[r][0] == single['results'] and ret[r][1] == single['image_ids']
+
+
+@pytest.mark.parametrize('kind', ['retina', 'fcos'])
+def test_single_image_detect_like_the_gradio_demo(kind):
+    """gradio_demo/3.gradio_detect_single_image.py::predict (SURVEY.md 8f-3's smoke test) on this path: ONE image, padded
+    to a multiple of 32 only (736 x 992: no multiple of the coarsest stride), model.eval(), decoder(outputs), then
+    boxes /= scale, keep classes > -1, clip to the original size.  The network outputs are compared with the CPU oracle
+    model (eval mode), the decoder with the oracle decoder on the SAME device outputs (bit-exact), the post-steps with
+    their NumPy statements.  Random init gives scores around the 0.01 prior: the threshold is set just below it so that
+    thousands of candidates reach the top-1000 selection and the NMS."""
+    from sacv_amd.detection import models, decode
+    fcos = kind == 'fcos'
+    H, W, scale, orig = 736, 992, 1.55, (470, 640)  # resized 728 x 992 image in a 736 x 992 canvas
+    img = np.zeros((1, 3, H, W), dtype=np.float32)
+    img[:, :, :728, :] = synth.images(9, 1, 728, W)
+    sd = omodel.init_retinanet_state(0, fcos=fcos)
+    net = models.__dict__['resnet50_fcos' if fcos else 'resnet50_retinanet']()
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    x = torch.tensor(img)
+    with torch.no_grad():
+        outs = net(x.cuda())
+        ref = (omodel.fcos_forward if fcos else omodel.retinanet_forward)({k: v.clone() for k, v in sd.items()}, x,
+                                                                          training=False)
+    for grp, rgrp in zip(outs, ref):
+        for o, r in zip(grp, rgrp):
+            assert tuple(o.shape) == tuple(r.shape)
+            assert float((o.cpu() - r).abs().max()) <= 2e-4 * max(1.0, float(r.abs().max()))
+    thr = 0.0099 if not fcos else 0.05
+    name = 'FCOSDecoder' if fcos else 'RetinaDecoder'
+    dec = decode.__dict__[name](min_score_threshold=thr)
+    scores, classes, boxes = dec(outs)
+    host = [[o.cpu().numpy() for o in grp] for grp in outs]
+    rs, rc, rb = (odecode.fcos_decode if fcos else odecode.retina_decode)(*host, min_score_threshold=thr)
+    assert np.array_equal(scores, rs) and np.array_equal(classes, rc) and np.array_equal(boxes, rb)
+    assert (classes[0] > -1).sum() >= 20, (classes[0] > -1).sum()
+    # the demo's post-steps, in its order
+    boxes /= scale
+    s, c, b = scores.squeeze(0), classes.squeeze(0), boxes.squeeze(0)
+    s, b, c = s[c > -1], b[c > -1], c[c > -1]
+    b[:, 0] = np.maximum(b[:, 0], 0)
+    b[:, 1] = np.maximum(b[:, 1], 0)
+    b[:, 2] = np.minimum(b[:, 2], orig[1])
+    b[:, 3] = np.minimum(b[:, 3], orig[0])
+    assert len(s) == len(b) == len(c) and np.all(b[:, 2] <= orig[1]) and np.all(b[:, 3] <= orig[0]) and np.all(b >= 0)
+    assert np.all(np.diff(s) <= 0)  # kept boxes come out in descending score

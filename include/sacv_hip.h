@@ -35,6 +35,8 @@ int sacv_abi_version(void);
 #define SACV_CF_MASK 16    /* result *= (mask > 0)  (ReLU backward fused) */
 #define SACV_CF_STATS 32   /* per-M-tile column sum / sum of squares of the stored values -> stats
                               (BatchNorm batch statistics of y; bias gradient when the output is a dy) */
+#define SACV_CF_AFFINE 128 /* with SACV_CF_BIAS: bias is [2][N], result = acc * bias[1][n] + bias[0][n]: an eval-mode
+                            BatchNorm (scale, shift from sacv_bn_fold_batched) folded into the convolution */
 
 /* Grouped implicit-GEMM convolution on the fp32 matrix cores.  mode 0 = forward
  * (src = x, w = pack kind 0), mode 1 = data gradient (src = dy, w = pack kind 1).
@@ -130,6 +132,9 @@ int sacv_stem_conv_fwd(const float* x, int Nb, int H, int W, long long sN, long 
                        const float* wpanel, int Kpad, float* y, int Ho, int Wo, float* stats, void* stream);
 
 /* ---- BatchNorm2d (classification/backbones/resnet.py:41; training mode batch statistics) ------------ */
+/* eval mode: (shift, scale) of every BatchNorm of a model in one launch, for SACV_CF_AFFINE.  jobs = device array of
+ * {const float* gamma, beta, running_mean, running_var; float* out; int C; int pad} (48 bytes), out = [2][C] */
+int sacv_bn_fold_batched(const void* jobs, int njobs, float eps, void* stream);
 long long sacv_bn_workspace_floats(int R, int C);
 int sacv_bn_train_stats(const float* y, int R, int C, float eps, float momentum, float* mean, float* invstd,
                         float* running_mean, float* running_var, long long* num_batches_tracked, float* workspace,

@@ -43,6 +43,7 @@ SIGNATURES = {
     'sacv_stem_conv_stats_rows': (I, [I, I, I]),
     'sacv_stem_conv_fwd': (I, [P, I, I, I, LL, LL, LL, LL, P, I, P, I, I, P, P]),
     'sacv_bn_workspace_floats': (LL, [I, I]),
+    'sacv_bn_fold_batched': (I, [P, I, F, P]),
     'sacv_bn_train_stats': (I, [P, I, I, F, F, P, P, P, P, P, P, P]),
     'sacv_bn_apply': (I, [P, P, P, P, P, P, P, LL, I, I, I, F, P]),
     'sacv_bn_train_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),

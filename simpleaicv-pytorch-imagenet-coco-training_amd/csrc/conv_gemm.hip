@@ -35,7 +35,8 @@
 #define CF_ACCUM 8
 #define CF_MASK 16
 #define CF_STATS 32
-#define CF_PUBLIC_MASK 63  // the flags the C ABI accepts
+#define CF_AFFINE 128  // bias is [2][N]: row 0 additive, row 1 multiplicative: v = acc * bias[1][n] + bias[0][n]
+#define CF_PUBLIC_MASK (63 | CF_AFFINE)  // the flags the C ABI accepts (64 is the bf16 entry point's SACV_CFH_OUT_F32)
 
 // Ablation switches (skip gathers / LDS stores / the K-loop barrier / fragment addressing) exist only in a
 // -DSACV_ABLATE diagnostic build (scripts/ablate_conv.py); the shipped kernel has none of them.
@@ -129,15 +130,19 @@ __device__ __forceinline__ void vec_epilogue(const ConvArgs& a, const TileCoord&
   const int N = a.N, M = P.M;
   const int n = tc.n0 + c4 * 4;
   const bool nok = n < N;  // N % 4 == 0
-  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sv = {1.f, 1.f, 1.f, 1.f};
   if ((flags & CF_BIAS) && nok) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+  // an eval-mode BatchNorm folded into the convolution: per-channel scale (gamma / sqrt(var + eps)) and shift
+  if ((flags & CF_AFFINE) && nok) sv = *reinterpret_cast<const f32x4*>(a.bias + N + n);
   f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
   const int hw = P.Hd * P.Wd;
 #pragma unroll 4
   for (int row = rr; row < BM; row += RS) {
     const int m = tc.m0 + row;
     if (!(nok && m < M)) continue;
-    f32x4 v = get_row(row, c4) + bv;
+    f32x4 v = get_row(row, c4);
+    if (flags & CF_AFFINE) v = v * sv;
+    v += bv;
     size_t orow = (size_t)m;
     if (P.remap_s > 0) {
       int nn = m / hw;
@@ -1161,6 +1166,7 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
   SACV_CHECK_ARG(sl >= 0, "conv2d_gemm: stride %d must be a power of two", stride);
   SACV_CHECK_ARG(mode == 0 || mode == 1, "conv2d_gemm: mode");
   SACV_CHECK_ARG(!(flags & CF_BIAS) || bias, "conv2d_gemm: bias flag without bias pointer");
+  SACV_CHECK_ARG(!(flags & CF_AFFINE) || (flags & CF_BIAS), "conv2d_gemm: SACV_CF_AFFINE needs SACV_CF_BIAS (bias = [2][N])");
   SACV_CHECK_ARG(remap_s == 0 || nprob == 1, "conv2d_gemm: remap only for single problems");
   SACV_CHECK_ARG((long long)N * KH * KW * Cs < (1LL << 30), "conv2d_gemm: weight panel too large");
   SACV_CHECK_ARG(N % 4 == 0, "conv2d_gemm: N=%d must be a multiple of 4", N);

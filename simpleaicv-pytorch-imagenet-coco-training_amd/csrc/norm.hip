@@ -429,6 +429,27 @@ static int bn_train_bwd_impl(const T* dz, const T* zmask, const T* y, const floa
   return SACV_OK;
 }
 
+// Eval-mode BatchNorm folded into the producing convolution's epilogue (SACV_CF_AFFINE): for every BatchNorm layer of a
+// model, out[0][c] = beta - mean * scale (shift), out[1][c] = scale = gamma / sqrt(var + eps).  One launch for all
+// layers: workgroup j handles record j of the table {gamma, beta, running_mean, running_var, out, C}.
+struct BnFoldJob {
+  const float* gamma;
+  const float* beta;
+  const float* mean;
+  const float* var;
+  float* out;  // [2][C]
+  int C, pad;
+};
+__global__ __launch_bounds__(256) void bn_fold_batched_kernel(const BnFoldJob* __restrict__ jobs, float eps) {
+  const BnFoldJob j = jobs[blockIdx.x];
+  for (int c = threadIdx.x; c < j.C; c += 256) {
+    const float is = 1.0f / sqrtf(j.var[c] + eps);  // as bn_apply's stat_is_var path
+    const float sc = is * j.gamma[c];
+    j.out[c] = j.beta[c] - j.mean[c] * sc;
+    j.out[j.C + c] = sc;
+  }
+}
+
 extern "C" {
 
 // floats of workspace needed by the BN kernels for a [R][C] activation
@@ -497,6 +518,17 @@ int sacv_bn_train_bwd_bf16(const void* dz, const void* zmask, const void* y, con
   return bn_train_bwd_impl<sacv_bf16>((const sacv_bf16*)dz, (const sacv_bf16*)zmask, (const sacv_bf16*)y, mean, invstd,
                                       gamma, beta, (sacv_bf16*)dy, (sacv_bf16*)g_out, dgamma, dbeta, R, C, accumulate,
                                       workspace, stream);
+}
+
+// jobs: device array of njobs records {const float* gamma, beta, running_mean, running_var; float* out /*[2][C]*/;
+// int C; int pad} (48 bytes): out[0] = shift, out[1] = scale of the eval-mode BatchNorm (classification/backbones/
+// resnet.py:41 in eval mode), the operand of SACV_CF_AFFINE.
+int sacv_bn_fold_batched(const void* jobs, int njobs, float eps, void* stream) {
+  SACV_CHECK_ARG(jobs && njobs > 0, "bn_fold_batched: bad args");
+  hipLaunchKernelGGL(bn_fold_batched_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream,
+                     (const BnFoldJob*)jobs, eps);
+  SACV_CHECK_LAUNCH("bn_fold_batched");
+  return SACV_OK;
 }
 
 }  // extern "C"

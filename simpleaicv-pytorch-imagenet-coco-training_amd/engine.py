@@ -68,6 +68,11 @@ class DetectorEngine:
         # the stem moves the 3-step AdamW fixture of SURVEY.md 8a-13 (1e-5 on the parameter norms) to 1.06e-5.
         # True forces it everywhere, False nowhere (tests, A/B).
         self.fused_stem = 'eval'
+        # Evaluation passes fold every BatchNorm into its convolution's epilogue (one batched launch computes the
+        # scales / shifts from the running statistics per forward pass): 53 bn_apply passes = 1.28 of the 8.9 ms of an
+        # eval forward + decode at 2 x 800x1333.  False: conv + bn_apply as in training (tests, A/B).
+        self.fold_bn = True
+        self._fold = None
         self._wino_cache = {}
         import os
         self._side, self._side_busy = None, False  # the weight gradients' stream (see _on_side)
@@ -241,6 +246,16 @@ class DetectorEngine:
             return z, c
         if training:  # batch statistics come out of the conv epilogue (no extra pass over y)
             (y,), st = ops.conv_gemm([x], wp, cout, k, k, stride, pad, 0, [hw], stats=True)
+        elif self._fold is not None and not keep:
+            # evaluation: BatchNorm with running statistics is a per-channel scale and shift -- applied in the conv's
+            # epilogue (SACV_CF_AFFINE) together with the ReLU; a residual block's last conv accumulates into the buffer
+            # that holds the shortcut (dead after this block in a pass that keeps nothing): no bn_apply pass at all
+            flags = ops.CF_AFFINE | (CF_RELU if relu else 0)
+            if residual is not None:
+                return ops.conv_gemm([x], wp, cout, k, k, stride, pad, 0, [hw], bias=self._fold.get(prefix),
+                                     flags=flags | CF_ACCUM, outs=[residual])[0], None
+            return ops.conv_gemm([x], wp, cout, k, k, stride, pad, 0, [hw], bias=self._fold.get(prefix),
+                                 flags=flags)[0], None
         else:
             y, st = ops.conv_gemm([x], wp, cout, k, k, stride, pad, 0, [hw])[0], None
         return self._bn_fwd(x, y, prefix, k, stride, pad, relu, training, residual, keep, st)
@@ -368,6 +383,7 @@ class DetectorEngine:
             else:
                 # fp32: the data-gradient panels are read by the backward pass only (which joins the side stream first)
                 self._on_side(self._refresh_dgrad_panels, [])
+        self._fold_prepare(training, keep)
         feats = self._backbone_fwd(images, training, keep, ctx)
         c3f, c4f, c5f = feats[1], feats[2], feats[3]
         fpn = self._fpn_fwd(c3f, c4f, c5f, ctx)
@@ -375,6 +391,21 @@ class DetectorEngine:
         if keep:
             self.ctx = ctx
         return outs
+
+    def _fold_prepare(self, training, keep):
+        """Scales / shifts of the eval-mode BatchNorm layers for this forward pass (None: not an evaluation pass)."""
+        if training or keep or self.amp or not self.fold_bn:
+            self._fold = None
+            return
+        f = getattr(self, '_fold_table', None)
+        if f is None or not f.is_current():
+            tail = '.layer.1.weight'
+            layers = [(k[:-len(tail)], self.p[k], self.p[k[:-len(tail)] + '.layer.1.bias'],
+                       self.p[k[:-len(tail)] + '.layer.1.running_mean'], self.p[k[:-len(tail)] + '.layer.1.running_var'])
+                      for k in self.p if k.endswith(tail)]
+            f = self._fold_table = ops.BnFold(layers, BN_EPS)
+        f.refresh()
+        self._fold = f
 
     def _backbone_fwd(self, images, training, keep, ctx):
         """ResNet trunk (classification/backbones/resnet.py:158-245): returns [C2, C3, C4, C5]."""
@@ -1062,6 +1093,7 @@ class ClassifierEngine(DetectorEngine):
         self._wino_cache = {}  # Winograd-domain weights are per forward (see DetectorEngine.forward)
         if keep:
             self._refresh_dgrad_panels()
+        self._fold_prepare(training, keep)
         c5 = self._backbone_fwd(images, training, keep, ctx)[3]
         pooled = ops.avgpool_fwd(c5)
         w, bias = self._fc_padded()

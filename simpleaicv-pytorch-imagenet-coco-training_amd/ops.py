@@ -12,6 +12,7 @@ from . import _lib
 from ._lib import lib, check, iarr, farr, parr
 
 CF_BIAS, CF_RELU, CF_SIGMOID, CF_ACCUM, CF_MASK, CF_STATS = 1, 2, 4, 8, 16, 32
+CF_AFFINE = 128  # bias = [2][N] (shift, scale): an eval-mode BatchNorm folded into the convolution
 CFH_OUT_F32 = 64  # bf16 convolution with an fp32 destination (the classifier's logits)
 BF16 = torch.bfloat16
 PACK_FWD, PACK_DGRAD, PACK_STEM = 0, 1, 2
@@ -925,6 +926,42 @@ def softmax_ce(logits, labels, want_grad=True, grad_scale=1.0):
 def sgd_step(params, grads, momentum_buf, split, lr, momentum, wd_lo, wd_hi, first_step, grad_scale=1.0):
     check(lib.sacv_sgd_step(_ptr(params), _ptr(grads), _ptr(momentum_buf), params.numel(), split, lr, momentum,
                             wd_lo, wd_hi, int(first_step), grad_scale, _stream()), 'sgd_step')
+
+
+class BnFold:
+    """(shift, scale) of the eval-mode BatchNorm layers of a model, recomputed by ONE launch per forward pass
+    (sacv_bn_fold_batched) and handed to the producing convolutions as their SACV_CF_AFFINE operand.  `layers`: list of
+    (key, gamma, beta, running_mean, running_var); `get(key)` -> the [2][C] tensor."""
+
+    def __init__(self, layers, eps):
+        import numpy as np
+        self.dev = layers[0][1].device
+        self.eps = eps
+        total = sum(2 * g.numel() for _, g, _, _, _ in layers)
+        self.buf = torch.empty(total, device=self.dev, dtype=torch.float32)
+        recs = np.zeros(len(layers), dtype=np.dtype([('g', '<u8'), ('b', '<u8'), ('m', '<u8'), ('v', '<u8'),
+                                                     ('o', '<u8'), ('c', '<i4'), ('pad', '<i4')]))
+        assert recs.dtype.itemsize == 48
+        self.views, self._keep, off = {}, [], 0
+        for i, (key, g, b, m, v) in enumerate(layers):
+            c = g.numel()
+            out = self.buf[off:off + 2 * c].view(2, c)
+            off += 2 * c
+            recs[i] = (g.data_ptr(), b.data_ptr(), m.data_ptr(), v.data_ptr(), out.data_ptr(), c, 0)
+            self.views[key] = out
+            self._keep += [g, b, m, v]
+        self.ptrs = [t.data_ptr() for t in self._keep]
+        self.n = len(layers)
+        self.descs = torch.from_numpy(recs.view(np.uint8).copy()).to(self.dev)
+
+    def is_current(self):
+        return all(t.data_ptr() == p for t, p in zip(self._keep, self.ptrs))
+
+    def refresh(self):
+        check(lib.sacv_bn_fold_batched(self.descs.data_ptr(), self.n, self.eps, _stream()), 'bn_fold_batched')
+
+    def get(self, key):
+        return self.views[key]
 
 
 class DgradPanels:

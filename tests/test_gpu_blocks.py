@@ -181,3 +181,41 @@ def test_stem_and_pool_bwd():
     ops.conv_wgrad([dy], [c.x], g['backbone.conv1.layer.0.weight'], 3, 1, 1, 1, 0, cin_pad=ops.STEM_KPAD, dw_taps=49)
     for k, pr in params.items():
         assert rel_l2(g[k].cpu(), pr.grad) <= 1e-4, k
+
+
+@pytest.mark.parametrize('kind', ['retina', 'fcos', 'retina18'])
+def test_eval_forward_with_folded_batchnorm(kind):
+    """Evaluation passes apply BatchNorm (running statistics) as a scale / shift in the convolution epilogue and
+    accumulate the last conv of a residual block into the shortcut's buffer (engine.fold_bn): against the same pass with
+    conv + bn_apply, and against the CPU oracle in eval mode.  Bottleneck and BasicBlock trunks; running statistics
+    away from (0, 1) so that the fold has something to do."""
+    from sacv_amd.detection import models
+    fcos = kind == 'fcos'
+    bb = 'resnet18backbone' if kind == 'retina18' else 'resnet50backbone'
+    sd = omodel.init_retinanet_state(0, fcos=fcos, backbone=bb)
+    for k in list(sd):
+        if k.endswith('running_mean'):
+            sd[k] = torch.from_numpy(synth.normal(len(k), tuple(sd[k].shape), std=0.2))
+        elif k.endswith('running_var'):
+            sd[k] = torch.from_numpy(synth.uniform(len(k) + 1, tuple(sd[k].shape), 0.5, 2.0))
+        elif k.endswith('layer.1.weight'):
+            sd[k] = torch.from_numpy(synth.uniform(len(k) + 2, tuple(sd[k].shape), 0.5, 1.5))
+        elif k.endswith('layer.1.bias'):
+            sd[k] = torch.from_numpy(synth.normal(len(k) + 3, tuple(sd[k].shape), std=0.1))
+    name = bb.replace('backbone', '') + ('_fcos' if fcos else '_retinanet')
+    net = models.__dict__[name]()
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    x = torch.tensor(synth.images(77, 2, 224, 288))
+    outs = {}
+    with torch.no_grad():
+        for fold in (True, False):
+            net._engine.fold_bn = fold
+            outs[fold] = [[o.clone() for o in grp] for grp in net(x.cuda())]
+        ref = (omodel.fcos_forward if fcos else omodel.retinanet_forward)({k: v.clone() for k, v in sd.items()}, x,
+                                                                          training=False)
+    for ga, gb, gr in zip(outs[True], outs[False], ref):
+        for a, b, r in zip(ga, gb, gr):
+            scale = max(1.0, float(r.abs().max()))
+            assert float((a - b).abs().max()) <= 2e-5 * scale
+            assert float((a.cpu() - r).abs().max()) <= 2e-4 * scale

@@ -382,13 +382,66 @@ def bench_decode(args, rank, world, ops, synth):
         dist.destroy_process_group()
 
 
+def bench_infer(args, rank, world, ops, synth):
+    """Secondary workload: evaluation / inference throughput -- model.eval() forward of a batch [2,3,H,W] under no_grad
+    (BatchNorm folded into the convolution epilogues, im2col-free stem) + the decoder on the device; what one iteration of
+    the reference's evaluate_coco_detection does per batch (tools/scripts.py:725-760) minus the host post-steps."""
+    import torch
+    import torch.distributed as dist
+    from sacv_amd.detection import models, decode
+    fcos = args.model == 'fcos_infer'
+    net = models.__dict__['resnet50_fcos' if fcos else 'resnet50_retinanet']().cuda().eval()
+    dec = decode.__dict__['FCOSDecoder' if fcos else 'RetinaDecoder'](nms_type=args.nms_type)
+    images = torch.tensor(synth.images(rank, BATCH, H, W)).cuda()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = dec.device_call(net(images))
+        sync()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(args.steps):
+            out = dec.device_call(net(images))
+            marks[i + 1].record()
+        sync()
+    elapsed = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    if world > 1:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    if rank == 0:
+        print(json.dumps({
+            'metric': f'images/sec/node {"FCOS" if fcos else "RetinaNet"}-R50 evaluation forward + decode/NMS {W}x{H} '
+                      f'bs={BATCH}/GPU (secondary)',
+            'value': round(world * BATCH * args.steps / elapsed, 2), 'unit': 'images/sec', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'ms_per_step_median': round(per_step[len(per_step) // 2], 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'model.eval() forward + {type(dec).__name__}({args.nms_type}) on the device, images '
+                                   f'[{BATCH},3,{H},{W}]/GPU, random init (scores sit at the 0.01 prior: the decoder '
+                                   'scans every prediction and selects none; its loaded latency is the *_decode workload)',
+                       'global_batch': world * BATCH, 'parallelism': f'replicas{world}'},
+            'roofline': None}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--model', default='retinanet', choices=['retinanet', 'fcos', 'resnet50_cls', 'vit_mae', 'retinanet_decode', 'fcos_decode'],
+    ap.add_argument('--model', default='retinanet', choices=['retinanet', 'fcos', 'resnet50_cls', 'vit_mae', 'retinanet_decode', 'fcos_decode', 'retinanet_infer',
+                             'fcos_infer'],
                     help='retinanet = the headline metric; fcos = secondary workload (BASELINE config 4); '
                          'resnet50_cls = ResNet50 ImageNet classification, bs 256/GPU, 224x224 (SURVEY.md 8f-1)')
     ap.add_argument('--nms-type', default='python_nms',
@@ -459,6 +512,8 @@ def main():
         return bench_mae(args, rank, world, group, ops, synth)
     if args.model.endswith('_decode'):
         return bench_decode(args, rank, world, ops, synth)
+    if args.model.endswith('_infer'):
+        return bench_infer(args, rank, world, ops, synth)
     if args.model == 'fcos':
         net = models.__dict__['resnet50_fcos'](backbone_pretrained_path='', num_classes=80).cuda().train()
         crit = losses.__dict__['FCOSLoss']()

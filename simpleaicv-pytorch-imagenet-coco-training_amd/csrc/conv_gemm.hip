@@ -1027,6 +1027,9 @@ struct NtPlan {
 #ifndef SACV_SK_EXTRA
 #define SACV_SK_EXTRA 6.0
 #endif
+#ifndef SACV_EPI_SPLIT
+#define SACV_EPI_SPLIT 7.0
+#endif
 #ifndef SACV_SK_MIN_ITERS
 #define SACV_SK_MIN_ITERS 4  // a stream-K range shorter than this is not worth its slab + fix-up
 #endif
@@ -1035,7 +1038,7 @@ struct NtPlan {
 // one K-iteration of this tile shape (1.0 for 128x128, ~0.6 for 128x64).  The split-K workspace holds two
 // slabs per workgroup (sacv_conv2d_gemm_workspace_bytes).
 static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w) {
-  const double epi = 3.0, epi_split = 7.0;  // epilogue / slab write + fix-up, in K-iterations
+  const double epi = 3.0, epi_split = SACV_EPI_SPLIT;  // epilogue / slab write + fix-up, in K-iterations
   NtPlan p;
   p.base = tiles / grid;
   p.rem = tiles - p.base * grid;

@@ -811,6 +811,8 @@ MAE_CFGS = {
     'tiny': (dict(patch=16, image=64, E=128, Le=2, He=4, D=64, Ld=1, Hd=4), 4),
     'base_d2': (dict(patch=16, image=224, E=768, Le=2, He=12, D=512, Ld=1, Hd=16), 4),
     'base': (dict(patch=16, image=224, E=768, Le=12, He=12, D=512, Ld=8, Hd=16), 2),
+    # the widths of vit_large_patch16_224_mae_pretrain_model (vit_mae.py: 1024 x 24 blocks x 16 heads), two blocks deep
+    'large_d2': (dict(patch=16, image=224, E=1024, Le=2, He=16, D=512, Ld=1, Hd=16), 4),
 }
 
 

@@ -137,7 +137,7 @@ def test_attention_core_fwd_bwd(b, n, heads, d, mfma):
     assert err <= 1.5e-2, err                                   # rel-L2 with bf16 S / P / dP / dS inside
 
 
-@pytest.mark.parametrize('name', ['tiny', 'base_d2', 'base'])
+@pytest.mark.parametrize('name', ['tiny', 'base_d2', 'base', 'large_d2'])
 def test_mae_step_against_reference(golden_dir, name):
     from sacv_amd.masked_image_modeling import models, losses
     meta = json.load(open(os.path.join(golden_dir, 'mae.json')))[name]

@@ -18,7 +18,7 @@ def mae_inputs(cfg, B):
     return images
 
 
-@pytest.mark.parametrize('name', ['tiny', 'base_d2'])
+@pytest.mark.parametrize('name', ['tiny', 'base_d2', 'large_d2'])
 def test_oracle_mae_matches_reference(golden_dir, name):
     meta = json.load(open(os.path.join(golden_dir, 'mae.json')))[name]
     arrs = np.load(os.path.join(golden_dir, 'mae.npz'))

@@ -563,6 +563,35 @@ def test_decoder_dense_suppression(ops, nms_type):
             assert kept.max() < 600 and kept.min() > 20, kept  # real suppression, beyond the first blocks
 
 
+@pytest.mark.parametrize('B,num_classes,topn,max_obj,hw', [(5, 80, 300, 50, (96, 128)), (1, 508, 1000, 100, (64, 64)),
+                                                             (16, 4, 64, 64, (32, 32)), (3, 20, 1, 1, (96, 128))])
+def test_decoder_argument_corners(ops, B, num_classes, topn, max_obj, hw):
+    """Corners of the decoder's argument space: odd batch sizes up to 16 images, topn / max_object_num far below the
+    defaults (down to 1), the widest class count the 32-prediction tiles take (508), 4 classes (one float4 per row),
+    pyramids whose upper levels are single pixels (a level smaller than one tile), images without candidates."""
+    from sacv_amd.detection import decode
+    H, W = hw
+    fs = synth.feature_sizes(H, W)
+    cls = [(synth.uniform(300 + l, (B, fh, fw, 9, num_classes)) * 0.04).astype(np.float32) for l, (fw, fh) in enumerate(fs)]
+    reg = [synth.normal(310 + l, (B, fh, fw, 9, 4), std=0.25) for l, (fw, fh) in enumerate(fs)]
+    q = 0
+    for l, c in enumerate(cls):
+        flat = c.reshape(B, -1, num_classes)
+        for b in range(B):
+            if b == 1:
+                continue  # image 1: nothing above the threshold
+            for a in range(b % 3, flat.shape[1], 3 + b % 2):
+                q += 1
+                flat[b, a, (q * 5) % num_classes] = np.float32(0.06 + 0.9 * ((q * 7919) % 100003) / 100003.0)
+    dec = decode.__dict__['RetinaDecoder'](topn=topn, max_object_num=max_obj, nms_threshold=0.5)
+    s, c, b = dec([[torch.tensor(x).cuda() for x in cls], [torch.tensor(x).cuda() for x in reg]])
+    rs, rc, rb = odecode.retina_decode(cls, reg, topn=topn, max_object_num=max_obj, nms_threshold=0.5)
+    assert s.shape == (B, max_obj) and b.shape == (B, max_obj, 4)
+    assert np.array_equal(s, rs) and np.array_equal(c, rc) and np.array_equal(b, rb)
+    if B > 1:
+        assert (c[1] == -1).all() and (c[0] > -1).any()
+
+
 def test_fcos_decoder_soft_nms_and_edge_cases(ops):
     """FCOS front end + Soft-NMS; an image without any score above the threshold; max_object_num larger than the
     number of survivors; a prune level that removes everything a decay touches (== hard suppression at >= thr)."""

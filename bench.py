@@ -461,6 +461,16 @@ def main():
                     help='bf16: the autocast recipe of resnet50_cls (BASELINE config #2); the detection recipes run '
                          'fp32 (use_amp=False in their train_config.py)')
     args = ap.parse_args()
+    # stdout carries the ONE JSON line of the contract and nothing else: the model constructors mirror the reference's
+    # `print('no backbone pretrained model!')` (detection/models/backbones/resnet.py:122), which goes to stderr here
+    import builtins
+    _print = builtins.print
+
+    def _print_json_only(*a, **k):
+        if k.get('file') is None and not (len(a) == 1 and isinstance(a[0], str) and a[0].startswith('{')):
+            k['file'] = sys.stderr
+        return _print(*a, **k)
+    builtins.print = _print_json_only
     if args.model == 'vit_mae':
         args.dtype = 'bf16'  # the MAE recipe runs under autocast (use_amp=True); there is no fp32 engine for it
     if args.dtype == 'bf16' and args.model not in ('resnet50_cls', 'vit_mae'):

@@ -2,6 +2,9 @@
 # One profiling session on the GPU box (run through gpurun); raw outputs land in gpurun_out/prof_$TAG/ and are turned
 # into profiles/$TAG_* by scripts/make_profile_summary.py in the build container.
 #   gpurun --timeout 1200 -- 'bash scripts/profile_session.sh r03'
+# (the decode + NMS latency lines and the evaluation-pass lines come from scripts/decode_session.sh and
+#  `bench.py --model retinanet_infer`; scripts/make_decode_summary.py appends their section to the summary -- run it
+#  AFTER make_profile_summary.py, which rewrites the file)
 set -e -o pipefail
 TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG

@@ -592,6 +592,28 @@ def test_decoder_argument_corners(ops, B, num_classes, topn, max_obj, hw):
         assert (c[1] == -1).all() and (c[0] > -1).any()
 
 
+@pytest.mark.parametrize('fcos', [False, True])
+def test_decoder_dense_candidate_lists(ops, fcos):
+    """min_score_threshold = 0: EVERY prediction is a candidate (15 354 / 1 706 per image at 256 x 320; more than the
+    8 192 keys the selection keeps in registers for RetinaNet, so it walks the segments instead), with hundreds of exactly
+    equal scores among them (maxima of 24-bit uniform noise): top-1000, order (ties by ascending prediction index) and
+    NMS result bit-exact vs the oracle."""
+    from sacv_amd.detection import decode
+    H, W = gi.SHAPES['MID']
+    preds = gi.synth_preds_decode(33, 2, H, W, fcos=fcos)
+    for p_ in preds[0]:
+        p_ *= 0.0
+        p_ += (synth.uniform(p_.size % 977, p_.shape) * 0.04).astype(np.float32) + np.float32(1e-3)
+    name = 'FCOSDecoder' if fcos else 'RetinaDecoder'
+    for M in (100, 1000):
+        dec = decode.__dict__[name](min_score_threshold=0.0, max_object_num=M)
+        s, c, b = dec([[torch.tensor(x).cuda() for x in grp] for grp in preds])
+        rs, rc, rb = (odecode.fcos_decode if fcos else odecode.retina_decode)(*preds, min_score_threshold=0.0,
+                                                                             max_object_num=M)
+        assert np.array_equal(s, rs) and np.array_equal(c, rc) and np.array_equal(b, rb), (fcos, M)
+    assert (rs[0] >= 0).sum() > 100
+
+
 def test_fcos_decoder_soft_nms_and_edge_cases(ops):
     """FCOS front end + Soft-NMS; an image without any score above the threshold; max_object_num larger than the
     number of survivors; a prune level that removes everything a decay touches (== hard suppression at >= thr)."""

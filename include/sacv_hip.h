@@ -297,6 +297,11 @@ int sacv_adamw_step_gated(float* params, const float* grads, float* exp_avg, flo
 int sacv_sgd_step_gated(float* params, const float* grads, float* momentum_buf, long long n, long long split,
                         float lr_lo, float lr_hi, float momentum, float wd_lo, float wd_hi, int nesterov,
                         const float* state, float grad_scale, float clip_value, void* stream);
+/* EmaModel.update (tools/utils.py:150-163) over a flat block: ema = decay * ema + one_minus_decay * model in torch's
+ * arithmetic (the caller passes float32(decay) and float32(1. - decay), two products and a sum, each rounded); state
+ * (optional): the step state of sacv_step_gate -- nothing is written when the step was skipped */
+int sacv_ema_update(float* ema, const float* model, long long n, float decay, float one_minus_decay, const float* state,
+                    void* stream);
 int sacv_fill(float* p, long long n, float value, void* stream);
 
 /* ---- data-parallel exchange over RCCL / xGMI (replaces nn.parallel.DistributedDataParallel of

@@ -84,6 +84,7 @@ SIGNATURES = {
     'sacv_grad_clip_coef': (I, [P, LL, F, F, F, P, P, P]),
     'sacv_adamw_step_gated': (I, [P, P, P, P, LL, LL, F, F, F, F, F, F, F, P, F, F, P]),
     'sacv_sgd_step_gated': (I, [P, P, P, LL, LL, F, F, F, F, F, I, P, F, F, P]),
+    'sacv_ema_update': (I, [P, P, LL, F, F, P, P]),
     'sacv_adamw_step': (I, [P, P, P, P, LL, LL, F, F, F, F, F, F, I, F, P]),
     'sacv_fill': (I, [P, LL, F, P]),
     'sacv_conv2d_gemm_bf16': (I, [P, P, I, I, I, I, I, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, P]),

@@ -170,6 +170,25 @@ __global__ void fill_kernel(float* __restrict__ p, size_t n, float value) {
     p[i] = value;
 }
 
+// EmaModel.update (tools/utils.py:156-163): ema = decay * ema + (1 - decay) * model, elementwise over a flat block, in
+// torch's arithmetic: both scalars arrive already rounded to fp32 (torch rounds the Python floats `decay` and
+// `1. - decay` to the tensor's dtype), two multiplications and one addition, each rounded (-ffp-contract=off).
+__global__ __launch_bounds__(256) void ema_update_kernel(float* __restrict__ ema, const float* __restrict__ model,
+                                                          size_t n, float decay, float one_minus_decay,
+                                                          const float* __restrict__ state) {
+  if (state && state[1] > 0.f) return;  // the step was skipped (sacv_step_gate): the reference `continue`s before its update
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 e = *reinterpret_cast<const f32x4*>(ema + i * 4), m = *reinterpret_cast<const f32x4*>(model + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = decay * e[k] + one_minus_decay * m[k];
+    *reinterpret_cast<f32x4*>(ema + i * 4) = o;
+  }
+  const size_t t = (n4 << 2) + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) ema[t] = decay * ema[t] + one_minus_decay * model[t];
+}
+
 extern "C" {
 
 // n must be a multiple of 4 (the arena pads every tensor to 4 floats); split likewise.
@@ -262,6 +281,17 @@ int sacv_fill(float* p, long long n, float value, void* stream) {
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, (size_t)n, value);
   SACV_CHECK_LAUNCH("fill");
+  return SACV_OK;
+}
+
+int sacv_ema_update(float* ema, const float* model, long long n, float decay, float one_minus_decay, const float* state,
+                    void* stream) {
+  SACV_CHECK_ARG(ema && model && n > 0, "ema_update: bad args");
+  SACV_CHECK_ARG((((size_t)ema | (size_t)model) & 15) == 0, "ema_update: blocks must be 16-byte aligned");
+  const long long blocks = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(ema_update_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 8192 ? 8192 : blocks))), dim3(256), 0,
+                     (hipStream_t)stream, ema, model, (size_t)n, decay, one_minus_decay, state);
+  SACV_CHECK_LAUNCH("ema_update");
   return SACV_OK;
 }
 

@@ -90,3 +90,19 @@ class ParamArena:
         """Expose the gradient arena as p.grad (no copies)."""
         for n, p in self.order:
             p.grad = self.grad_views[n]
+
+
+def deepcopy_without_runtime(self, memo):
+    """`copy.deepcopy(model)` -- what the reference's EmaModel does with the model (tools/utils.py:150-153): the copy gets
+    the module tree, parameters and buffers; the flat arenas and the executor (HIP streams, events, scratch) are RUNTIME
+    state and are rebuilt for the copy (lazily at its first use, or at once when the model sits on the GPU)."""
+    import copy
+    runtime = ('_arena', '_engine', '_param_list', '_last_outputs')
+    new = type(self).__new__(type(self))
+    memo[id(self)] = new
+    for k, v in self.__dict__.items():
+        new.__dict__[k] = None if k in runtime else copy.deepcopy(v, memo)
+    p = next(new.parameters(), None)
+    if p is not None and p.device.type == 'cuda' and hasattr(new, 'prepare'):
+        new.prepare()
+    return new

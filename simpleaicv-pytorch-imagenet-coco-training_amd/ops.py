@@ -923,6 +923,17 @@ def softmax_ce(logits, labels, want_grad=True, grad_scale=1.0):
     return loss, dl
 
 
+def ema_update(ema_flat, model_flat, decay, gate=None):
+    """ema = decay * ema + (1. - decay) * model over two flat fp32 blocks of the same layout, with torch's roundings of
+    the two Python-float scalars (tools/utils.py:156)."""
+    import numpy as np
+    if ema_flat.numel() != model_flat.numel():
+        raise ValueError('ema_update: the two blocks differ in size (wrong ema model!)')
+    check(lib.sacv_ema_update(_ptr(_chk(ema_flat, 'ema block')), _ptr(_chk(model_flat, 'model block')), ema_flat.numel(),
+                              float(np.float32(decay)), float(np.float32(1. - decay)), _ptr(gate), _stream()),
+          'ema_update')
+
+
 def sgd_step(params, grads, momentum_buf, split, lr, momentum, wd_lo, wd_hi, first_step, grad_scale=1.0):
     check(lib.sacv_sgd_step(_ptr(params), _ptr(grads), _ptr(momentum_buf), params.numel(), split, lr, momentum,
                             wd_lo, wd_hi, int(first_step), grad_scale, _stream()), 'sgd_step')

@@ -58,6 +58,7 @@ class _StepDriver:
         self.flag = torch.zeros(1, device=dev, dtype=torch.float32)
         self.accum = torch.zeros_like(arena.grads) if self.accumulation_steps > 1 else None
         self.micro = 0       # micro-batches accumulated in the current window
+        self.ema_model = None  # a utils.EmaModel: updated after every optimizer step (tools/scripts.py:1013-1015)
         self.iter_index = 1  # the reference's iter_index (advances only on iterations that are not skipped)
         if hasattr(transport, 'all_reduce') and hasattr(transport, 'wait') and hasattr(transport, 'broadcast'):
             self.comm = transport if self.world > 1 else None  # a caller-built communicator with RcclComm's surface
@@ -296,6 +297,8 @@ class DetectionTrainer(_StepDriver):
                                  self.betas[0], self.betas[1], self.eps, g1['weight_decay'], g2['weight_decay'],
                                  self.state, grad_scale=1.0 / self.world, clip_value=self.clip_grad_value,
                                  lr_hi=g2['lr'])
+            if self.ema_model is not None:
+                self.ema_model.update(self.model, gate=self.state)
             self.micro = 0
         self.iter_index += 1
         return out
@@ -351,6 +354,8 @@ class MAETrainer(DetectionTrainer):
                                  self.betas[0], self.betas[1], self.eps, g1['weight_decay'], g2['weight_decay'],
                                  self.state, grad_scale=1.0 / self.world, clip_value=self.clip_grad_value,
                                  lr_hi=g2['lr'])
+            if self.ema_model is not None:
+                self.ema_model.update(self.model, gate=self.state)
             self.micro = 0
         self.iter_index += 1
         return out
@@ -405,6 +410,8 @@ class ClassificationTrainer(_StepDriver):
             ops.sgd_step_gated(arena.params, arena.grads, self.momentum_buf, arena.split, g1['lr'], self.momentum,
                                g1['weight_decay'], g2['weight_decay'], self.state, grad_scale=1.0 / self.world,
                                clip_value=self.clip_grad_value, lr_hi=g2['lr'], nesterov=self.nesterov)
+            if self.ema_model is not None:
+                self.ema_model.update(self.model, gate=self.state)
             self.micro = 0
         self.iter_index += 1
         return out

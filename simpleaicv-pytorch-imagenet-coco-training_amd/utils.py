@@ -8,7 +8,7 @@ is bit-identical (tests/golden/scheduler.json).
 """
 import math
 
-__all__ = ['Scheduler', 'build_trainer']
+__all__ = ['Scheduler', 'build_trainer', 'EmaModel']
 
 
 class Scheduler:
@@ -53,6 +53,50 @@ class Scheduler:
         self.__dict__.update(state_dict)
 
 
+class EmaModel:
+    """tools/utils.py:136-163: an exponential moving average of the model's whole state_dict,
+    ema = decay * ema + (1 - decay) * model after every optimizer step (tools/scripts.py:1013-1015).
+
+    `ema_model` is a deep copy of the model in eval mode, as in the reference (and what its evaluation loop runs,
+    scripts.py:839-840).  `update` is TWO launches over the flat blocks the models keep their state in -- the parameter
+    arena and the BatchNorm statistics block -- instead of a Python loop over 354 tensors; the integer buffers
+    (num_batches_tracked) and any tensor outside the blocks (frozen position tables) take the reference's own statement.
+    Bit-identical to the reference's loop."""
+
+    def __init__(self, model, decay=0.9999):
+        import copy
+        self.ema_model = copy.deepcopy(model)
+        self.ema_model.eval()
+        self.decay = decay
+        self.update_fn = lambda e, m: self.decay * e + (1. - self.decay) * m
+
+    def update(self, model, gate=None):
+        """gate: a trainer's device-side step state -- when the step it describes was skipped (inf / nan / zero loss,
+        the cross-rank vote) nothing moves, like the reference's `continue` ahead of its update (scripts.py:968-974)."""
+        import torch
+        from . import ops
+        ea, ma = self.ema_model.arena, model.arena
+        with torch.no_grad():
+            ops.ema_update(ea.params, ma.params, self.decay, gate)
+            if ea.buffers.numel():
+                ops.ema_update(ea.buffers, ma.buffers, self.decay, gate)
+            esd, msd = self.ema_model.state_dict(keep_vars=True), model.state_dict(keep_vars=True)
+            arena_names = {n for n, _ in ea.order} | {n for n, _ in ea.buffer_order}
+            for (k, ev), mv in zip(esd.items(), msd.values()):
+                assert ev.shape == mv.shape, 'wrong ema model!'
+                if k not in arena_names:
+                    new = self.update_fn(ev.data, mv.data)
+                    if gate is not None:
+                        new = torch.where(gate[1] > 0, ev.data.to(new.dtype), new)
+                    ev.data.copy_(new)
+
+    def state_dict(self):
+        return self.ema_model.state_dict()
+
+    def load_state_dict(self, sd):
+        return self.ema_model.load_state_dict(sd)
+
+
 def build_trainer(config, model, criterion, process_group=None, transport='torch'):
     """What build_optimizer (tools/utils.py:275-582) + build_training_mode (:166-185) set up for the step, for the
     configurations this path supports: optimizer ('AdamW' for detection, 'SGD' for classification), two weight-decay
@@ -71,22 +115,29 @@ def build_trainer(config, model, criterion, process_group=None, transport='torch
                   clip_grad_value=getattr(config, 'clip_grad_value', 0.0) or 0.0,
                   clip_max_norm=getattr(config, 'clip_max_norm', 0.0) or 0.0,
                   skip_inf_nan_grad=getattr(config, 'skip_inf_nan_grad', False), transport=transport)
+    def with_ema(trainer):  # build_training_mode's EmaModel (tools/utils.py:172-177): config.ema_model, updated by the step
+        if getattr(config, 'use_ema_model', False):
+            config.ema_model = EmaModel(model, decay=config.ema_model_decay)
+            trainer.ema_model = config.ema_model
+        return trainer
+
     # the trainer follows the MODEL (which step signature and loss call apply), the optimizer follows the config
     if isinstance(model, VITMAEPretrainModel):
         if name != 'AdamW':
             raise NotImplementedError('the MAE pre-training step is built on the fused AdamW kernel')
         # the MAE recipe runs autocast (use_amp=True); this engine's Linear layers are bf16 GEMMs in either case
-        return MAETrainer(model, criterion, betas=(prm.get('beta1', 0.9), prm.get('beta2', 0.999)),
-                          eps=prm.get('eps', 1e-8), **common)
+        return with_ema(MAETrainer(model, criterion, betas=(prm.get('beta1', 0.9), prm.get('beta2', 0.999)),
+                                   eps=prm.get('eps', 1e-8), **common))
     if hasattr(model, 'fpn'):  # RetinaNet / FCOS
         if name != 'AdamW':
             raise NotImplementedError('the detection step is built on the fused AdamW kernel')
         if getattr(config, 'use_amp', False):
             raise NotImplementedError('use_amp on the detection path (the graded recipes run fp32, '
                                       '3.detection_training/coco/res50_retinanet_retinaresize800/train_config.py:151)')
-        return DetectionTrainer(model, criterion, betas=(prm.get('beta1', 0.9), prm.get('beta2', 0.999)),
-                                eps=prm.get('eps', 1e-8), **common)
+        return with_ema(DetectionTrainer(model, criterion, betas=(prm.get('beta1', 0.9), prm.get('beta2', 0.999)),
+                                         eps=prm.get('eps', 1e-8), **common))
     if name != 'SGD':
         raise NotImplementedError('the classification step is built on the fused SGD kernel')
-    return ClassificationTrainer(model, criterion, momentum=prm['momentum'], nesterov=prm.get('nesterov', False),
-                                 use_amp=getattr(config, 'use_amp', None), **common)
+    return with_ema(ClassificationTrainer(model, criterion, momentum=prm['momentum'],
+                                          nesterov=prm.get('nesterov', False),
+                                          use_amp=getattr(config, 'use_amp', None), **common))

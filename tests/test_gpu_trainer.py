@@ -232,3 +232,88 @@ def test_guard_and_clip_kernels_vs_torch():
         wd[:1024] = 0.0
         want = p0 * (1 - lr * wd) - lr / 0.1 * (0.1 * geff) / ((0.001 * geff * geff).sqrt() / 0.001**0.5 + 1e-8)
         torch.testing.assert_close(p, want, rtol=1e-5, atol=1e-7)
+
+
+def _small_models():
+    from sacv_amd.detection import models
+    from sacv_amd.classification import backbones
+    from sacv_amd.masked_image_modeling import models as mm
+    yield 'resnet18_fcos', lambda: models.__dict__['resnet18_fcos']()
+    yield 'resnet18cifar', lambda: backbones.__dict__['resnet18cifar'](num_classes=10)
+    yield 'mae_tiny', lambda: mm.VITMAEPretrainModel(patch_size=16, image_size=64, encoder_embedding_planes=128,
+                                                     encoder_block_nums=2, encoder_head_nums=4,
+                                                     decoder_embedding_planes=64, decoder_block_nums=1,
+                                                     decoder_head_nums=4)
+
+
+@pytest.mark.parametrize('name', ['resnet18_fcos', 'resnet18cifar', 'mae_tiny'])
+def test_ema_model_like_the_reference(name):
+    """tools/utils.py:136-163 (EmaModel) + its call site tools/scripts.py:1013-1015: `copy.deepcopy(model)` works on the
+    HIP models (the copy owns fresh arenas and a fresh executor, the original is untouched), and `update` -- two launches
+    over the flat blocks -- leaves EVERY state_dict entry (parameters, BatchNorm statistics, the integer
+    num_batches_tracked, frozen tables) bit-identical to the reference's per-tensor statement evaluated by torch on the
+    CPU, over three updates with moving model weights."""
+    import copy
+    from sacv_amd.utils import EmaModel
+    make = dict(_small_models())[name]
+    torch.manual_seed(3)
+    net = make().cuda().train()
+    ema = EmaModel(net, decay=0.9999)
+    assert not ema.ema_model.training and ema.ema_model is not net
+    a, b = net.state_dict(), ema.ema_model.state_dict()
+    assert list(a) == list(b) and all(torch.equal(a[k], b[k]) and a[k].data_ptr() != b[k].data_ptr() for k in a)
+    ref = {k: v.detach().cpu().clone() for k, v in b.items()}
+    g = torch.Generator().manual_seed(7)
+    for it in range(3):
+        with torch.no_grad():  # the optimizer and the BatchNorm layers move the model
+            for k, v in net.state_dict().items():
+                if v.dtype.is_floating_point:
+                    v.add_(torch.randn(v.shape, generator=g).to(v.device) * 0.05)
+                else:
+                    v.add_(3 + it)
+        ema.update(net)
+        for k, mv in net.state_dict().items():
+            e, m = ref[k], mv.detach().cpu()
+            ref[k] = e.copy_(0.9999 * e + (1. - 0.9999) * m)  # the reference's update_fn + copy_
+    got = ema.ema_model.state_dict()
+    for k in ref:
+        assert torch.equal(got[k].cpu(), ref[k]), k
+    # the copy is a working model of its own
+    if name == 'resnet18cifar':
+        with torch.no_grad():
+            y = ema.ema_model(torch.rand(2, 3, 32, 32).cuda())
+        assert tuple(y.shape) == (2, 10) and bool(torch.isfinite(y).all())
+    c2 = copy.deepcopy(ema.ema_model)
+    assert all(torch.equal(u, v) for u, v in zip(c2.state_dict().values(), got.values()))
+
+
+def test_trainer_updates_the_ema_model_and_respects_the_skip_gate():
+    """build_trainer with config.use_ema_model (tools/utils.py:172-177): the EMA model follows every optimizer step
+    (tools/scripts.py:1013-1015) and stays put on a skipped batch (zero loss: the reference `continue`s at :968-974)."""
+    from sacv_amd.detection import models, losses
+    from sacv_amd import utils as U
+
+    class Cfg:
+        optimizer = ('AdamW', {'lr': 1e-3, 'weight_decay': 1e-3, 'global_weight_decay': False})
+        use_ema_model, ema_model_decay = True, 0.99
+    H, W = gi.TINY
+    net = models.__dict__['resnet18_retinanet']().cuda().train()
+    cfg = Cfg()
+    tr = U.build_trainer(cfg, net, losses.__dict__['RetinaLoss']())
+    assert tr.ema_model is cfg.ema_model and isinstance(cfg.ema_model, U.EmaModel)
+    images = torch.tensor(synth.images(1, 2, H, W)).cuda()
+    boxes = torch.tensor(synth.annotations(2, 2, H, W, boxes_per_image=4)).cuda()
+    empty = torch.tensor(synth.annotations(2, 2, H, W, boxes_per_image=0)).cuda()
+    e0 = {k: v.clone() for k, v in cfg.ema_model.state_dict().items()}
+    p0 = {k: v.clone() for k, v in net.state_dict().items()}
+    fin = tr.finish_step(tr.step(images, boxes))
+    assert not fin['skipped']
+    e1 = {k: v.clone() for k, v in cfg.ema_model.state_dict().items()}
+    for k, v in net.state_dict().items():  # ema_1 = d e_0 + (1 - d) p_1, the reference's statement on the CPU
+        want = 0.99 * e0[k].cpu() + (1. - 0.99) * v.cpu()
+        assert torch.equal(e1[k].cpu(), e0[k].cpu().copy_(want)), k
+    assert any(not torch.equal(e1[k], e0[k]) for k in e1) and any(not torch.equal(p0[k], v) for k, v in net.state_dict().items())
+    fin = tr.finish_step(tr.step(images, empty))  # no positive anchor: zero loss -> skipped
+    assert fin['skipped']
+    for k, v in cfg.ema_model.state_dict().items():
+        assert torch.equal(v, e1[k]), k

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from ...engine import ClassifierEngine
-from ...detection.models._arena import ParamArena, deepcopy_without_runtime
+from ...detection.models._arena import ParamArena, deepcopy_without_runtime, getstate_without_runtime
 from ...detection.models._base import _resnet_trunk
 
 __all__ = ['resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152', 'ResNet']
@@ -31,6 +31,7 @@ class _ClassifierFunction(torch.autograd.Function):
 
 class ResNet(nn.Module):
     __deepcopy__ = deepcopy_without_runtime
+    __getstate__ = getstate_without_runtime
 
     STEM = 'imagenet'
 

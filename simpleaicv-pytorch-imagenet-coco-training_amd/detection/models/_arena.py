@@ -106,3 +106,13 @@ def deepcopy_without_runtime(self, memo):
     if p is not None and p.device.type == 'cuda' and hasattr(new, 'prepare'):
         new.prepare()
     return new
+
+
+_RUNTIME_ATTRS = ('_arena', '_engine', '_param_list', '_last_outputs')
+
+
+def getstate_without_runtime(self):
+    """pickle / torch.save(model): the module tree, parameters and buffers travel; arenas and executor are rebuilt on
+    first use after loading (the reference's checkpoints hold state_dicts, tools/scripts.py:1080-1100, but whole-model
+    saves must not crash on HIP streams either)."""
+    return {k: (None if k in _RUNTIME_ATTRS else v) for k, v in self.__dict__.items()}

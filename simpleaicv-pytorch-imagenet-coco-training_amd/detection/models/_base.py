@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from ...engine import DetectorEngine, RESNET50_LAYERS
-from ._arena import ParamArena, deepcopy_without_runtime
+from ._arena import ParamArena, deepcopy_without_runtime, getstate_without_runtime
 
 def _conv_bn_act(cin, cout, k, stride, pad, act=True):
     """Container with the key layout of ConvBnActBlock: layer.0 = conv (no bias), layer.1 = BN."""
@@ -139,6 +139,7 @@ class HipDetector(nn.Module):
     """nn.Module whose forward is the HIP executor.  Subclasses build the parameter containers and set
     `_fcos`; there is no non-HIP execution path."""
     __deepcopy__ = deepcopy_without_runtime
+    __getstate__ = getstate_without_runtime
     _fcos = False
     num_anchors = 1
 

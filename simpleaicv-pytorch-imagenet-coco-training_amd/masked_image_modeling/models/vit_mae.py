@@ -6,7 +6,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ...detection.models._arena import ParamArena, deepcopy_without_runtime
+from ...detection.models._arena import ParamArena, deepcopy_without_runtime, getstate_without_runtime
 from ...mae_engine import MAEEngine
 
 __all__ = ['vit_base_patch16_224_mae_pretrain_model', 'vit_large_patch16_224_mae_pretrain_model',
@@ -84,6 +84,7 @@ class _MAEFunction(torch.autograd.Function):
 
 class VITMAEPretrainModel(nn.Module):
     __deepcopy__ = deepcopy_without_runtime
+    __getstate__ = getstate_without_runtime
 
     def __init__(self, patch_size=16, image_size=224, mask_ratio=0.75, encoder_embedding_planes=768,
                  encoder_block_nums=12, encoder_head_nums=12, encoder_feedforward_ratio=4, encoder_dropout_prob=0.,

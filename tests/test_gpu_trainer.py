@@ -317,3 +317,20 @@ def test_trainer_updates_the_ema_model_and_respects_the_skip_gate():
     assert fin['skipped']
     for k, v in cfg.ema_model.state_dict().items():
         assert torch.equal(v, e1[k]), k
+
+
+def test_models_survive_pickle():
+    """torch.save(model) / pickle: the runtime state (arenas, executor, HIP streams) stays behind and is rebuilt."""
+    import io
+    for name, make in _small_models():
+        net = make().cuda().eval()
+        buf = io.BytesIO()
+        torch.save(net, buf)
+        buf.seek(0)
+        back = torch.load(buf, weights_only=False)  # (a file this test wrote itself)
+        a, b = net.state_dict(), back.state_dict()
+        assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a), name
+        if name == 'resnet18cifar':
+            x = torch.rand(2, 3, 32, 32).cuda()
+            with torch.no_grad():
+                assert torch.equal(net(x), back(x))

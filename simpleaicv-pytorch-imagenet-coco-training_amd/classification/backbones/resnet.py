@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from ...engine import ClassifierEngine
-from ...detection.models._arena import ParamArena, deepcopy_without_runtime, getstate_without_runtime
+from ...detection.models._arena import ParamArena, deepcopy_without_runtime, getstate_without_runtime, refuse_sync_batchnorm
 from ...detection.models._base import _resnet_trunk
 
 __all__ = ['resnet18', 'resnet34', 'resnet50', 'resnet101', 'resnet152', 'ResNet']
@@ -72,6 +72,7 @@ class ResNet(nn.Module):
         if dev.type != 'cuda':
             raise RuntimeError('sacv_amd ResNet runs on MI355X only: move the model to the GPU (.cuda()); there is '
                                'no CPU/PyTorch fallback path')
+        refuse_sync_batchnorm(self)
         self._arena = ParamArena(self)
         self._param_list = list(self._arena.order)
         tensors = {n: p.data for n, p in self.named_parameters()}

@@ -116,3 +116,11 @@ def getstate_without_runtime(self):
     first use after loading (the reference's checkpoints hold state_dicts, tools/scripts.py:1080-1100, but whole-model
     saves must not crash on HIP streams either)."""
     return {k: (None if k in _RUNTIME_ATTRS else v) for k, v in self.__dict__.items()}
+
+
+def refuse_sync_batchnorm(module):
+    """config.sync_bn (tools/utils.py:168-169: SyncBatchNorm.convert_sync_batchnorm) replaces the BatchNorm containers;
+    the engine computes per-GPU batch statistics (the graded recipes: sync_bn = False) and must not ignore the request."""
+    if any(isinstance(m, torch.nn.SyncBatchNorm) for m in module.modules()):
+        raise NotImplementedError('sync_bn: this path implements per-GPU BatchNorm statistics (the recipes\' sync_bn = '
+                                  'False); SyncBatchNorm is not built')

@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from ...engine import DetectorEngine, RESNET50_LAYERS
-from ._arena import ParamArena, deepcopy_without_runtime, getstate_without_runtime
+from ._arena import ParamArena, deepcopy_without_runtime, getstate_without_runtime, refuse_sync_batchnorm
 
 def _conv_bn_act(cin, cout, k, stride, pad, act=True):
     """Container with the key layout of ConvBnActBlock: layer.0 = conv (no bias), layer.1 = BN."""
@@ -163,6 +163,7 @@ class HipDetector(nn.Module):
         if dev.type != 'cuda':
             raise RuntimeError(f'sacv_amd {type(self).__name__} runs on MI355X only: move the model to the GPU '
                                '(.cuda()); there is no CPU/PyTorch fallback path')
+        refuse_sync_batchnorm(self)
         self._arena = ParamArena(self)
         self._param_list = list(self._arena.order)
         tensors = {n: p.data for n, p in self.named_parameters()}

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ...detection.models._arena import ParamArena, deepcopy_without_runtime, getstate_without_runtime
+from ...detection.models._arena import ParamArena, deepcopy_without_runtime, getstate_without_runtime, refuse_sync_batchnorm
 from ...mae_engine import MAEEngine
 
 __all__ = ['vit_base_patch16_224_mae_pretrain_model', 'vit_large_patch16_224_mae_pretrain_model',
@@ -143,6 +143,7 @@ class VITMAEPretrainModel(nn.Module):
         if dev.type != 'cuda':
             raise RuntimeError('sacv_amd VITMAEPretrainModel runs on MI355X only: move the model to the GPU (.cuda()); '
                                'there is no CPU/PyTorch fallback path')
+        refuse_sync_batchnorm(self)
         self._arena = ParamArena(self)
         self._param_list = list(self._arena.order)
         tensors = {n: p.data for n, p in self.named_parameters()}

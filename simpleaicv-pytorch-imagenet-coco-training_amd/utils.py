@@ -8,7 +8,7 @@ is bit-identical (tests/golden/scheduler.json).
 """
 import math
 
-__all__ = ['Scheduler', 'build_trainer', 'EmaModel']
+__all__ = ['Scheduler', 'build_trainer', 'EmaModel', 'compute_macs_and_params']
 
 
 class Scheduler:
@@ -51,6 +51,46 @@ class Scheduler:
 
     def load_state_dict(self, state_dict):
         self.__dict__.update(state_dict)
+
+
+def compute_macs_and_params(config, model):
+    """tools/utils.py:116-133 for the HIP models.  The reference profiles a CPU forward pass with thop's nn.Module hooks
+    (tools/test_detection_model.py:79); these models have no torch.nn forward to hook and no CPU path, so the
+    multiply-accumulates are counted where the work is issued: one evaluation pass of a [1,3,H,W] input on the GPU with a
+    counter in the place of bench.py's kernel timer (every convolution / Linear launch reports its algorithmic flops;
+    MACs = flops / 2 -- normalisation and activation layers, which thop also tallies, are not counted).  Returns the two
+    strings of thop.clever_format('%.3f')."""
+    import torch
+    from . import ops
+    size = config.input_image_size
+    assert isinstance(size, (int, list)), 'Illegal input_image_size type!'
+    h, w = (size, size) if isinstance(size, int) else (size[0], size[1])
+
+    class _Counter:
+        flops = 0.0
+
+        def time(self, key, flops, launch, nbytes=0.0):
+            self.flops += flops
+            return launch()
+
+    dev = next(model.parameters()).device
+    was_training, counter, saved = model.training, _Counter(), ops.TIMER
+    model.eval()
+    ops.TIMER = counter
+    try:
+        with torch.no_grad():
+            model(torch.randn(1, 3, h, w, device=dev))
+    finally:
+        ops.TIMER = saved
+        model.train(was_training)
+    params = sum(p.numel() for p in model.parameters())
+
+    def fmt(v):  # thop.clever_format
+        for unit, div in (('T', 1e12), ('G', 1e9), ('M', 1e6), ('K', 1e3)):
+            if v > div:
+                return '%.3f' % (v / div) + unit
+        return '%.3f' % v + 'B'
+    return fmt(counter.flops / 2.0), fmt(float(params))
 
 
 class EmaModel:

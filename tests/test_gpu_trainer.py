@@ -334,3 +334,20 @@ def test_models_survive_pickle():
             x = torch.rand(2, 3, 32, 32).cuda()
             with torch.no_grad():
                 assert torch.equal(net(x), back(x))
+
+
+def test_macs_params_probe_and_sync_bn_refusal():
+    """compute_macs_and_params (tools/utils.py:116-133) counted at the launch sites: RetinaNet-R50 at 800 x 1333 is the
+    249.5 GMAC / 37.97 M parameters SURVEY.md 8d measured with the reference's hooks (conv MACs); sync_bn is refused."""
+    from sacv_amd.detection import models
+    from sacv_amd import utils as U
+
+    class Cfg:
+        input_image_size = [800, 1333]
+    net = models.__dict__['resnet50_retinanet']().cuda().train()
+    macs, params = U.compute_macs_and_params(Cfg(), net)
+    assert net.training and macs.endswith('G') and params.endswith('M')
+    assert abs(float(macs[:-1]) - 249.5) < 1.0 and abs(float(params[:-1]) - 37.969) < 0.01, (macs, params)
+    conv = torch.nn.SyncBatchNorm.convert_sync_batchnorm(models.__dict__['resnet18_retinanet']())
+    with pytest.raises(NotImplementedError, match='sync_bn'):
+        conv.cuda()

@@ -361,7 +361,7 @@ def bench_decode(args, rank, world, ops, synth):
                                f'100; outputs stay on the device; {kept} detections kept in the batch',
                    'global_batch': world * BATCH, 'parallelism': f'replicas{world}'},
         'roofline': roofline}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import statistics
         from oracle import decode as odecode  # the checker, timed as the CPU baseline
         fn = odecode.fcos_decode if fcos else odecode.retina_decode

@@ -46,6 +46,15 @@ def main():
             if 'nms_mask' in k:
                 note = 'latency / VALU (1000 x 16 waves over the chip)'
             md.append(f'| `{k}` | {r["Calls"]} | {avg:.1f} | {note} |')
+    infer = sorted(glob.glob(os.path.join(prof, f'{tag}_infer_*.json')))
+    if infer:
+        md += ['', 'Evaluation passes (`bench.py --model {retinanet,fcos}_infer`: `model.eval()` forward with BatchNorm folded into the '
+               'convolution epilogues and the im2col-free stem + the decoder on the device, batch of 2):', '',
+               '| workload | ms / batch (median) | images/s |', '|---|---|---|']
+        for path in infer:
+            d = json.load(open(path))
+            md.append(f'| {os.path.basename(path)[len(tag) + 7:-5]} ({d["metric"].split(" evaluation")[0].split("node ")[1]}, '
+                      f'{d["metric"].split("NMS ")[1].split(" bs")[0]}) | {d["ms_per_step_median"]} | {d["value"]} |')
     spath = os.path.join(prof, f'{tag}_summary.md')
     text = open(spath).read()
     if MARK in text:

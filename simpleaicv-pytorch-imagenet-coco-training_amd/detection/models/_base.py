@@ -197,6 +197,8 @@ class HipDetector(nn.Module):
         self._ready()
         return self._engine
 
+    @torch.compiler.disable  # config.use_compile (torch.compile(model), tools/train_detection_model.py:176-178): nothing to trace --
+    # the forward pass is one call into the HIP executor; the compiled wrapper runs it as is
     def forward(self, inputs):
         if inputs.device.type != 'cuda':
             raise RuntimeError(f'sacv_amd {type(self).__name__} runs on MI355X only: inputs must be on the GPU '

@@ -180,6 +180,8 @@ class VITMAEPretrainModel(nn.Module):
         self._next_noise = noise
         return self
 
+    @torch.compiler.disable  # config.use_compile (torch.compile(model), tools/train_detection_model.py:176-178): nothing to trace --
+    # the forward pass is one call into the HIP executor; the compiled wrapper runs it as is
     def forward(self, x):
         if x.device.type != 'cuda':
             raise RuntimeError('sacv_amd VITMAEPretrainModel runs on MI355X only: inputs must be on the GPU')

@@ -351,3 +351,19 @@ def test_macs_params_probe_and_sync_bn_refusal():
     conv = torch.nn.SyncBatchNorm.convert_sync_batchnorm(models.__dict__['resnet18_retinanet']())
     with pytest.raises(NotImplementedError, match='sync_bn'):
         conv.cuda()
+
+
+def test_torch_compile_wrapper_is_harmless():
+    """config.use_compile = True (tools/train_detection_model.py:176-178 wraps the model in torch.compile): the forward
+    pass is exempt from tracing, the wrapper returns what the model returns and backward works through it."""
+    from sacv_amd.detection import models, losses
+    H, W = gi.TINY
+    net = models.__dict__['resnet18_retinanet']().cuda().train()
+    x = torch.tensor(synth.images(1, 2, H, W)).cuda()
+    ann = torch.tensor(synth.annotations(2, 2, H, W, boxes_per_image=4)).cuda()
+    ref = [[o.detach().clone() for o in grp] for grp in net(x)]
+    comp = torch.compile(net)
+    outs = comp(x)
+    assert all(torch.equal(a, b) for ga, gb in zip(outs, ref) for a, b in zip(ga, gb))
+    sum(losses.__dict__['RetinaLoss']()(outs, ann).values()).backward()
+    assert float(net.arena.grads.abs().sum()) > 0

@@ -115,6 +115,7 @@ class EmaModel:
         the cross-rank vote) nothing moves, like the reference's `continue` ahead of its update (scripts.py:968-974)."""
         import torch
         from . import ops
+        model = getattr(model, 'module', model)  # a DistributedDataParallel wrapper (tools/utils.py:178-180)
         ea, ma = self.ema_model.arena, model.arena
         with torch.no_grad():
             ops.ema_update(ea.params, ma.params, self.decay, gate)

@@ -24,6 +24,20 @@ extern "C" {
 const char* sacv_last_error(void);
 int sacv_abi_version(void);
 
+/* Launch plan of the calling host thread's subsequent launches.  The convolution kernels are PERSISTENT: a launch is
+ * sized to the workgroup slots it expects to own (slots per CU x CUs) and its tiles / stream-K ranges are cut for exactly
+ * that many co-resident workgroups.  A caller that runs a second queue beside the launch stream -- the weight gradients on
+ * a side HIP stream (the reference gets the same overlap from cuDNN + NCCL kernels co-running, tools/utils.py:178-180),
+ * RCCL's all-reduce kernels -- states here what the launch stream may plan for, so that both queues' workgroups FIT a CU's
+ * 160 KB of LDS and 512 registers per lane together instead of queueing behind each other:
+ *   nt64 / nt128     slots per CU of sacv_conv2d_gemm's 128x64 / 128x128 tile kernels (alone: 3 / 2)
+ *   wino             slots per CU of sacv_wino_gemm (alone: 3 narrow-item, 2 wide-item workgroups)
+ *   wgrad            slots per CU the split planner of sacv_wino_wgrad fills (alone: 2); sacv_conv2d_wgrad takes its
+ *                    split size (`chunk`) from the caller
+ *   cu_reserve       CUs every persistent grid leaves free (RCCL's channels)
+ * A value <= 0 (cu_reserve: < 0) keeps the current setting.  Results do not depend on the plan (fixed-order sums). */
+int sacv_launch_share(int nt64_wg_per_cu, int nt128_wg_per_cu, int wino_wg_per_cu, int wgrad_wg_per_cu, int cu_reserve);
+
 /* ---- convolution (nn.Conv2d: classification/backbones/resnet.py:33-39; detection/models/fpn.py:20-58;
  *      detection/models/head.py:20-33,60-73) -------------------------------------------------------- */
 

@@ -365,7 +365,7 @@ static int launch_bwd(const void* qkv, const void* out, const void* dout, const 
   return SACV_OK;
 }
 
-extern "C" {
+SACV_API_BEGIN
 
 // 1 when the matrix-core attention kernels cover (n, d): head dim 32 or 64, up to 224 tokens, LDS fit
 int sacv_attention_mfma_supported(int n, int d) {
@@ -400,4 +400,4 @@ int sacv_attention_bwd_mfma(const void* qkv, const void* out, const void* dout, 
                   : launch_bwd<32, 7>(qkv, out, dout, lse, dqkv, B, n, H, scale, st);
 }
 
-}  // extern "C"
+SACV_API_END

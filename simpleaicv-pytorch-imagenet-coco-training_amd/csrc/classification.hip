@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
   }
 }
 
-extern "C" {
+SACV_API_BEGIN
 
 int sacv_avgpool_fwd(const float* x, float* out, int N, int HW, int C, void* stream) {
   SACV_CHECK_ARG(x && out && N > 0 && HW > 0 && C % 4 == 0, "avgpool_fwd: bad args");
@@ -174,4 +174,4 @@ int sacv_sgd_step_gated(float* params, const float* grads, float* momentum_buf, 
   return SACV_OK;
 }
 
-}  // extern "C"
+SACV_API_END

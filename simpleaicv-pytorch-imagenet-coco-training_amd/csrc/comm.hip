@@ -86,7 +86,7 @@ struct SacvComm {
     }                                                                           \
   } while (0)
 
-extern "C" {
+SACV_API_BEGIN
 
 int sacv_comm_unique_id_bytes(void) { return (int)sizeof(ncclUniqueId); }
 
@@ -188,4 +188,4 @@ int sacv_comm_broadcast(void* comm, float* buf, long long count, int root, void*
   return SACV_OK;
 }
 
-}  // extern "C"
+SACV_API_END

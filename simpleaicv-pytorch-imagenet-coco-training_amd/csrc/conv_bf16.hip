@@ -693,7 +693,7 @@ static int launch_tn_h(const WgradArgsH& a, hipStream_t st) {
   return SACV_OK;
 }
 
-extern "C" {
+SACV_API_BEGIN
 
 // bf16 convolution (forward mode 0 / data gradient mode 1) of ONE problem.  src NHWC bf16 [Nb][Hs][Ws][Cs]; w bf16
 // panel [N][KH*KW*Cs] (mode 0: the weight itself when stored channels_last or 1x1; mode 1: the [Cin][taps*Cout]
@@ -902,4 +902,4 @@ int sacv_im2col_stem_bf16(const float* x, void* col, int Nb, int Cin, int H, int
   return SACV_OK;
 }
 
-}  // extern "C"
+SACV_API_END

@@ -690,7 +690,7 @@ __global__ __launch_bounds__(1024) void soft_nms_kernel(const float* __restrict_
   }
 }
 
-extern "C" {
+SACV_API_BEGIN
 
 // Workspace layout (256-byte aligned pieces): segment counters [B][nseg <= 1024] | candidate segments
 // [B][nseg][segcap] u64 (nseg * segcap <= A + (DMAXL + nseg) * rows per tile <= A + SEG_SLACK) | suppression mask
@@ -838,4 +838,4 @@ int sacv_decode_topk_soft_nms(int kind, int nlev, const float* const* cls, const
   return SACV_OK;
 }
 
-}  // extern "C"
+SACV_API_END

@@ -733,7 +733,7 @@ static void fill_anchor_args(AnchorArgs& a, int nlev, const int* fw, const int* 
   a.off[nlev] = off;
 }
 
-extern "C" {
+SACV_API_BEGIN
 
 // anchors_out: [sum_l fh*fw*A, 4] fp32 (A = nratios*nscales), order ((y*W + x)*A + a), a = r*S + s.
 int sacv_retina_anchors(int nlev, const int* fw, const int* fh, const float* areas /*[nlev][2]*/,
@@ -957,4 +957,4 @@ int sacv_fcos_split_bwd(const float* dreg, const float* dctr, const float* reg, 
   return SACV_OK;
 }
 
-}  // extern "C"
+SACV_API_END

@@ -221,7 +221,7 @@ static int gn_blocks(int HW, int* rpb) {
   return nb;
 }
 
-extern "C" {
+SACV_API_BEGIN
 
 long long sacv_gn_workspace_floats(int N, int HW, int C) {
   int rpb;
@@ -281,4 +281,4 @@ int sacv_groupnorm_bwd(const float* x, const float* dz, const float* zmask, cons
   return SACV_OK;
 }
 
-}  // extern "C"
+SACV_API_END

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_bf16_kernel(const bf16* __res
   }
 }
 
-extern "C" {
+SACV_API_BEGIN
 
 int sacv_maxpool_fwd_bf16(const void* x, void* y, unsigned char* idx, int Nb, int H, int W, int C, int Ho, int Wo,
                           int k, int s, int p, void* stream) {
@@ -192,4 +192,4 @@ int sacv_avgpool_bwd_bf16(const void* dy, void* dx, int N, int HW, int C, void* 
   return SACV_OK;
 }
 
-}  // extern "C"
+SACV_API_END

@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void bn_fold_batched_kernel(const BnFoldJob* _
   }
 }
 
-extern "C" {
+SACV_API_BEGIN
 
 // floats of workspace needed by the BN kernels for a [R][C] activation
 long long sacv_bn_workspace_floats(int R, int C) {
@@ -531,4 +531,4 @@ int sacv_bn_fold_batched(const void* jobs, int njobs, float eps, void* stream) {
   return SACV_OK;
 }
 
-}  // extern "C"
+SACV_API_END

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void ema_update_kernel(float* __restrict__ ema
   if (t < n) ema[t] = decay * ema[t] + one_minus_decay * model[t];
 }
 
-extern "C" {
+SACV_API_BEGIN
 
 // n must be a multiple of 4 (the arena pads every tensor to 4 floats); split likewise.
 int sacv_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
@@ -295,4 +295,4 @@ int sacv_ema_update(float* ema, const float* model, long long n, float decay, fl
   return SACV_OK;
 }
 
-}  // extern "C"
+SACV_API_END

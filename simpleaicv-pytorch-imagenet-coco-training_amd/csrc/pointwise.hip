@@ -304,7 +304,7 @@ static int grid_for(size_t work, int cap = 8192) {
   return (int)(b > (size_t)cap ? cap : b);
 }
 
-extern "C" {
+SACV_API_BEGIN
 
 int sacv_maxpool_fwd(const float* x, float* y, unsigned char* idx, int Nb, int H, int W, int C, int Ho, int Wo,
                      int k, int s, int p, void* stream) {
@@ -417,7 +417,7 @@ int sacv_colsum_finalize_multi(int n, const float* const* partial, const int* nb
   return SACV_OK;
 }
 
-}  // extern "C"
+SACV_API_END
 
 // ---------------------------------------------------------------- device-side data boundary
 // DetectionCollater + Normalize (simpleAICV/detection/common.py:223-286): uint8 HWC images of different sizes ->
@@ -472,7 +472,7 @@ __global__ void eval_postprocess_kernel(float* __restrict__ boxes, const float* 
   *reinterpret_cast<f32x4*>(boxes + (size_t)i * 4) = v;
 }
 
-extern "C" {
+SACV_API_BEGIN
 
 // imgs: host array of B (<= 16) device pointers to uint8 [h][w][3]; out: fp32 [B][R][R][3]
 int sacv_collate_u8(int B, const unsigned char* const* imgs, const int* h, const int* w, int R, float* out,
@@ -525,4 +525,4 @@ int sacv_eval_postprocess(float* boxes, const float* scales, const float* sizes,
   return SACV_OK;
 }
 
-}  // extern "C"
+SACV_API_END

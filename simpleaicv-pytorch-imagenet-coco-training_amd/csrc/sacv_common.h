@@ -9,7 +9,26 @@
 #define SACV_ERR_LAUNCH -2
 #define SACV_ERR_UNSUPPORTED -3
 
+// The library is built with -fvisibility=hidden: only the C ABI of include/sacv_hip.h is exported.  Every entry point
+// is defined between SACV_API_BEGIN and SACV_API_END (C linkage, default visibility); helpers shared between the
+// translation units (sacv_internal_*, sacv_set_error) stay internal to the shared object.
+#define SACV_API_BEGIN extern "C" { _Pragma("GCC visibility push(default)")
+#define SACV_API_END _Pragma("GCC visibility pop") }
+#define SACV_API extern "C" __attribute__((visibility("default")))
+
 void sacv_set_error(const char* fmt, ...);
+
+// Launch plan shared by the persistent kernels (errors.hip; set through sacv_launch_share): how many workgroup slots per CU
+// a launch may plan for and how many CUs it leaves alone -- the caller runs a second queue (weight gradients, RCCL)
+// beside the launch stream and the two have to FIT a CU's LDS / registers together.
+struct SacvShare {
+  int nt64_wg_per_cu;    // conv_nt_kernel<128,64>   (3 alone)
+  int nt128_wg_per_cu;   // conv_nt_kernel<128,128>  (2 alone)
+  int wino_wg_per_cu;    // wino_gemm_kernel, narrow items (3 alone; wide items: min(2, this))
+  int wgrad_wg_per_cu;   // wino_wgrad_kernel plan (2 alone); conv_tn's split count is the caller's `chunk`
+  int cu_reserve;        // CUs every persistent grid leaves free
+};
+extern thread_local SacvShare sacv_share;
 
 #define SACV_CHECK_ARG(cond, ...)          \
   do {                                     \

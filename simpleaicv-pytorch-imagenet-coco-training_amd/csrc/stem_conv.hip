@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 3) void stem_conv_kernel(const StemArgs a) {
 
 }  // namespace
 
-extern "C" {
+SACV_API_BEGIN
 
 // rows of the statistics buffer of sacv_stem_conv_fwd (one per output tile)
 int sacv_stem_conv_stats_rows(int Nb, int Ho, int Wo) { return Nb * ((Ho + TR - 1) / TR) * ((Wo + TC - 1) / TC); }
@@ -213,4 +213,4 @@ int sacv_stem_conv_fwd(const float* x, int Nb, int H, int W, long long sN, long 
   return SACV_OK;
 }
 
-}  // extern "C"
+SACV_API_END

@@ -709,7 +709,7 @@ __global__ void mae_mse_finalize_kernel(const float* __restrict__ partial, int n
   if (threadIdx.x == 0) loss[0] = (float)(s / ((double)(float)m + 1e-4));
 }
 
-extern "C" {
+SACV_API_BEGIN
 
 int sacv_colsum_finalize(const float* partial, int nblocks, int stride, int C, float* out, int accumulate,
                          void* stream);
@@ -914,4 +914,4 @@ int sacv_mae_mse_loss(const void* pred, const float* label, const float* mask, v
   return SACV_OK;
 }
 
-}  // extern "C"
+SACV_API_END

@@ -922,7 +922,7 @@ static int wino_fill_geom(WinoGeom& g, int nlev, int Nb, const int* H, const int
   return SACV_OK;
 }
 
-extern "C" {
+SACV_API_BEGIN
 
 // Number of 2x2 output tiles of a pyramid (rows of the transformed operand V before padding to a multiple of 64).
 int sacv_wino_tiles(int nlev, int Nb, const int* H, const int* W) {
@@ -1061,14 +1061,16 @@ int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, cons
     wide += mt_items * ((a.p[p].N + 127) / 128);
     narrow_items += mt_items * ((a.p[p].N + 63) / 64);
   }
-  const int cus = wino_num_cus();
+  int cus = wino_num_cus() - sacv_share.cu_reserve;
+  if (cus < 8) cus = 8;
+  const int occ_n = sacv_share.wino_wg_per_cu, occ_w = occ_n < 2 ? occ_n : 2;  // slots per CU (sacv_launch_share)
   auto rounds_cost = [](double r, double t1, double t2, double t3) {  // r = items / slots
     const double full = (double)(long long)r, f = r - full;
     const double tail = f <= 1e-9 ? 0.0 : (f <= 1.0 / 3 ? t1 : (f <= 2.0 / 3 ? t2 : t3));
     return full + tail;
   };
-  const double cost_wide = rounds_cost((double)wide / (2 * cus), 0.45, 0.64, 1.0);
-  double cost_narrow = 0.845 * rounds_cost((double)narrow_items / (3 * cus), 0.5, 0.7, 0.85);
+  const double cost_wide = rounds_cost((double)wide / (occ_w * cus), 0.45, 0.64, 1.0);
+  double cost_narrow = 0.845 * rounds_cost((double)narrow_items / (occ_n * cus), 0.5, 0.7, 0.85);
   if (cost_narrow < 0.845) cost_narrow = 0.845;
   const bool narrow = cost_narrow < cost_wide;
   const int bn = narrow ? 64 : 128;
@@ -1088,7 +1090,7 @@ int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, cons
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel<BM, BN, 2, 3>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
-    int grid = wino_num_cus() * 3;
+    int grid = cus * occ_n;
     if (grid > items) grid = items;
     hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, 2, 3>), dim3(grid), dim3(256), lds, st, a);
     SACV_CHECK_LAUNCH("wino_gemm_kernel");
@@ -1103,7 +1105,7 @@ int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, cons
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel<BM, BN, WN, WN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
-  int grid = wino_num_cus() * 2;
+  int grid = cus * occ_w;
   if (grid > items) grid = items;
   hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WN, WN>), dim3(grid), dim3(128 * WN), lds, st, a);
   SACV_CHECK_LAUNCH("wino_gemm_kernel");
@@ -1114,7 +1116,9 @@ int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, cons
 static int wino_wgrad_plan(int Tpad, int Cout, int Kp, int* BNout, int* chunk_out) {
   const int BN = (Kp % 128 == 0) ? 128 : 64;
   const int tiles = ((Cout + 127) / 128) * (16 * Kp / BN);
-  const int slots = 2 * wino_num_cus();
+  int cus = wino_num_cus() - sacv_share.cu_reserve;
+  if (cus < 8) cus = 8;
+  const int slots = sacv_share.wgrad_wg_per_cu * cus;
   int best = 1;
   double best_cost = 1e30;
   for (int c = 1; c <= 32; ++c) {
@@ -1207,4 +1211,4 @@ int sacv_wino_wgrad(int nlev, const float* const* dy, int Nb, const int* H, cons
   return SACV_OK;
 }
 
-}  // extern "C"
+SACV_API_END

@@ -137,8 +137,9 @@ class DetectorEngine:
             out.append(z)
         return out
 
-    def _wgrad(self, dys, xs, dw, cin, kh, kw, stride, pad, **kw_args):
-        self._on_side(lambda: ops.conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, **kw_args), list(dys) + list(xs))
+    def _wgrad(self, dys, xs, dw, cin, kh, kw, stride, pad, sync=True, **kw_args):
+        self._on_side(lambda: ops.conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, **kw_args), list(dys) + list(xs),
+                      sync=sync)
 
     # -- weight gradients on a side HIP stream ----------------------------------------------------------------------
     # A layer's weight gradient depends only on its dy and the saved input and nothing in the backward pass reads it
@@ -150,19 +151,18 @@ class DetectorEngine:
     # side stream in program order, so their workspaces ('wgrad', 'wino_wgrad') never meet the launch stream's.
     # Contract for callers: `dys` / `xs` are not written by the launch stream after this call (every in-place
     # accumulation into a gradient tensor precedes its use as a dy; checked call site by call site).
-    def _on_side(self, launch, tensors):
+    def _on_side(self, launch, tensors, sync=True):
+        """sync=False: everything `launch` reads was already enqueued on the launch stream when the PREVIOUS _on_side
+        call recorded its event (several launches of one dependency group, e.g. a layer's weight gradient and its bias
+        gradient): no new event.  An event record is a barrier packet in the launch queue -- the next kernel of the
+        launch stream starts 6-7 us after its predecessor instead of ~2 (kernel trace, round 4)."""
         s = self._side
         if s is None or ops.TIMER is not None:
             # no side stream, or a step instrumented with per-launch HIP events (bench.py's roofline measurement): a
             # kernel timed while another stream's kernels share the chip would not report its OWN duration
             return launch()
-        cur = torch.cuda.current_stream()
-        # events come from a small ring (creating / destroying ~150 HIP events per step showed up as multi-second host
-        # stalls on a loaded box); a ring slot is reused only long after its wait has been enqueued
-        ev = self._side_events[self._side_evi]
-        self._side_evi = (self._side_evi + 1) % len(self._side_events)
-        ev.record(cur)
-        s.wait_event(ev)
+        if sync or not self._side_busy:
+            self._side_wait_launch()
         # scratch buffers of their own: nothing the launch stream's kernels are using.  (A module-level switch: the
         # engines enqueue from ONE host thread, like the reference's training loop.)
         prev_suffix, ops.WS_SUFFIX = ops.WS_SUFFIX, '@side'  # (restored, not reset: a side-stream branch may nest)
@@ -176,6 +176,39 @@ class DetectorEngine:
         # recycle them for launch-stream work without any cross-stream bookkeeping (no Tensor.record_stream).
         self._side_keep.extend(tensors)
         self._side_busy = True
+
+    def _side_wait_launch(self):
+        """The side stream waits for everything enqueued on the launch stream so far."""
+        # events come from a small ring (creating / destroying ~150 HIP events per step showed up as multi-second host
+        # stalls on a loaded box); a ring slot is reused only long after its wait has been enqueued
+        ev = self._side_events[self._side_evi]
+        self._side_evi = (self._side_evi + 1) % len(self._side_events)
+        ev.record(torch.cuda.current_stream())
+        self._side.wait_event(ev)
+
+    def _stage(self, on_stage, name, pre=None):
+        """The gradients of exchange stage `name` are all enqueued (weight gradients on the side stream, the rest on the
+        launch stream): run `pre` (optional) and hand the stage to the caller's exchange -- ON THE SIDE STREAM, behind an
+        event of the launch stream, so that the collective is chained to the last weight gradient while the launch
+        stream goes on with the data-gradient chain.  (Until round 4 the launch stream joined the side stream here: the
+        kernel trace showed it idle for 954 us after the head towers' backward pass, 34 / 96 us at the other two stages
+        -- the side stream's queue of weight gradients runs that far behind.)"""
+        if on_stage is None and pre is None:
+            return
+        s = self._side
+        if s is None or not self._side_busy or ops.TIMER is not None:
+            self._side_join()
+            if pre is not None:
+                pre()
+            if on_stage is not None:
+                on_stage(name)
+            return
+        self._side_wait_launch()
+        with torch.cuda.stream(s):
+            if pre is not None:
+                pre()
+            if on_stage is not None:
+                on_stage(name)
 
     def _side_join(self):
         if self._side is not None and self._side_busy:
@@ -540,7 +573,7 @@ class DetectorEngine:
             return self._conv_bias_bwd(dy, x, name, 3, 1, 1)
         w = self.p[name + '.weight']
         self._wino_wgrad([dy], [x], v, self.g[name + '.weight'], w.shape[1])
-        self._bias_grad([dy], name)
+        self._bias_grad([dy], name, sync=False)
         return ops.conv3x3_wino([[dy]], [self._wino_u(w, dgrad=True)], [w.shape[1]], mode=1)[0][0]
 
     def _fpn_fwd(self, c3, c4, c5, ctx):
@@ -675,12 +708,12 @@ class DetectorEngine:
         v0 = self._wino_input(xs2[0], keep, 'wino_v0')
         return [v0, v0 if shared else self._wino_input(xs2[1], keep, 'wino_v1')]
 
-    def _wino_wgrad(self, dys, xs, v, dw, cin):
+    def _wino_wgrad(self, dys, xs, v, dw, cin, sync=True):
         """3x3 weight gradient: Winograd path from the kept V when the channel count allows it, else conv_tn."""
         if v is not None and ops.wino_wgrad_supported(cin) and dys[0].shape[3] >= 64:
-            self._on_side(lambda: ops.wino_wgrad(dys, v, dw, cin), list(dys) + [v])
+            self._on_side(lambda: ops.wino_wgrad(dys, v, dw, cin), list(dys) + [v], sync=sync)
         else:
-            self._wgrad(dys, xs, dw, cin, 3, 3, 1, 1)
+            self._wgrad(dys, xs, dw, cin, 3, 3, 1, 1, sync=sync)
 
     # ------------------------------------------------------------------ FCOS heads
     # FCOSClsRegCntHead (head.py:88-181): two towers of 4 x (3x3 conv no bias, GroupNorm(32), ReLU) shared by
@@ -831,7 +864,7 @@ class DetectorEngine:
         dz_cls = self._pad_channels(dz_cls, w.shape[0])
         vcls = self.ctx['fcos_out_v'][0] if self._use_wino() else None
         self._wino_wgrad(dz_cls, o['cls_x'], vcls, g['clsregcnt_head.cls_out.weight'], w.shape[1])
-        self._bias_grad(dz_cls, 'clsregcnt_head.cls_out')
+        self._bias_grad(dz_cls, 'clsregcnt_head.cls_out', sync=False)
         # regression + centerness branch (8-channel combined output conv)
         dy8 = [ops.fcos_split_bwd(dr.contiguous(), dc.contiguous(), r, c, p['scales'][l:l + 1], g['scales'], l,
                                   gscale=grad_scale)
@@ -858,8 +891,9 @@ class DetectorEngine:
         return self._gn_tower_bwd(d_reg_x, 'clsregcnt_head.reg_head', accum_into=dfeat)
 
     # ------------------------------------------------------------------ backward
-    def _bias_grad(self, dys, name):
-        """Column sums of dy: like the weight gradients, nothing in the backward pass waits for them -> side stream."""
+    def _bias_grad(self, dys, name, sync=True):
+        """Column sums of dy: like the weight gradients, nothing in the backward pass waits for them -> side stream.
+        sync=False: right behind the same dys' weight gradient (see _on_side)."""
         gb = self.g[name + '.bias']
         c = gb.numel()
 
@@ -867,14 +901,14 @@ class DetectorEngine:
             for i, d in enumerate(dys):
                 ops.colsum(d, c, gb, accumulate=i > 0)
         if self._bias_on_side:
-            self._on_side(launch, list(dys))
+            self._on_side(launch, list(dys), sync=sync)
         else:
             launch()
 
-    def _bias_grad_from_stats(self, st, gb):
+    def _bias_grad_from_stats(self, st, gb, sync=True):
         """Second stage of a bias gradient whose column sums came out of a data-gradient epilogue (CF_STATS)."""
         if self._bias_on_side:
-            self._on_side(lambda: ops.colsum_finalize(st, gb), [st])
+            self._on_side(lambda: ops.colsum_finalize(st, gb), [st], sync=sync)
         else:
             ops.colsum_finalize(st, gb)
 
@@ -889,7 +923,7 @@ class DetectorEngine:
         xs = saved[4]
         w = p[out_name + '.weight']
         self._wgrad(dys, xs, g[out_name + '.weight'], w.shape[1], 3, 3, 1, 1)
-        self._bias_grad(dys, out_name)
+        self._bias_grad(dys, out_name, sync=False)
         hw = [(x.shape[1], x.shape[2]) for x in xs]
         cur, st = ops.conv_gemm(dys, self._dgrad_panel(w), w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_MASK,
                                 masks=xs, stats=True)
@@ -898,7 +932,7 @@ class DetectorEngine:
             w = p[name + '.weight']
             xs = saved[li]
             self._wgrad(cur, xs, g[name + '.weight'], w.shape[1], 3, 3, 1, 1)
-            self._bias_grad_from_stats(st, g[name + '.bias'])
+            self._bias_grad_from_stats(st, g[name + '.bias'], sync=False)
             wd = self._dgrad_panel(w)
             if li > 0:
                 cur, st = ops.conv_gemm(cur, wd, w.shape[1], 3, 3, 1, 1, 1, hw, flags=CF_MASK, masks=xs, stats=True)
@@ -919,8 +953,8 @@ class DetectorEngine:
         dys = [dz_cls, dz_reg]
         for t, (_, out_name) in enumerate(towers):
             w = p[out_name + '.weight']
-            self._wino_wgrad(dys[t], saved[t][4], vsaved[t][4], g[out_name + '.weight'], w.shape[1])
-            self._bias_grad(dys[t], out_name)
+            self._wino_wgrad(dys[t], saved[t][4], vsaved[t][4], g[out_name + '.weight'], w.shape[1], sync=t == 0)
+            self._bias_grad(dys[t], out_name, sync=False)
         # the two output convs have very different depths (720 / 36 channels): in one launch the item lengths differ
         # 11x and the static item order leaves whole XCDs idle (1384 us against 922 + 104 us separately)
         cur, st = [], []
@@ -933,8 +967,9 @@ class DetectorEngine:
             names = [f'{t}.{i}' for t, _ in towers]
             ws = [p[n + '.weight'] for n in names]
             for t in range(2):
-                self._wino_wgrad(cur[t], saved[t][li], vsaved[t][li], g[names[t] + '.weight'], ws[t].shape[1])
-                self._bias_grad_from_stats(st[t], g[names[t] + '.bias'])
+                self._wino_wgrad(cur[t], saved[t][li], vsaved[t][li], g[names[t] + '.weight'], ws[t].shape[1],
+                                 sync=t == 0)
+                self._bias_grad_from_stats(st[t], g[names[t] + '.bias'], sync=False)
             us = [self._wino_u(w, dgrad=True) for w in ws]
             if li > 0:
                 cur, st = ops.conv3x3_wino(cur, us, [self.planes] * 2, flags=[CF_MASK] * 2,
@@ -948,7 +983,7 @@ class DetectorEngine:
     def _conv_bias_bwd(self, dy, x, name, k, stride, pad, need_dx=True, out=None, accumulate=False, mask=None):
         w = self.p[name + '.weight']
         self._wgrad([dy], [x], self.g[name + '.weight'], w.shape[1], k, k, stride, pad)
-        self._bias_grad([dy], name)
+        self._bias_grad([dy], name, sync=False)
         if need_dx:
             return self._dgrad(dy, w, x.shape, k, stride, pad, out=out, accumulate=accumulate, mask=mask)
         return None
@@ -961,6 +996,34 @@ class DetectorEngine:
         if ctx is None:
             raise RuntimeError('backward() without a preceding forward(keep=True)')
         self._side_join()  # the forward pass's side-stream work (data-gradient panels) is complete
+        prev_share = self._share_begin()
+        try:
+            self._backward(dcls_levels, dreg_levels, dctr_levels, grad_scale, on_stage)
+        finally:
+            self._share_end(prev_share)
+
+    # Two queues share the chip for the whole backward pass (the data-gradient chain on the launch stream, the weight
+    # gradients on the side stream): each plans for ITS share of a CU's workgroup slots (ops.launch_share) -- together the
+    # two kernels fit a CU's LDS and registers, every workgroup of a persistent grid is resident from the start and the
+    # stream-K ranges are cut for the workgroups that really run side by side.
+    BWD_SHARE = None  # (nt64, nt128, wino, wgrad) slots per CU during the backward pass; None: plan as if alone
+
+    def _share_begin(self):
+        import os
+        share = self.BWD_SHARE
+        env = os.environ.get('SACV_BWD_SHARE')  # round-4 experiment switch (removed once the default is chosen)
+        if env:
+            share = tuple(int(v) for v in env.split(','))
+        if share is None or self._side is None or ops.TIMER is not None:
+            return None
+        return ops.launch_share(*share)
+
+    def _share_end(self, prev):
+        if prev is not None:
+            ops.launch_share(*prev)
+
+    def _backward(self, dcls_levels, dreg_levels, dctr_levels, grad_scale, on_stage):
+        ctx = self.ctx
         if self.fcos:
             dfeat = self._fcos_heads_bwd(dcls_levels, dreg_levels, dctr_levels, grad_scale)
             return self._trunk_bwd(dfeat, on_stage)
@@ -986,11 +1049,8 @@ class DetectorEngine:
 
     def _trunk_bwd(self, dfeat, on_stage):
         ctx = self.ctx
-        if on_stage or self._shadows:
-            self._side_join()
-            self._shadow_flush()
-        if on_stage:
-            on_stage('heads')  # head gradients are final: their all-reduce can start now
+        # head gradients are final: their all-reduce can start now (behind the side stream's weight gradients)
+        self._stage(on_stage, 'heads', pre=self._shadow_flush if self._shadows else None)
         dc3, dc4, dc5 = self._fpn_bwd(dfeat)
         self._backbone_bwd(dc5, dc4, dc3, on_stage)
         self._side_join()
@@ -1011,8 +1071,7 @@ class DetectorEngine:
                 accum_target = dc3
             dout = bwd(saved, dout, accum_target)
             if on_stage and bi == 0 and li in (3, 4):
-                    self._side_join()
-                    on_stage('neck' if li == 4 else 'mid')  # fpn + layer4 / layer3 gradients are final
+                self._stage(on_stage, 'neck' if li == 4 else 'mid')  # fpn + layer4 / layer3 gradients are final
         # max pool + stem
         if self.stem == 'imagenet':
             dpool = ops.maxpool_bwd(dout, ctx['pool_idx'], ctx['pool_in_shape'], 3, 2, 1)
@@ -1161,8 +1220,7 @@ class ClassifierEngine(DetectorEngine):
         else:
             dpooled = self._dgrad(dy, w.view(npad, nin, 1, 1), ctx['pooled'].shape, 1, 1, 0)
         dc5 = ops.avgpool_bwd(dpooled, ctx['c5_shape'])
-        if on_stage:
-            on_stage('heads')
+        self._stage(on_stage, 'heads')
         self._backbone_bwd(dc5, None, None, on_stage)
         self._side_join()
         if on_stage:

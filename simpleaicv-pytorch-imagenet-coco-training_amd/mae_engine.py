@@ -44,18 +44,34 @@ class MAEEngine:
         s = self._side
         if s is None or ops.TIMER is not None:  # instrumented steps run in stream order (DetectorEngine._on_side)
             return launch()
-        ev = self._side_events[self._side_evi]  # event ring and keep-alive list: see DetectorEngine._on_side
-        self._side_evi = (self._side_evi + 1) % len(self._side_events)
-        ev.record(torch.cuda.current_stream())
-        s.wait_event(ev)
-        ops.WS_SUFFIX = '@side'
+        self._side_wait_launch()
+        prev_suffix, ops.WS_SUFFIX = ops.WS_SUFFIX, '@side'  # restored, not reset (DetectorEngine._on_side)
         try:
             with torch.cuda.stream(s):
                 launch()
         finally:
-            ops.WS_SUFFIX = ''
+            ops.WS_SUFFIX = prev_suffix
         self._side_keep.extend(tensors)
         self._side_busy = True
+
+    def _side_wait_launch(self):
+        ev = self._side_events[self._side_evi]  # event ring and keep-alive list: see DetectorEngine._on_side
+        self._side_evi = (self._side_evi + 1) % len(self._side_events)
+        ev.record(torch.cuda.current_stream())
+        self._side.wait_event(ev)
+
+    def _stage(self, on_stage, name):
+        """Hand exchange stage `name` to the caller on the side stream (DetectorEngine._stage): the collective is chained
+        behind the last weight gradient, the launch stream does not wait."""
+        if on_stage is None:
+            return
+        if self._side is None or not self._side_busy or ops.TIMER is not None:
+            self._side_join()
+            on_stage(name)
+            return
+        self._side_wait_launch()
+        with torch.cuda.stream(self._side):
+            on_stage(name)
 
     def _side_join(self):
         if self._side is not None and self._side_busy:
@@ -176,9 +192,7 @@ class MAEEngine:
         ops.colsum(gmask, self.D, g['decoder.mask_token'].reshape(-1))
         V.linear_wgrad(dy, ctx['xn'], g['encoder_to_decoder.weight'], g['encoder_to_decoder.bias'],
                        side=self._on_side)
-        if on_stage:
-            self._side_join()
-            on_stage('heads')  # decoder + encoder_to_decoder weights (the tail of the arena) are final
+        self._stage(on_stage, 'heads')  # decoder + encoder_to_decoder weights (the tail of the arena) are final
         dxn = V.linear_dgrad(dy, self._wd('encoder_to_decoder.weight'), self.E)
         dx = V.layernorm_bwd(dxn, ctx['x_enc'], ctx['me'], ctx['re'], p['encoder.norm.weight'],
                              g['encoder.norm.weight'], g['encoder.norm.bias'])

@@ -191,7 +191,7 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
             iarr([hw[0] for hw in out_hw]), iarr([hw[1] for hw in out_hw]),
             _ptr(w_packed), _ptr(bias), cs, n_out, kh, kw, stride, pad, mode, flags, rs, hr, wr,
             iarr(ext) if ext is not None else None,
-            workspace(_gemm_ws_bytes(), srcs[0].device, 'conv_gemm').data_ptr(), _ptr(stats_buf), _stream()),
+            workspace(_gemm_ws_bytes(), srcs[0].device, 'conv_gemm', zero=True).data_ptr(), _ptr(stats_buf), _stream()),
             'conv2d_gemm')
 
     if TIMER is not None:
@@ -411,8 +411,26 @@ def _conv_gemm_bf16(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bi
     return outs
 
 
-_WGRAD_TARGET_MULTI = int(os.environ.get('SACV_WGRAD_TARGET_MULTI', '1024'))
-_WGRAD_TARGET = int(os.environ.get('SACV_WGRAD_TARGET_BLOCKS', '512'))  # = resident workgroups (2/CU): one wave of blocks; 544 or 1024 measured slower
+_WGRAD_TARGET_MULTI = 1024
+_WGRAD_TARGET = 512  # = resident workgroups (2/CU): one wave of blocks; 544 or 1024 measured slower
+SHARE_ALONE = (3, 2, 3, 2, 0)
+_share = SHARE_ALONE
+
+
+def launch_share(nt64=0, nt128=0, wino=0, wgrad=0, cu_reserve=-1):
+    """Launch plan of the following launches (include/sacv_hip.h: sacv_launch_share): workgroup slots per CU the
+    persistent convolution kernels may plan for, CUs they leave free.  Returns the previous plan (a 5-tuple that can be
+    passed back as launch_share(*prev))."""
+    global _share, _WGRAD_TARGET, _WGRAD_TARGET_MULTI
+    prev = _share
+    cur = tuple(n if n > 0 else o for n, o in zip((nt64, nt128, wino, wgrad), prev[:4])) + \
+        (cu_reserve if cu_reserve >= 0 else prev[4],)
+    check(lib.sacv_launch_share(*cur), 'launch_share')
+    _share = cur
+    # direct weight gradients: the split count is chosen here (one co-resident wave of workgroups)
+    _WGRAD_TARGET = 256 * cur[3]
+    _WGRAD_TARGET_MULTI = 512 * cur[3]
+    return prev
 
 
 def _wgrad_chunk(npix, cout, n2, target_blocks=None):
@@ -435,12 +453,15 @@ _ws_cache = {}
 WS_SUFFIX = ''  # set by a caller that enqueues on another stream (engine._on_side): that stream's own scratch buffers
 
 
-def workspace(nbytes, device, tag='ws'):
-    """Grow-only scratch buffer per tag (kernels on one stream reuse it in order)."""
+def workspace(nbytes, device, tag='ws', zero=False):
+    """Grow-only scratch buffer per tag (kernels on one stream reuse it in order).  zero=True: zero-filled when it is
+    (re)allocated -- the split-K workspace of sacv_conv2d_gemm starts with arrival counters that every call leaves at
+    zero (include/sacv_hip.h)."""
     key = (tag + WS_SUFFIX, device)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), device=device, dtype=torch.uint8)
+        alloc = torch.zeros if zero else torch.empty
+        buf = alloc(max(int(nbytes), 1 << 20), device=device, dtype=torch.uint8)
         _ws_cache[key] = buf
     return buf
 

@@ -130,8 +130,15 @@ class _StepDriver:
             else:
                 self._vote = dist.all_reduce(self.flag, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def _stage_cb(self):
+        """The engines' per-stage callback, or None when a stage has nothing to do (one rank, no accumulation window):
+        the engine then skips the stage's event chaining altogether."""
+        return self._on_stage if (self.world > 1 or self.accum is not None) else None
+
     def _on_stage(self, stage):
-        """Backward finished the gradients of `stage`: fold in the accumulation window, start the exchange."""
+        """Backward finished the gradients of `stage`: fold in the accumulation window, start the exchange.  Called with
+        the engine's weight-gradient stream current (DetectorEngine._stage): what is enqueued here runs behind the
+        stage's last weight gradient without holding up the launch stream."""
         if self.accum is not None and self.boundary and self.micro > 0:
             b, e = self.exchanger.ranges[stage]
             if e > b:
@@ -283,7 +290,7 @@ class DetectionTrainer(_StepDriver):
         ops.loss_skip_flag(values, self.flag)
         self._vote_begin()
         inv = 1.0 / self.accumulation_steps
-        engine.backward(*grads, grad_scale=inv, on_stage=self._on_stage)
+        engine.backward(*grads, grad_scale=inv, on_stage=self._stage_cb())
         names = ('cls_loss', 'reg_loss', 'center_ness_loss')[:values.numel()]
         if inv != 1.0:
             values = ops.eltwise(ops.EW_SCALE, values, scalar=inv)
@@ -341,7 +348,7 @@ class MAETrainer(DetectionTrainer):
         loss, dpred = self.criterion.fused(pred, labels.contiguous().float(), mask, grad_scale=inv)
         ops.loss_skip_flag(loss, self.flag)
         self._vote_begin()
-        engine.backward(dpred, on_stage=self._on_stage)
+        engine.backward(dpred, on_stage=self._stage_cb())
         if inv != 1.0:
             loss = ops.eltwise(ops.EW_SCALE, loss, scalar=inv)
         out = {'loss': loss[0]}
@@ -398,7 +405,7 @@ class ClassificationTrainer(_StepDriver):
         loss, dlogits = self.criterion.fused(logits, labels, grad_scale=inv)
         ops.loss_skip_flag(loss, self.flag)
         self._vote_begin()
-        engine.backward(dlogits, on_stage=self._on_stage)
+        engine.backward(dlogits, on_stage=self._stage_cb())
         if inv != 1.0:
             loss = ops.eltwise(ops.EW_SCALE, loss, scalar=inv)
         out = {'loss': loss[0]}

@@ -29,6 +29,16 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.sacv_abi_version() == 2
 
 
+def test_library_exports_nothing_else():
+    """-fvisibility=hidden + csrc/exports.map: the dynamic symbol table holds the C ABI and nothing else (no C++
+    device stubs, kernel handles or internal helpers)."""
+    import subprocess
+    from sacv_amd import _lib
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == _declared_symbols()
+
+
 def test_state_dict_contract(golden_dir):
     from sacv_amd.detection import models
     c = json.load(open(os.path.join(golden_dir, 'contract.json')))['resnet50_retinanet']

@@ -144,6 +144,12 @@ int sacv_im2col_stem(const float* x, float* col, int Nb, int Cin, int H, int W, 
 int sacv_stem_conv_stats_rows(int Nb, int Ho, int Wo);
 int sacv_stem_conv_fwd(const float* x, int Nb, int H, int W, long long sN, long long sC, long long sH, long long sW,
                        const float* wpanel, int Kpad, float* y, int Ho, int Wo, float* stats, void* stream);
+/* ... and its weight gradient, from the image and dy [Nb][Ho][Wo][64] (the backward of the same nn.Conv2d; autograd's
+ * convolution_backward in the reference): dw [64][3][7][7] (OIHW) (+)= x (*) dy.  workspace: one [64][160] slab per
+ * persistent workgroup, summed in a fixed order. */
+long long sacv_stem_conv_wgrad_workspace_bytes(int Nb, int Ho, int Wo);
+int sacv_stem_conv_wgrad(const float* x, int Nb, int H, int W, long long sN, long long sC, long long sH, long long sW,
+                         const float* dy, int Ho, int Wo, float* dw, float* workspace, int accumulate, void* stream);
 
 /* ---- BatchNorm2d (classification/backbones/resnet.py:41; training mode batch statistics) ------------ */
 /* eval mode: (shift, scale) of every BatchNorm of a model in one launch, for SACV_CF_AFFINE.  jobs = device array of

@@ -547,12 +547,16 @@ def _module_of(name):
 
 def _run_reference_loop(ref, tu, H, W, n_iters, accumulation_steps=1, clip_grad_value=0.0, clip_max_norm=0.0,
                         sched=('MultiStepLR', {'warm_up_epochs': 0, 'gamma': 0.1, 'milestones': [1, 2]}), epochs=3,
-                        iters_per_epoch=2, bad_iter=None):
+                        iters_per_epoch=2, bad_iter=None, dtype=torch.float32):
     """The body of tools/scripts.py::train_detection (:866-1036) for world size 1 on CPU, with the reference's
-    model, loss, build_optimizer and Scheduler objects (the function itself needs CUDA and a process group)."""
+    model, loss, build_optimizer and Scheduler objects (the function itself needs CUDA and a process group).
+    dtype=torch.float64: the same loop with the model, its inputs and the optimizer state in double precision -- the
+    yardstick for quantities that sit at the noise floor of fp32 arithmetic (parameter norms after a few AdamW steps:
+    elements whose gradient is rounding noise move by +-lr in ANY fp32 implementation, the reference's included)."""
     models, losses, decode = ref
     net = models.__dict__['resnet50_retinanet'](num_classes=80)
     net.load_state_dict(omodel.init_retinanet_state(0), strict=True)
+    net = net.to(dtype)
     net.train()
     crit = losses.__dict__['RetinaLoss']()
     cfg = _Cfg()
@@ -567,7 +571,7 @@ def _run_reference_loop(ref, tu, H, W, n_iters, accumulation_steps=1, clip_grad_
     iter_index, epoch, seen = 1, 1, 0
     data_i = 0
     while seen < n_iters:
-        images = torch.tensor(synth.images(40 + data_i, 2, H, W))
+        images = torch.tensor(synth.images(40 + data_i, 2, H, W)).to(dtype)
         annots = torch.tensor(synth.annotations(60 + data_i, 2, H, W, boxes_per_image=6))
         if bad_iter is not None and data_i == bad_iter:
             annots[0, 0, 0] = float('inf')  # an inf in the annotations: the input guard must skip the batch
@@ -641,6 +645,23 @@ def sec_trainer(ref):
     H, W = MID
     rec, _ = _run_reference_loop(ref, tu, H, W, 3)
     out['plain3_MID'] = rec
+    # fp64 yardsticks of the two plain runs: the same loop in double precision.  module_param_norm_fp64 is what the
+    # parameter norms converge to; |fp32 reference - fp64| per module is the reference arithmetic's own noise.
+    for case, (H, W) in (('plain3', TINY), ('plain3_MID', MID)):
+        rec64, _ = _run_reference_loop(ref, tu, H, W, 3, dtype=torch.float64)
+        out[case]['module_param_norm_fp64'] = rec64['module_param_norm']
+        out[case]['module_delta_norm_fp64'] = rec64['module_delta_norm']
+        out[case]['loss_fp64'] = [it['loss'] for it in rec64['iters']]
+        worst = max(abs(out[case]['module_param_norm'][k] - v) / v for k, v in rec64['module_param_norm'].items())
+        print(case, 'fp32 reference vs fp64: worst module parameter-norm distance', worst)
+    # the clipped total gradient norms of the accumulation run in double precision (96 x 128: BatchNorm statistics over
+    # 24 pixels in layer4 -- the gradient is ill-conditioned, the fp32 reference itself is percents away from fp64)
+    rec64, _ = _run_reference_loop(ref, tu, TINY[0], TINY[1], 4, accumulation_steps=2, clip_grad_value=0.05,
+                                   clip_max_norm=0.5, iters_per_epoch=4, epochs=3,
+                                   sched=('CosineLR', {'warm_up_epochs': 1, 'min_lr': 1e-6}), dtype=torch.float64)
+    out['accum2_clip']['grad_norm_fp64'] = [it['grad_norm'] for it in rec64['iters'] if 'grad_norm' in it]
+    print('accum2_clip grad norms fp32', [it['grad_norm'] for it in out['accum2_clip']['iters'] if 'grad_norm' in it],
+          'fp64', out['accum2_clip']['grad_norm_fp64'])
     json.dump(out, open(os.path.join(GOLD, 'trainer.json'), 'w'))
     for k, v in out.items():
         print(k, [(i['loss'], i['skipped']) for i in v['iters']], v['opt_steps'])

@@ -43,6 +43,8 @@ SIGNATURES = {
     'sacv_im2col_stem': (I, [P, P, I, I, I, I, LL, LL, LL, LL, I, I, I, I, I, I, I, P]),
     'sacv_stem_conv_stats_rows': (I, [I, I, I]),
     'sacv_stem_conv_fwd': (I, [P, I, I, I, LL, LL, LL, LL, P, I, P, I, I, P, P]),
+    'sacv_stem_conv_wgrad_workspace_bytes': (LL, [I, I, I]),
+    'sacv_stem_conv_wgrad': (I, [P, I, I, I, LL, LL, LL, LL, P, I, I, P, P, I, P]),
     'sacv_bn_workspace_floats': (LL, [I, I]),
     'sacv_bn_fold_batched': (I, [P, I, F, P]),
     'sacv_bn_train_stats': (I, [P, I, I, F, F, P, P, P, P, P, P, P]),

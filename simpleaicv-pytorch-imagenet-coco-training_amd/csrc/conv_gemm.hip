@@ -25,8 +25,6 @@
 #include <stdlib.h>
 
 #define SACV_MAXP 8
-#define SACV_MAX_TICKETS 1024  // arrival counters at the head of the split-K workspace (remainder tiles < grid <= 768)
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef SACV_SGB_VALU
 #define SACV_SGB_VALU 5
 #endif
@@ -91,7 +89,6 @@ struct ConvArgs {
   int grid, base, rem_tiles, sk_blocks;
   float* partial;  // [slots][BM][BN] row-major K-slice tiles
   float* stats;    // [total_mtiles][2][N] column sum / sum of squares (CF_STATS)
-  int* tickets;    // [rem_tiles] arrival counters of the split remainder tiles: zero between launches
 };
 
 struct TileCoord {
@@ -120,12 +117,9 @@ __device__ __forceinline__ TileCoord tile_coord(const ConvArgs& a, int tile) {
 // CF_STATS: per-column sum and sum of squares of the STORED values over the tile's valid rows go to
 // stats[mt][0][n] / stats[mt][1][n] (mt = global M-tile index) -- the BatchNorm batch statistics of a
 // forward conv, or the bias gradient when the stored value is a dy.  Fixed order => deterministic.
-// VL > 1 (CF_STATS of a split tile summed inside the main kernel): a thread plays VL row lanes of a wider workgroup --
-// row lane rr + RS * j takes rows = rr + RS * j (mod RS * VL) and keeps its own column sums -- so that the sums are
-// added in exactly the order of a workgroup of NT * VL threads (the 1024-thread fix-up of rounds 1-3: same bits).
-template <int BM, int BN, int NT, int VL = 1, typename RowFn>
+template <int BM, int BN, int NT, typename RowFn>
 __device__ __forceinline__ void vec_epilogue(const ConvArgs& a, const TileCoord& tc, int mt, RowFn get_row,
-                                             float* red /* LDS scratch, 2*VL*(NT/(BN/4))*BN floats, CF_STATS only */) {
+                                             float* red /* LDS scratch, 2*(NT/(BN/4))*BN floats, CF_STATS only */) {
   constexpr int CG = BN / 4;
   constexpr int RS = NT / CG;  // row lanes
   const int t = threadIdx.x;
@@ -140,16 +134,10 @@ __device__ __forceinline__ void vec_epilogue(const ConvArgs& a, const TileCoord&
   if ((flags & CF_BIAS) && nok) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
   // an eval-mode BatchNorm folded into the convolution: per-channel scale (gamma / sqrt(var + eps)) and shift
   if ((flags & CF_AFFINE) && nok) sv = *reinterpret_cast<const f32x4*>(a.bias + N + n);
-  f32x4 ssum[VL], ssq[VL];
-#pragma unroll
-  for (int j = 0; j < VL; ++j) {
-    ssum[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    ssq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
   const int hw = P.Hd * P.Wd;
 #pragma unroll 4
-  for (int it = 0; it < BM / RS; ++it) {
-    const int row = rr + it * RS;
+  for (int row = rr; row < BM; row += RS) {
     const int m = tc.m0 + row;
     if (!(nok && m < M)) continue;
     f32x4 v = get_row(row, c4);
@@ -179,31 +167,18 @@ __device__ __forceinline__ void vec_epilogue(const ConvArgs& a, const TileCoord&
       for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
     }
     *reinterpret_cast<f32x4*>(dst + o) = v;
-    if (VL == 1) {
-      ssum[0] += v;
-      ssq[0] += v * v;
-    } else {
-#pragma unroll
-      for (int j = 0; j < VL; ++j)  // (it % VL is a compile-time constant once the row loop is unrolled by 4)
-        if ((it % VL) == j) {
-          ssum[j] += v;
-          ssq[j] += v * v;
-        }
-    }
+    ssum += v;
+    ssq += v * v;
   }
   if (flags & CF_STATS) {
-    constexpr int RSV = RS * VL;  // (virtual) row lanes
     __syncthreads();  // callers' row sources (LDS stage) are dead from here on
-#pragma unroll
-    for (int j = 0; j < VL; ++j) {
-      *reinterpret_cast<f32x4*>(red + (size_t)(rr + RS * j) * BN + c4 * 4) = ssum[j];
-      *reinterpret_cast<f32x4*>(red + (size_t)(RSV + rr + RS * j) * BN + c4 * 4) = ssq[j];
-    }
+    *reinterpret_cast<f32x4*>(red + (size_t)rr * BN + c4 * 4) = ssum;
+    *reinterpret_cast<f32x4*>(red + (size_t)(RS + rr) * BN + c4 * 4) = ssq;
     __syncthreads();
     for (int c = t; c < 2 * BN; c += NT) {
       const int which = c / BN, col = c - which * BN;
       float acc = 0.f;
-      for (int l = 0; l < RSV; ++l) acc += red[(size_t)(which * RSV + l) * BN + col];
+      for (int l = 0; l < RS; ++l) acc += red[(size_t)(which * RS + l) * BN + col];
       if (tc.n0 + col < N) a.stats[((size_t)mt * 2 + which) * N + tc.n0 + col] = acc;
     }
   }
@@ -212,80 +187,6 @@ __device__ __forceinline__ void vec_epilogue(const ConvArgs& a, const TileCoord&
 // first K-iteration (in the end-to-end numbering of the remainder tiles) of stream-K block b
 __device__ __forceinline__ int sk_range_begin(const ConvArgs& a, int KT, int b) {
   return (int)(((long long)b * a.rem_tiles * KT) / a.sk_blocks);
-}
-
-// A workgroup has written its K-slice of remainder tile `tile`, drained the stores, passed a barrier and taken arrival
-// ticket `ticket` (thread 0's value counts): the LAST arriver sums the slabs of the tile in block (= K) order -- the
-// order is fixed, whoever arrives last -- and applies the epilogue.  Replaces the conv_fixup_kernel launch of rounds
-// 1-3 (72 dependent launches per RetinaNet step, 1.8 ms of the launch queue's time in the overlapped trace).
-// `lds`: the workgroup's dynamic LDS (free).
-template <int BM, int BN, int NT>
-__device__ __forceinline__ void split_tile_finish(const ConvArgs& a, int tile, int ticket, int KT, float* lds) {
-  int* slab_of = reinterpret_cast<int*>(lds);  // [0] = number of parts (0: not the last arriver), [1 + i] = slab i
-  const int rt = tile - a.base * a.grid;
-  if (threadIdx.x == 0) {
-    // blocks whose ranges hold the first and the last K-iteration of this tile
-    const int u_first = rt * KT, u_last = u_first + KT - 1;
-    const long long U = (long long)a.rem_tiles * KT;
-    int b_first = (int)(((long long)u_first * a.sk_blocks) / U);
-    while (sk_range_begin(a, KT, b_first + 1) <= u_first) ++b_first;
-    while (sk_range_begin(a, KT, b_first) > u_first) --b_first;
-    int b_last = (int)(((long long)u_last * a.sk_blocks) / U);
-    while (sk_range_begin(a, KT, b_last + 1) <= u_last) ++b_last;
-    while (sk_range_begin(a, KT, b_last) > u_last) --b_last;
-    int n = 0;
-    for (int b = b_first; b <= b_last && n < 255; ++b) {
-      const int ub = sk_range_begin(a, KT, b);
-      if (sk_range_begin(a, KT, b + 1) == ub) continue;
-      slab_of[1 + n++] = 2 * b + ((ub / KT == rt) ? 0 : 1);
-    }
-    const bool last = ticket == n - 1;
-    if (last) {
-      __hip_atomic_store(a.tickets + rt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero for the next launch
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (the add returned long ago) this CU's L1 drops its lines
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the invalidate has completed before the barrier opens
-    }
-    slab_of[0] = last ? n : 0;
-  }
-  __syncthreads();
-  const int nparts = slab_of[0];
-  if (nparts == 0) return;  // (workgroup-uniform)
-  const int ntn = (a.N + BN - 1) / BN;
-  const TileCoord tc = tile_coord<BM, BN>(a, tile);
-  // Sum of the slabs in part (= K) order into an LDS image of the tile, every row of a thread requested at once and two
-  // parts in flight (the finishing workgroup is alone with the tile: its loads' latency is the launch's tail)
-  constexpr int CG = BN / 4, RS = NT / CG, RPT = BM / RS, CS = BN + 4;
-  float* stage = lds + 256;
-  {
-    const int c4 = threadIdx.x % CG, rr = threadIdx.x / CG;
-    f32x4 v[RPT];
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int part = 0;
-    for (; part + 1 < nparts; part += 2) {
-      const float* s0 = a.partial + (size_t)slab_of[1 + part] * (BM * BN) + c4 * 4;
-      const float* s1 = a.partial + (size_t)slab_of[2 + part] * (BM * BN) + c4 * 4;
-      f32x4 p0[RPT], p1[RPT];
-#pragma unroll
-      for (int i = 0; i < RPT; ++i) p0[i] = *reinterpret_cast<const f32x4*>(s0 + (rr + i * RS) * BN);
-#pragma unroll
-      for (int i = 0; i < RPT; ++i) p1[i] = *reinterpret_cast<const f32x4*>(s1 + (rr + i * RS) * BN);
-#pragma unroll
-      for (int i = 0; i < RPT; ++i) v[i] = (v[i] + p0[i]) + p1[i];
-    }
-    if (part < nparts) {
-      const float* s0 = a.partial + (size_t)slab_of[1 + part] * (BM * BN) + c4 * 4;
-#pragma unroll
-      for (int i = 0; i < RPT; ++i) v[i] += *reinterpret_cast<const f32x4*>(s0 + (rr + i * RS) * BN);
-    }
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) *reinterpret_cast<f32x4*>(stage + (rr + i * RS) * CS + c4 * 4) = v[i];
-  }
-  __syncthreads();
-  // CF_STATS: column sums in the order of the 1024-thread fix-up workgroup of rounds 1-3 (VL = 4 virtual row lanes)
-  vec_epilogue<BM, BN, NT, 1024 / NT>(
-      a, tc, tile / ntn, [&](int row, int c4) { return *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4); },
-      stage /* the column-sum scratch reuses the tile image: vec_epilogue passes a barrier before it writes there */);
 }
 
 // OCC = workgroups per CU the launch bounds allow for; SWZ = unpadded LDS rows (32 floats) with the 16-byte chunks
@@ -487,9 +388,6 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
   __syncthreads();
   SACV_STAMP_HERE();
   int cur = 0;
-  // split tiles this workgroup contributed a slab to (at most two: the ends of its stream-K range); thread 0 holds the
-  // arrival tickets
-  int pend_tile[2] = {0, 0}, pend_ticket[2] = {0, 0}, npend = 0;
   for (int sidx = 0; sidx < nseg; ++sidx) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -594,29 +492,14 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
             [&](int row, int c4) { return *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4); },
             smem + BM * CS);
       } else {
-        // K-slice of a split tile: a row-major slab, then an arrival ticket on the tile; the workgroup whose ticket is
-        // the last one sums the tile's slabs in block (= K) order and runs the epilogue -- after its own K loops
-        // (split_tile_finish, at the end of the kernel: nothing of the gather pipeline is live there).  No workgroup
-        // waits for another one.  Hand-off form (cdna_hip_programming.md Guideline 16, R1): the slab goes out as
-        // write-through (sc1) 16-byte stores, every storing wave drains them, the workgroup's barrier, then ONE lane's
-        // agent-scope add; the last arriver: ONE agent-scope acquire, its wait, the barrier, plain loads.
+        // K-slice of a split tile: row-major slab for the fix-up kernel
         float* dst = a.partial + (size_t)my_slot * (BM * BN);
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, BM * BN * 4, 0x00020000);
         constexpr int CG = BN / 4, RS = NT / CG;
         const int c4 = tid % CG, rr = tid / CG;
 #pragma unroll 4
-        for (int row = rr; row < BM; row += RS) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (row * BN + c4 * 4) * 4, 0,
-                                                 16 /* sc1: write-through */);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, before the barrier in front of the ticket
-        __syncthreads();                                   // (the stage is also fully read here)
-        if (tid == 0)
-          pend_ticket[npend] = __hip_atomic_fetch_add(a.tickets + (my_tile - a.base * a.grid), 1, __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT);
-        pend_tile[npend] = my_tile;
-        ++npend;
+        for (int row = rr; row < BM; row += RS)
+          *reinterpret_cast<f32x4*>(dst + row * BN + c4 * 4) =
+              *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4);
       }
       if (more) {
         __syncthreads();  // stage fully consumed
@@ -627,11 +510,63 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
       SACV_STAMP_HERE();  // end of epilogue (+ next slab in LDS)
     }
   }
-  // ---- split tiles whose last slab was ours
-  for (int q = 0; q < npend; ++q) {
-    __syncthreads();  // the LDS is free (previous epilogue / previous finish)
-    split_tile_finish<BM, BN, NT>(a, pend_tile[q], q == 0 ? pend_ticket[0] : pend_ticket[1], KT, smem);
+}
+
+// Sums the stream-K slabs of each remainder tile in block order (deterministic) and applies the epilogue.
+// (Round 4 built the alternative -- the slabs summed and the tile finished INSIDE conv_nt_kernel by the workgroup that
+// arrives last at a per-tile ticket: write-through slab stores, drained, one agent-scope add per workgroup, one acquire in
+// the finisher, the finish deferred to the end of the workgroup's K loops, column sums in this kernel's order by four
+// virtual row lanes per thread; commit f65708e, outputs and CF_STATS sums bit-identical to this kernel on 26 shapes.  72
+// launches fewer per RetinaNet step and the same step time: 27.13 vs 27.11 ms in a same-session A/B -- one 256-thread
+// workgroup per tile finishing after everybody else has left is as long a tail as this launch.  Not adopted.)
+// NT = 1024: one workgroup per tile (the form CF_STATS needs: the tile's column sums come out of one workgroup).
+// NT = 256, QS = 4: four workgroups per tile, 32 rows each -- for launches without CF_STATS.  In the backward pass the
+// fix-up shares the chip with the weight gradients of the side stream, whose persistent workgroups hold most of every
+// CU's registers: a 1024-thread workgroup has to wait for a CU to drain (13 us alone became 25-44 us there), 256-thread
+// ones fit into what is left.
+template <int BM, int BN, int NT = 1024, int QS = 1>
+__global__ __launch_bounds__(NT) void conv_fixup_kernel(const ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[QS == 1 ? 2 * (NT / (BN / 4)) * BN : 4];
+  __shared__ int slab_of[256];
+  __shared__ int nparts_s;
+  const int rt = blockIdx.x / QS;
+  const int qrow = (blockIdx.x % QS) * (BM / QS);  // first tile row of this workgroup
+  const int ntn = (a.N + BN - 1) / BN;
+  const int KT = a.KH * a.KW * ((a.Cs + 31) >> 5);
+  const int tile = a.base * a.grid + rt;
+  // blocks whose ranges hold the first and the last K-iteration of this tile
+  const int u_first = rt * KT, u_last = u_first + KT - 1;
+  const long long U = (long long)a.rem_tiles * KT;
+  int b_first = (int)(((long long)u_first * a.sk_blocks) / U);
+  while (sk_range_begin(a, KT, b_first + 1) <= u_first) ++b_first;
+  while (sk_range_begin(a, KT, b_first) > u_first) --b_first;
+  int b_last = (int)(((long long)u_last * a.sk_blocks) / U);
+  while (sk_range_begin(a, KT, b_last + 1) <= u_last) ++b_last;
+  while (sk_range_begin(a, KT, b_last) > u_last) --b_last;
+  if (b_first == b_last) return;  // one block held the whole tile and finished it in place
+  if (threadIdx.x == 0) {
+    int n = 0;
+    for (int b = b_first; b <= b_last && n < 256; ++b) {
+      const int ub = sk_range_begin(a, KT, b);
+      if (sk_range_begin(a, KT, b + 1) == ub) continue;
+      slab_of[n++] = 2 * b + ((ub / KT == rt) ? 0 : 1);
+    }
+    nparts_s = n;
   }
+  __syncthreads();
+  const int nparts = nparts_s;
+  TileCoord tc = tile_coord<BM, BN>(a, tile);
+  tc.m0 += qrow;
+  vec_epilogue<BM / QS, BN, NT>(
+      a, tc, tile / ntn,
+      [&](int row, int c4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int part = 0; part < nparts; ++part)
+          v += *reinterpret_cast<const f32x4*>(a.partial + (size_t)slab_of[part] * (BM * BN) + (qrow + row) * BN +
+                                               c4 * 4);
+        return v;
+      },
+      red);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1172,28 +1107,27 @@ static int launch_nt(ConvArgs& a, const NtPlan& plan, float* workspace, hipStrea
   a.base = plan.base;
   a.rem_tiles = plan.rem;
   a.sk_blocks = plan.sk_blocks;
-  // workspace = [SACV_MAX_TICKETS arrival counters | 2 slabs per workgroup]; the counters are zero between launches
-  a.tickets = reinterpret_cast<int*>(workspace);
-  a.partial = workspace ? workspace + SACV_MAX_TICKETS : nullptr;
+  a.partial = workspace;
   size_t lds = (size_t)2 * (BM + BN) * (SWZ ? 32 : 36) * sizeof(float);
   size_t lds_epi = ((size_t)BM * (BN + 4) + 2 * (128 * WN / (BN / 4)) * BN) * sizeof(float);
   if (lds_epi > lds) lds = lds_epi;
-  // split-tile finish: slab list (1 KB) + tile image + column-sum scratch of 1024 / NT virtual row lanes per thread
-  size_t lds_fin = (256 + (size_t)BM * (BN + 4)) * sizeof(float);
-  static_assert((size_t)BM * (BN + 4) >= (size_t)2 * (1024 / (BN / 4)) * BN, "column-sum scratch inside the tile image");
-  if (lds_fin > lds) lds = lds_fin;
   static std::once_flag attr_once;  // one per template instance; lds is a compile-time function of it
   std::call_once(attr_once, [lds] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN, MODE, WN, OCC, SWZ>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   int launch_blocks = a.base > 0 ? grid : a.sk_blocks;
-  SACV_CHECK_ARG(a.sk_blocks <= grid && (a.sk_blocks == 0 || a.sk_blocks >= a.rem_tiles) &&
-                     a.rem_tiles <= SACV_MAX_TICKETS,
-                 "conv2d_gemm: stream-K plan outside the workspace (%d ranges, %d tiles)", a.sk_blocks, a.rem_tiles);
-  // (split remainder tiles are summed and finished by their last-arriving workgroup: no second launch)
+  SACV_CHECK_ARG(a.sk_blocks <= grid && (a.sk_blocks == 0 || a.sk_blocks >= a.rem_tiles),
+                 "conv2d_gemm: stream-K plan outside the workspace (%d ranges)", a.sk_blocks);
   hipLaunchKernelGGL((conv_nt_kernel<BM, BN, MODE, WN, OCC, SWZ>), dim3(launch_blocks), dim3(128 * WN), lds, st, a);
   SACV_CHECK_LAUNCH("conv_nt_kernel");
+  if (a.sk_blocks > a.rem_tiles) {
+    if (a.flags & CF_STATS)
+      hipLaunchKernelGGL((conv_fixup_kernel<BM, BN>), dim3(a.rem_tiles), dim3(1024), 0, st, a);
+    else
+      hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, 256, 4>), dim3(a.rem_tiles * 4), dim3(256), 0, st, a);
+    SACV_CHECK_LAUNCH("conv_fixup_kernel");
+  }
   return SACV_OK;
 }
 
@@ -1346,11 +1280,9 @@ int sacv_conv2d_gemm_stats_rows(int nprob, const int* Nb, const int* Hd, const i
   return rows;
 }
 
-// Bytes of split-K workspace sacv_conv2d_gemm wants (it runs unsplit when given NULL).  The caller zero-fills it ONCE
-// (its first 4 KB hold arrival counters that every call leaves at zero); one workspace per stream.
+// Bytes of split-K workspace sacv_conv2d_gemm wants (it runs unsplit when given NULL).
 long long sacv_conv2d_gemm_workspace_bytes(void) {
-  return SACV_MAX_TICKETS * (long long)sizeof(int) +
-         2LL * num_cus() * SACV_NT_BLOCKS_PER_CU * 128 * 128 * (long long)sizeof(float);  // 2 slabs per workgroup
+  return 2LL * num_cus() * SACV_NT_BLOCKS_PER_CU * 128 * 128 * (long long)sizeof(float);  // 2 slabs per workgroup
 }
 
 // Workspace (bytes) needed by sacv_conv2d_wgrad for the given problem list.

@@ -60,14 +60,13 @@ class DetectorEngine:
         # Winograd F(2x2,3x3) for the stride-1 3x3 head convolutions (csrc/winograd.hip): layer i of both towers in
         # one launch.  False selects the direct implicit-GEMM kernel for every conv (A/B measurements, tests).
         self.winograd = True
-        # The 7x7 stem without the im2col matrix (csrc/stem_conv.hip: 113 us instead of 142 + 140).  'eval': forward
-        # passes that keep nothing for a backward pass (evaluation, inference) use it; a TRAINING step keeps the
-        # im2col + GEMM pair -- its weight gradient contracts with the im2col matrix anyway (rebuilt on the side stream
-        # when the forward pass did not write it: one more launch competing with the weight gradients there), the step
-        # did not get faster in the A/B (27.27-27.34 ms with, 27.20-27.25 without), and the different summation order of
-        # the stem moves the 3-step AdamW fixture of SURVEY.md 8a-13 (1e-5 on the parameter norms) to 1.06e-5.
-        # True forces it everywhere, False nowhere (tests, A/B).
-        self.fused_stem = 'eval'
+        # The 7x7 stem without the im2col matrix (csrc/stem_conv.hip): the forward pass reads the image itself (124 us
+        # instead of 143 + 155 for im2col + GEMM) and so does the weight gradient (121 us instead of 207 for conv_tn on the
+        # matrix + its reduction) -- the last kernel of the backward pass, alone on the chip while the optimizer waits.
+        # Round 3 had the forward kernel only and kept the matrix in training (its weight gradient needed it anyway);
+        # with both, the 341 MB matrix is gone from the step.  False: im2col + GEMM everywhere (tests, A/B); 'eval': the
+        # round-3 arrangement (image-reading forward only in passes that keep nothing for a backward pass).
+        self.fused_stem = True
         # Evaluation passes fold every BatchNorm into its convolution's epilogue (one batched launch computes the
         # scales / shifts from the running statistics per forward pass): 53 bn_apply passes = 1.28 of the 8.9 ms of an
         # eval forward + decode at 2 x 800x1333.  False: conv + bn_apply as in training (tests, A/B).
@@ -1081,15 +1080,9 @@ class DetectorEngine:
         bn = bp + 'conv1.layer.1.'
         dy, _ = ops.bn_train_bwd(dpool, None, st.y, st.mean, st.invstd, self.p[bn + 'weight'], self.g[bn + 'weight'],
                                  self.g[bn + 'bias'], relu_beta=self.p[bn + 'bias'])
-        if st.x is None:  # fused stem forward: no im2col matrix was kept
+        if st.x is None:  # fused stem forward: no im2col matrix was kept -- the weight gradient reads the image too
             img = ctx['stem_images']
-            kpad = ops.stem_kpad(st.k, img.shape[1])
-
-            def stem_wgrad():
-                col = ops.im2col_stem(img, dy.shape[1], dy.shape[2], st.k, st.k, st.stride, st.pad)
-                ops.conv_wgrad([dy], [col], self.g[bp + 'conv1.layer.0.weight'], 3, 1, 1, 1, 0, cin_pad=kpad,
-                               dw_taps=st.k * st.k)
-            self._on_side(stem_wgrad, [dy, img])
+            self._on_side(lambda: ops.stem_conv_wgrad(img, dy, self.g[bp + 'conv1.layer.0.weight']), [dy, img])
         else:
             self._wgrad([dy], [st.x], self.g[bp + 'conv1.layer.0.weight'], 3, 1, 1, 1, 0,
                         cin_pad=st.x.shape[-1], dw_taps=st.k * st.k)

@@ -191,7 +191,7 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
             iarr([hw[0] for hw in out_hw]), iarr([hw[1] for hw in out_hw]),
             _ptr(w_packed), _ptr(bias), cs, n_out, kh, kw, stride, pad, mode, flags, rs, hr, wr,
             iarr(ext) if ext is not None else None,
-            workspace(_gemm_ws_bytes(), srcs[0].device, 'conv_gemm', zero=True).data_ptr(), _ptr(stats_buf), _stream()),
+            workspace(_gemm_ws_bytes(), srcs[0].device, 'conv_gemm').data_ptr(), _ptr(stats_buf), _stream()),
             'conv2d_gemm')
 
     if TIMER is not None:
@@ -453,15 +453,12 @@ _ws_cache = {}
 WS_SUFFIX = ''  # set by a caller that enqueues on another stream (engine._on_side): that stream's own scratch buffers
 
 
-def workspace(nbytes, device, tag='ws', zero=False):
-    """Grow-only scratch buffer per tag (kernels on one stream reuse it in order).  zero=True: zero-filled when it is
-    (re)allocated -- the split-K workspace of sacv_conv2d_gemm starts with arrival counters that every call leaves at
-    zero (include/sacv_hip.h)."""
+def workspace(nbytes, device, tag='ws'):
+    """Grow-only scratch buffer per tag (kernels on one stream reuse it in order)."""
     key = (tag + WS_SUFFIX, device)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        alloc = torch.zeros if zero else torch.empty
-        buf = alloc(max(int(nbytes), 1 << 20), device=device, dtype=torch.uint8)
+        buf = torch.empty(max(int(nbytes), 1 << 20), device=device, dtype=torch.uint8)
         _ws_cache[key] = buf
     return buf
 
@@ -564,6 +561,30 @@ def stem_conv(x_nchw_logical, wpanel, ho, wo, stats=False):
     else:
         launch()
     return (y, st) if stats else y
+
+
+def stem_conv_wgrad(x_nchw_logical, dy, dw, accumulate=False):
+    """dw [64,3,7,7] (+)= weight gradient of the 7x7/s2/p3 stem convolution from the image (logical [N,3,H,W], any
+    strides) and dy [N,ho,wo,64]: no im2col matrix (csrc/stem_conv.hip)."""
+    x = x_nchw_logical
+    if x.device.type != 'cuda' or x.dtype != torch.float32 or x.shape[1] != 3:
+        raise ValueError('stem_conv_wgrad: expected an fp32 CUDA(HIP) image batch [N,3,H,W]')
+    _chk(dy, 'stem_conv_wgrad dy')
+    if tuple(dw.shape) != (64, 3, 7, 7) or not dw.is_contiguous():
+        raise ValueError(f'stem_conv_wgrad: dw is {tuple(dw.shape)} (strides {dw.stride()}), expected contiguous [64,3,7,7]')
+    n, _, h, w = x.shape
+    sn, sc, sh, sw = x.stride()
+    ho, wo = dy.shape[1], dy.shape[2]
+    ws = workspace(lib.sacv_stem_conv_wgrad_workspace_bytes(n, ho, wo), x.device, 'stem_wgrad')
+
+    def launch():
+        check(lib.sacv_stem_conv_wgrad(_ptr(x), n, h, w, sn, sc, sh, sw, _ptr(dy), ho, wo, _ptr(dw), ws.data_ptr(),
+                                       int(accumulate), _stream()), 'stem_conv_wgrad')
+    if TIMER is not None:
+        TIMER.time('conv_tn_stem|k7 s2 ci3 co64 np1', 2.0 * n * ho * wo * 64 * 147, launch)
+    else:
+        launch()
+    return dw
 
 
 # ------------------------------------------------------------------------------------------ norm

@@ -318,6 +318,39 @@ def test_stem_conv_without_im2col(ops, hw):
     assert float((y3 - y).abs().max()) <= 1e-5 * scale  # (not bit-identical: the GEMM path may split K over workgroups)
 
 
+@pytest.mark.parametrize('hw', [(70, 93), (64, 128), (33, 31), (9, 200), (800, 1333)])
+def test_stem_wgrad_without_im2col(ops, hw):
+    """sacv_stem_conv_wgrad (the stem's weight gradient from the image and dy) vs torch's conv2d backward in fp64, for
+    NCHW-contiguous and channels_last images, odd sizes (partial tiles in both directions), accumulation into dw, run to
+    run bit stability, and against the im2col + conv_tn path it replaces."""
+    H, W = hw
+    x = torch.from_numpy(synth.images(3, 2, H, W))
+    wt = rnd(7, 64, 3, 7, 7, std=0.05)
+    wr = wt.double().requires_grad_(True)
+    yr = F.conv2d(x.double(), wr, None, 2, 3)
+    dy = rnd(8, *yr.shape)
+    yr.backward(dy.double())
+    ho, wo = yr.shape[2:]
+    want = wr.grad
+    scale = float(want.abs().max())
+    dyd = nhwc(dy)
+    first = None
+    for img in (x.cuda(), x.cuda().contiguous(memory_format=torch.channels_last)):
+        dw = torch.full((64, 3, 7, 7), float('nan'), device='cuda')
+        ops.stem_conv_wgrad(img, dyd, dw)
+        assert float((dw.cpu().double() - want).abs().max()) <= 2e-5 * scale
+        first = dw.clone() if first is None else first
+        assert torch.equal(dw, first)  # same bits for both image layouts and from run to run
+    acc = rnd(9, 64, 3, 7, 7).cuda()
+    got = acc.clone()
+    ops.stem_conv_wgrad(x.cuda(), dyd, got, accumulate=True)
+    assert float((got.cpu().double() - (acc.cpu().double() + want)).abs().max()) <= 2e-5 * scale + 1e-6
+    col = ops.im2col_stem(x.cuda(), ho, wo)
+    dw2 = torch.empty((64, 3, 7, 7), device='cuda')
+    ops.conv_wgrad([dyd], [col], dw2, 3, 1, 1, 1, 0, cin_pad=ops.STEM_KPAD, dw_taps=49)
+    assert float((dw2 - first).abs().max()) <= 2e-5 * scale
+
+
 # ----------------------------------------------------------------------------------------- norm / pointwise
 @pytest.mark.parametrize('shape', [(2, 64, 50, 67), (2, 256, 13, 21), (2, 2048, 4, 6), (2, 1024, 7, 11)])
 @pytest.mark.parametrize('relu,res', [(True, False), (True, True), (False, False)])

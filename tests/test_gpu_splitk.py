@@ -1,8 +1,8 @@
-"""Split remainder tiles of the implicit-GEMM convolution (stream-K / uniform K split): since round 4 the partial slabs
-of a tile are summed and finished INSIDE the launch by the workgroup that arrives last (csrc/conv_gemm.hip:
-split_tile_finish; agent-scope hand-off of write-through slabs + an arrival ticket).  These tests hammer that hand-off:
-alternating inputs through the same slab addresses (a stale L1 / L2 line would surface as the previous problem's
-values), uneven load from a second stream, run-to-run bit stability, and the arrival counters left at zero."""
+"""Split remainder tiles of the implicit-GEMM convolution (stream-K / uniform K split): partial slabs of a tile meet in
+the workspace and are summed in a fixed order (csrc/conv_gemm.hip: conv_fixup_kernel).  These tests hammer the slab
+path: alternating inputs through the same slab addresses (a stale slab would surface as the previous problem's values),
+uneven load from a second stream, run-to-run bit stability.  (Written for round 4's in-kernel finish by the last-arriving
+workgroup -- measured a tie with the fix-up launch and not adopted -- and kept for the launch that stayed.)"""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -69,8 +69,6 @@ def test_split_tiles_alternating_inputs_under_load(ops, case):
             assert torch.equal(y, first[j][0]), f'iteration {it}: output differs from the first run of input {j}'
             assert torch.equal(st, first[j][1]), f'iteration {it}: column sums differ'
     torch.cuda.synchronize()
-    ws = ops.workspace(ops._gemm_ws_bytes(), torch.device('cuda', torch.cuda.current_device()), 'conv_gemm', zero=True)
-    assert int(ws[:4096].view(torch.int32).abs().max()) == 0, 'arrival counters are not back at zero'
 
 
 def test_split_tiles_data_gradient_epilogues(ops):

@@ -469,6 +469,9 @@ def main():
                          'padded square S2 (SURVEY.md 8d)')
     ap.add_argument('--class-table', default='',
                     help='write the per-conv-class roofline table (MFMA and HBM fractions) to this JSON file')
+    ap.add_argument('--engine-set', action='append', default=[], metavar='NAME=VALUE',
+                    help='A/B runs: set an attribute of the model\'s executor before the first step, e.g. '
+                         '--engine-set fuse_bn_bwd=False (value: a Python literal)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help='bf16: the autocast recipe of resnet50_cls (BASELINE config #2); the detection recipes run '
                          'fp32 (use_amp=False in their train_config.py)')
@@ -544,6 +547,12 @@ def main():
         crit = losses.__dict__['RetinaLoss'](box_loss_type='SmoothL1')
     trainer = DetectionTrainer(net, crit, lr=1e-4, weight_decay=1e-3, process_group=group,
                                transport=os.environ.get('SACV_TRANSPORT', 'torch'))
+    import ast
+    for kv in args.engine_set:
+        name, value = kv.split('=', 1)
+        if not hasattr(net.engine, name):
+            raise SystemExit(f'--engine-set: the executor has no attribute {name!r}')
+        setattr(net.engine, name, ast.literal_eval(value))
     images = torch.tensor(synth.images(rank, BATCH, H, W)).cuda()
     annots = torch.tensor(synth.annotations(rank, BATCH, H, W, boxes_per_image=8)).cuda()
 

@@ -74,6 +74,18 @@ int sacv_conv2d_gemm(int nprob, const float* const* src /*host array*/, float* c
  * per pixel on average instead of 9). */
 long long sacv_conv2d_gemm_workspace_bytes(void);
 int sacv_conv2d_gemm_stats_rows(int nprob, const int* Nb, const int* Hd, const int* Wd);
+/* One problem of sacv_conv2d_gemm -- a data gradient (mode 1) in the backward pass of conv -> BatchNorm -> ReLU
+ * (classification/backbones/resnet.py:33-48; autograd's native_batch_norm_backward in the reference) -- whose output
+ * dz [M][N] is the upstream gradient of a BatchNorm layer with input bn_y [M][N]: the epilogue also writes that layer's
+ * backward partial sums, stats[m tile] = (sum g, sum g * xhat) with g = dz * (z > 0) and xhat = (y - mean) * invstd, for
+ * sacv_bn_train_bwd_partial.  Mask: bn_z (the stored layer output), or recomputed from y with bn_gamma / bn_beta when bn_z
+ * is NULL (bn_beta NULL too: no ReLU).  flags: SACV_CF_ACCUM / SACV_CF_MASK / SACV_CF_BIAS; stats:
+ * sacv_conv2d_gemm_stats_rows(1, ...) rows of [2][N]. */
+int sacv_conv2d_gemm_bnbwd(const float* src, float* dst, const float* mask, int Nb, int Hs, int Ws, int Hd, int Wd,
+                           const float* w, const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode,
+                           int flags, float* workspace, float* stats, const float* bn_y, const float* bn_z,
+                           const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                           void* stream);
 
 /* ---- Winograd F(2x2,3x3) path of the stride-1 3x3 head convolutions (head.py:20-36, 55-70, 103-141: nn.Conv2d
  *      3x3 / pad 1 over the 5 pyramid levels).  Three steps: weights -> U (once per optimizer step), input -> V,
@@ -173,6 +185,12 @@ int sacv_bn_apply(const float* y, const float* mean, const float* invstd_or_var,
 int sacv_bn_train_bwd(const float* dz, const float* zmask, const float* y, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, float* dy, float* g_out, float* dgamma, float* dbeta,
                       int R, int C, int accumulate, float* workspace, void* stream);
+/* The same with its first stage (the per-channel sums of g and g * xhat over the rows) done elsewhere -- by the
+ * epilogue of the data gradient that PRODUCES dz (sacv_conv2d_gemm_bnbwd): partial = [nparts][2][C]. */
+int sacv_bn_train_bwd_partial(const float* dz, const float* zmask, const float* y, const float* mean,
+                              const float* invstd, const float* gamma, const float* beta, float* dy, float* g_out,
+                              float* dgamma, float* dbeta, int R, int C, int accumulate, const float* partial, int nparts,
+                              float* workspace, void* stream);
 
 /* ---- GroupNorm(32, C) + ReLU of the FCOS head towers (detection/models/head.py:110,125) --------------- */
 long long sacv_gn_workspace_floats(int N, int HW, int C);

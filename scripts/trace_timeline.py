@@ -7,6 +7,7 @@ for r in rows:
 rows.sort(key=lambda r: r['s'])
 def short(n):
     n = re.sub(r'^void ', '', n)
+    n = n.replace('(anonymous namespace)::', '')
     n = re.sub(r'\(.*', '', n)
     return n[:60]
 ad = [i for i, r in enumerate(rows) if 'adamw' in r['Kernel_Name']]

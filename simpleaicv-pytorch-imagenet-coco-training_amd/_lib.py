@@ -19,6 +19,7 @@ SIGNATURES = {
     'sacv_launch_share': (I, [I, I, I, I, I]),
     'sacv_conv2d_gemm': (I, [I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P]),
     'sacv_conv2d_gemm_stats_rows': (I, [I, P, P, P]),
+    'sacv_conv2d_gemm_bnbwd': (I, [P, P, P, I, I, I, I, I, P, P, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P]),
     'sacv_bn_finalize_stats': (I, [P, I, I, I, F, F, P, P, P, P, P, P]),
     'sacv_colsum_finalize': (I, [P, I, I, I, P, I, P]),
     'sacv_colsum_finalize_multi': (I, [I, P, P, P, P, P, P, P]),
@@ -50,6 +51,7 @@ SIGNATURES = {
     'sacv_bn_train_stats': (I, [P, I, I, F, F, P, P, P, P, P, P, P]),
     'sacv_bn_apply': (I, [P, P, P, P, P, P, P, LL, I, I, I, F, P]),
     'sacv_bn_train_bwd': (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
+    'sacv_bn_train_bwd_partial': (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, I, P, P]),
     'sacv_gn_workspace_floats': (LL, [I, I, I]),
     'sacv_groupnorm_fwd': (I, [P, P, P, P, P, I, I, I, I, F, I, P, P]),
     'sacv_groupnorm_bwd': (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P, P]),

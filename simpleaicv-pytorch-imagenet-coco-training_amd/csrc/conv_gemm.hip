@@ -36,6 +36,8 @@
 #define CF_MASK 16
 #define CF_STATS 32
 #define CF_AFFINE 128  // bias is [2][N]: row 0 additive, row 1 multiplicative: v = acc * bias[1][n] + bias[0][n]
+#define CF_BNBWD 256   // internal (sacv_conv2d_gemm_bnbwd): the stored value is the upstream gradient dz of a BatchNorm
+//                        (+ ReLU) layer -- stats rows = [sum g, sum g * xhat], g = dz * relu mask, xhat from that layer's y
 #define CF_PUBLIC_MASK (63 | CF_AFFINE)  // the flags the C ABI accepts (64 is the bf16 entry point's SACV_CFH_OUT_F32)
 
 // Ablation switches (skip gathers / LDS stores / the K-loop barrier / fragment addressing) exist only in a
@@ -88,7 +90,14 @@ struct ConvArgs {
   //            Every workgroup gets the same number of K-iterations, so all CUs finish together.
   int grid, base, rem_tiles, sk_blocks;
   float* partial;  // [slots][BM][BN] row-major K-slice tiles
-  float* stats;    // [total_mtiles][2][N] column sum / sum of squares (CF_STATS)
+  float* stats;    // [total_mtiles][2][N] column sum / sum of squares (CF_STATS); [sum g, sum g*xhat] (CF_BNBWD)
+  // CF_BNBWD: the BatchNorm layer whose upstream gradient this launch stores (single problem, dst rows = its rows)
+  const float* bn_y;       // its pre-normalisation input [M][N]
+  const float* bn_z;       // ReLU mask source (the stored block output) or null: the mask is recomputed from y
+  const float* bn_mean;    // [N]
+  const float* bn_invstd;  // [N]
+  const float* bn_gamma;   // [N] (mask recomputation)
+  const float* bn_beta;    // [N] (mask recomputation; null with a layer that has no ReLU: no mask)
 };
 
 struct TileCoord {
@@ -135,6 +144,16 @@ __device__ __forceinline__ void vec_epilogue(const ConvArgs& a, const TileCoord&
   // an eval-mode BatchNorm folded into the convolution: per-channel scale (gamma / sqrt(var + eps)) and shift
   if ((flags & CF_AFFINE) && nok) sv = *reinterpret_cast<const f32x4*>(a.bias + N + n);
   f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+  // CF_BNBWD: per-channel constants of the BatchNorm layer this tile's values are the upstream gradient of
+  f32x4 bmu = {0.f, 0.f, 0.f, 0.f}, bis = bmu, bga = bmu, bbe = bmu;
+  if ((flags & CF_BNBWD) && nok) {
+    bmu = *reinterpret_cast<const f32x4*>(a.bn_mean + n);
+    bis = *reinterpret_cast<const f32x4*>(a.bn_invstd + n);
+    if (!a.bn_z && a.bn_beta) {
+      bga = *reinterpret_cast<const f32x4*>(a.bn_gamma + n);
+      bbe = *reinterpret_cast<const f32x4*>(a.bn_beta + n);
+    }
+  }
   const int hw = P.Hd * P.Wd;
 #pragma unroll 4
   for (int row = rr; row < BM; row += RS) {
@@ -167,10 +186,30 @@ __device__ __forceinline__ void vec_epilogue(const ConvArgs& a, const TileCoord&
       for (int e = 0; e < 4; ++e) v[e] = mk[e] > 0.f ? v[e] : 0.f;
     }
     *reinterpret_cast<f32x4*>(dst + o) = v;
-    ssum += v;
-    ssq += v * v;
+    if (flags & CF_BNBWD) {
+      // the first stage of that layer's BatchNorm backward (norm.hip: bn_bwd_partial_kernel) on values that are in
+      // registers anyway: g = dz * (z > 0) with z read (residual layers) or recomputed from y by the forward pass's
+      // own expression ((y - mean) * invstd) * gamma + beta (bit-identical: -ffp-contract=off); sums of g and g * xhat
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(a.bn_y + o);
+      f32x4 xh, g = v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xh[e] = (yv[e] - bmu[e]) * bis[e];
+      if (a.bn_z) {
+        const f32x4 zv = *reinterpret_cast<const f32x4*>(a.bn_z + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = zv[e] > 0.f ? v[e] : 0.f;
+      } else if (a.bn_beta) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = (xh[e] * bga[e] + bbe[e]) > 0.f ? v[e] : 0.f;
+      }
+      ssum += g;
+      ssq += g * xh;
+    } else {
+      ssum += v;
+      ssq += v * v;
+    }
   }
-  if (flags & CF_STATS) {
+  if (flags & (CF_STATS | CF_BNBWD)) {
     __syncthreads();  // callers' row sources (LDS stage) are dead from here on
     *reinterpret_cast<f32x4*>(red + (size_t)rr * BN + c4 * 4) = ssum;
     *reinterpret_cast<f32x4*>(red + (size_t)(RS + rr) * BN + c4 * 4) = ssq;
@@ -1122,7 +1161,7 @@ static int launch_nt(ConvArgs& a, const NtPlan& plan, float* workspace, hipStrea
   hipLaunchKernelGGL((conv_nt_kernel<BM, BN, MODE, WN, OCC, SWZ>), dim3(launch_blocks), dim3(128 * WN), lds, st, a);
   SACV_CHECK_LAUNCH("conv_nt_kernel");
   if (a.sk_blocks > a.rem_tiles) {
-    if (a.flags & CF_STATS)
+    if (a.flags & (CF_STATS | CF_BNBWD))
       hipLaunchKernelGGL((conv_fixup_kernel<BM, BN>), dim3(a.rem_tiles), dim3(1024), 0, st, a);
     else
       hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, 256, 4>), dim3(a.rem_tiles * 4), dim3(256), 0, st, a);
@@ -1169,13 +1208,19 @@ int sacv_internal_wgrad_reduce(const float* part, float* dw, int chunks, int Cou
 
 SACV_API_BEGIN
 
+// The BatchNorm layer a data-gradient launch computes the backward partial sums of (CF_BNBWD)
+struct BnFuse {
+  const float *y, *z, *mean, *invstd, *gamma, *beta;
+};
+
 // Grouped implicit-GEMM convolution (forward when mode==0, data-gradient when mode==1).
 // Every problem p: src[p] is NHWC [Nb[p]][Hs[p]][Ws[p]][Cs]; dst[p] is [M_p][N] with
 // M_p = Nb*Hd*Wd.  w is the packed panel [N][KH*KW*Cs].
-int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, const float* const* mask,
-                     const int* Nb, const int* Hs, const int* Ws, const int* Hd, const int* Wd, const float* w,
-                     const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode, int flags,
-                     int remap_s, int Hr, int Wr, const int* ext, float* workspace, float* stats, void* stream) {
+static int conv2d_gemm_impl(int nprob, const float* const* src, float* const* dst, const float* const* mask,
+                            const int* Nb, const int* Hs, const int* Ws, const int* Hd, const int* Wd, const float* w,
+                            const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode, int flags,
+                            int remap_s, int Hr, int Wr, const int* ext, float* workspace, float* stats, void* stream,
+                            const BnFuse* bn) {
   SACV_CHECK_ARG(nprob >= 1 && nprob <= SACV_MAXP, "conv2d_gemm: nprob %d out of range", nprob);
   SACV_CHECK_ARG(Cs % 4 == 0 && Cs > 0, "conv2d_gemm: Cs=%d must be a positive multiple of 4", Cs);
   SACV_CHECK_ARG(N > 0 && KH > 0 && KW > 0, "conv2d_gemm: bad N/KH/KW");
@@ -1253,6 +1298,20 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
   a.mode = mode;
   a.flags = flags;
   a.stats = stats;
+  a.bn_y = a.bn_z = a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr;
+  if (bn) {
+    SACV_CHECK_ARG(nprob == 1 && remap_s == 0 && !(flags & CF_STATS) && stats,
+                   "conv2d_gemm_bnbwd: one problem, no row remap, no SACV_CF_STATS, a stats buffer");
+    SACV_CHECK_ARG(bn->y && bn->mean && bn->invstd && (bn->z || !bn->beta || bn->gamma),
+                   "conv2d_gemm_bnbwd: y / mean / invstd (and gamma with beta) are required");
+    a.flags |= CF_BNBWD;
+    a.bn_y = bn->y;
+    a.bn_z = bn->z;
+    a.bn_mean = bn->mean;
+    a.bn_invstd = bn->invstd;
+    a.bn_gamma = bn->gamma;
+    a.bn_beta = bn->beta;
+  }
   hipStream_t st = (hipStream_t)stream;
   const int grid = nt_slots(128);
   const int KT = KH * KW * ((Cs + 31) / 32);
@@ -1271,6 +1330,33 @@ int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, cons
                      : launch_nt<128, 64, 1, 2, 3, true>(a, p64, workspace, st);
   return mode == 0 ? launch_nt<128, 128, 0, SACV_NT_WN>(a, p128, workspace, st)
                    : launch_nt<128, 128, 1, SACV_NT_WN>(a, p128, workspace, st);
+}
+
+int sacv_conv2d_gemm(int nprob, const float* const* src, float* const* dst, const float* const* mask,
+                     const int* Nb, const int* Hs, const int* Ws, const int* Hd, const int* Wd, const float* w,
+                     const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode, int flags,
+                     int remap_s, int Hr, int Wr, const int* ext, float* workspace, float* stats, void* stream) {
+  return conv2d_gemm_impl(nprob, src, dst, mask, Nb, Hs, Ws, Hd, Wd, w, bias, Cs, N, KH, KW, stride, pad, mode, flags,
+                          remap_s, Hr, Wr, ext, workspace, stats, stream, nullptr);
+}
+
+// One problem of sacv_conv2d_gemm (usually a data gradient, mode 1) whose output dz [M][N] is the upstream gradient of a
+// BatchNorm (+ ReLU) layer with pre-normalisation input bn_y [M][N]: the epilogue also emits that layer's backward
+// partial sums -- stats[m tile][0][n] = sum g, [1][n] = sum g * xhat, g = dz * (z > 0), xhat = (y - mean) * invstd --
+// i.e. the first stage of sacv_bn_train_bwd, so that sacv_bn_train_bwd_partial can go straight to the second.  The ReLU
+// mask comes from bn_z (the layer's stored output) or, with bn_z NULL, is recomputed from y with bn_gamma / bn_beta
+// (bn_beta NULL: the layer has no ReLU).  stats: sacv_conv2d_gemm_stats_rows rows.
+int sacv_conv2d_gemm_bnbwd(const float* src, float* dst, const float* mask, int Nb, int Hs, int Ws, int Hd, int Wd,
+                           const float* w, const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode,
+                           int flags, float* workspace, float* stats, const float* bn_y, const float* bn_z,
+                           const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                           void* stream) {
+  const BnFuse bn = {bn_y, bn_z, bn_mean, bn_invstd, bn_gamma, bn_beta};
+  const float* srcs[1] = {src};
+  float* dsts[1] = {dst};
+  const float* masks[1] = {mask};
+  return conv2d_gemm_impl(1, srcs, dsts, mask ? masks : nullptr, &Nb, &Hs, &Ws, &Hd, &Wd, w, bias, Cs, N, KH, KW, stride,
+                          pad, mode, flags, 0, 0, 0, nullptr, workspace, stats, stream, &bn);
 }
 
 // Rows of the CF_STATS buffer ([rows][2][N] floats): the number of 128-row M tiles over all problems.

@@ -400,10 +400,13 @@ static int bn_apply_impl(const T* y, const float* mean, const float* invstd_or_v
 
 // dz: upstream grad; y: conv output (pre-BN).  ReLU mask: zmask = the block output (or null); with zmask null and
 // beta non-null the mask is recomputed from y (layers whose output is relu(bn(y)), no residual).
+// `partial` non-null: the first stage ran elsewhere (the producing data gradient's epilogue, sacv_conv2d_gemm_bnbwd):
+// [nparts][2][C] rows of (sum g, sum g * xhat) covering the R rows
 template <typename T>
 static int bn_train_bwd_impl(const T* dz, const T* zmask, const T* y, const float* mean, const float* invstd,
                              const float* gamma, const float* beta, T* dy, T* g_out, float* dgamma, float* dbeta,
-                             int R, int C, int accumulate, float* workspace, void* stream) {
+                             int R, int C, int accumulate, float* workspace, void* stream,
+                             const float* partial = nullptr, int nparts = 0) {
   constexpr int V = VecIO<T>::N;
   SACV_CHECK_ARG(dz && y && mean && invstd && gamma && dy && dgamma && dbeta && workspace, "bn_train_bwd: null");
   SACV_CHECK_ARG(C % V == 0 && C > 0 && R > 0, "bn_train_bwd: bad shape (C=%d must be a multiple of %d)", C, V);
@@ -412,12 +415,18 @@ static int bn_train_bwd_impl(const T* dz, const T* zmask, const T* y, const floa
   int nb = pick_blocks(R, &rpb);
   hipStream_t st = (hipStream_t)stream;
   float* coef = workspace + (size_t)nb * 2 * C;
-  hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(nb), dim3(BN_THREADS), lds_for(C, V), st, dz, zmask, y, mean,
-                     invstd, gamma, zmask ? nullptr : beta, workspace, R, C, rpb);
-  SACV_CHECK_LAUNCH("bn_bwd_partial");
+  if (partial) {
+    SACV_CHECK_ARG(nparts > 0, "bn_train_bwd_partial: nparts");
+    nb = nparts;
+  } else {
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<T>, dim3(nb), dim3(BN_THREADS), lds_for(C, V), st, dz, zmask, y, mean,
+                       invstd, gamma, zmask ? nullptr : beta, workspace, R, C, rpb);
+    SACV_CHECK_LAUNCH("bn_bwd_partial");
+    partial = workspace;
+  }
   const int FCH = fin_channels_host(nb, C);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + FCH - 1) / FCH), dim3(FIN_THREADS), 0, st,
-                     workspace, nb, R, C, dgamma,
+                     partial, nb, R, C, dgamma,
                      dbeta, coef, accumulate);
   SACV_CHECK_LAUNCH("bn_bwd_finalize");
   size_t nv = (size_t)R * C / V;
@@ -511,6 +520,16 @@ int sacv_bn_train_bwd(const float* dz, const float* zmask, const float* y, const
                       int R, int C, int accumulate, float* workspace, void* stream) {
   return bn_train_bwd_impl<float>(dz, zmask, y, mean, invstd, gamma, beta, dy, g_out, dgamma, dbeta, R, C, accumulate,
                                   workspace, stream);
+}
+// Second and third stage of sacv_bn_train_bwd from partial sums computed elsewhere: partial = [nparts][2][C] rows of
+// (sum g, sum g * xhat) over the R rows, as written by sacv_conv2d_gemm_bnbwd (nparts = its stats rows).
+int sacv_bn_train_bwd_partial(const float* dz, const float* zmask, const float* y, const float* mean,
+                              const float* invstd, const float* gamma, const float* beta, float* dy, float* g_out,
+                              float* dgamma, float* dbeta, int R, int C, int accumulate, const float* partial, int nparts,
+                              float* workspace, void* stream) {
+  SACV_CHECK_ARG(partial, "bn_train_bwd_partial: null partial sums");
+  return bn_train_bwd_impl<float>(dz, zmask, y, mean, invstd, gamma, beta, dy, g_out, dgamma, dbeta, R, C, accumulate,
+                                  workspace, stream, partial, nparts);
 }
 int sacv_bn_train_bwd_bf16(const void* dz, const void* zmask, const void* y, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, void* dy, void* g_out, float* dgamma, float* dbeta,

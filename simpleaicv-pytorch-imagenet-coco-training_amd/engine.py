@@ -332,8 +332,17 @@ class DetectorEngine:
         c.k, c.stride, c.pad, c.relu, c.residual = k, stride, pad, relu, residual is not None
         return z, c
 
-    def _cba_bwd(self, c, dz, need_dx=True, want_g=False, dx_out=None, dx_accum=False):
-        """Backward of one layer.  Returns (dx, g) where g is the ReLU-masked upstream gradient."""
+    # BatchNorm backward, first stage, in the epilogue of the data gradient that PRODUCES the layer's upstream gradient
+    # (ops.conv_gemm_bnbwd): the per-channel sums of g and g * xhat come from values that are in registers there, the
+    # bn_bwd_partial pass (one read of dz and y, one launch; 0.9 ms per RetinaNet step in stream order, 1.7 ms beside the
+    # weight gradients) disappears for 41 of the trunk's 53 layers.  False: every layer runs its own first stage (A/B,
+    # tests).
+    fuse_bn_bwd = True
+
+    def _cba_bwd(self, c, dz, need_dx=True, want_g=False, dx_out=None, dx_accum=False, partial=None, fuse=None):
+        """Backward of one layer.  Returns (dx, g, st): g is the ReLU-masked upstream gradient; st -- when `fuse` (the
+        saved state of the layer whose BatchNorm receives dx as ITS upstream gradient) could be served -- that layer's
+        first-stage sums, to be handed to its own _cba_bwd as `partial`."""
         p, g = self.p, self.g
         bn = c.prefix + '.layer.1.'
         wname = c.prefix + '.layer.0.weight'
@@ -341,7 +350,7 @@ class DetectorEngine:
         recompute = c.relu and not c.residual
         dy, gm = ops.bn_train_bwd(dz, c.z if (c.relu and not recompute) else None, c.y, c.mean, c.invstd,
                                   p[bn + 'weight'], g[bn + 'weight'], g[bn + 'bias'], want_g=want_g,
-                                  relu_beta=p[bn + 'bias'] if recompute else None)
+                                  relu_beta=p[bn + 'bias'] if recompute else None, partial=partial)
         w = p[wname]
         cin = w.shape[1]
         v = getattr(c, 'wino_v', None)
@@ -352,12 +361,22 @@ class DetectorEngine:
                 dx = ops.conv3x3_wino([[dy]], [self._wino_u(w, dgrad=True)], [cin],
                                       flags=[CF_ACCUM if dx_accum else 0],
                                       outs_list=[[dx_out]] if dx_out is not None else None, mode=1)[0][0]
-            return dx, gm
+            return dx, gm, None
         self._wgrad([dy], [c.x], g[wname], cin, c.k, c.k, c.stride, c.pad)
-        dx = None
+        dx, st = None, None
         if need_dx:
-            dx = self._dgrad(dy, w, c.x.shape, c.k, c.stride, c.pad, out=dx_out, accumulate=dx_accum)
-        return dx, gm
+            if (fuse is not None and self.fuse_bn_bwd and not self.amp and c.stride == 1 and fuse.relu
+                    and tuple(fuse.y.shape) == tuple(c.x.shape)):
+                f_rc = not fuse.residual  # as above: mask recomputed from y unless a residual entered the ReLU
+                fbn = fuse.prefix + '.layer.1.'
+                dx, st = ops.conv_gemm_bnbwd(dy, self._dgrad_panel(w), cin, c.k, c.k, c.pad, c.x.shape[1:3], fuse.y,
+                                             fuse.mean, fuse.invstd, bn_gamma=p[fbn + 'weight'] if f_rc else None,
+                                             bn_beta=p[fbn + 'bias'] if f_rc else None,
+                                             bn_z=None if f_rc else fuse.z, out=dx_out,
+                                             flags=CF_ACCUM if dx_accum else 0)
+            else:
+                dx = self._dgrad(dy, w, c.x.shape, c.k, c.stride, c.pad, out=dx_out, accumulate=dx_accum)
+        return dx, gm, st
 
     def _dgrad(self, dy, w, x_shape, k, stride, pad, out=None, accumulate=False, mask=None):
         cin = w.shape[1]
@@ -502,14 +521,14 @@ class DetectorEngine:
 
     def _basicblock_bwd(self, saved, dout, accum_target):
         c1, c2, cd = saved
-        dz1, gshared = self._cba_bwd(c2, dout, want_g=True)
+        dz1, gshared, _ = self._cba_bwd(c2, dout, want_g=True)
         if cd is None:
-            dx, _ = self._cba_bwd(c1, dz1, dx_out=gshared, dx_accum=True)
+            dx, _, _ = self._cba_bwd(c1, dz1, dx_out=gshared, dx_accum=True)
             return dx
         if accum_target is not None:
-            dx, _ = self._cba_bwd(c1, dz1, dx_out=accum_target, dx_accum=True)
+            dx, _, _ = self._cba_bwd(c1, dz1, dx_out=accum_target, dx_accum=True)
         else:
-            dx, _ = self._cba_bwd(c1, dz1)
+            dx, _, _ = self._cba_bwd(c1, dz1)
         self._cba_bwd(cd, gshared, dx_out=dx, dx_accum=True)
         return dx
 
@@ -1061,14 +1080,21 @@ class DetectorEngine:
         """Backward of the trunk, last block first; dc4 / dc3 are the FPN lateral gradients that join the
         data gradient at the inputs of layer4 / layer3 (None for the classifier)."""
         ctx, bp = self.ctx, self.bp
-        bwd = self._bottleneck_bwd if self.block == 'Bottleneck' else self._basicblock_bwd
-        for saved, li, bi in reversed(ctx['blocks']):
+        blocks = ctx['blocks']
+        st = None
+        for idx in reversed(range(len(blocks))):
+            saved, li, bi = blocks[idx]
             accum_target = None
             if bi == 0 and li == 4:
                 accum_target = dc4
             elif bi == 0 and li == 3:
                 accum_target = dc3
-            dout = bwd(saved, dout, accum_target)
+            if self.block == 'Bottleneck':
+                # an identity block's dx is the previous block's upstream gradient, complete in conv1's data gradient
+                prev_c3 = blocks[idx - 1][0][2] if (bi > 0 and saved[3] is None) else None
+                dout, st = self._bottleneck_bwd(saved, dout, accum_target, partial=st, fuse_prev=prev_c3)
+            else:
+                dout = self._basicblock_bwd(saved, dout, accum_target)
             if on_stage and bi == 0 and li in (3, 4):
                 self._stage(on_stage, 'neck' if li == 4 else 'mid')  # fpn + layer4 / layer3 gradients are final
         # max pool + stem
@@ -1081,27 +1107,30 @@ class DetectorEngine:
         dy, _ = ops.bn_train_bwd(dpool, None, st.y, st.mean, st.invstd, self.p[bn + 'weight'], self.g[bn + 'weight'],
                                  self.g[bn + 'bias'], relu_beta=self.p[bn + 'bias'])
         if st.x is None:  # fused stem forward: no im2col matrix was kept -- the weight gradient reads the image too
-            img = ctx['stem_images']
-            self._on_side(lambda: ops.stem_conv_wgrad(img, dy, self.g[bp + 'conv1.layer.0.weight']), [dy, img])
+            # On the LAUNCH stream: it is the last kernel of the backward pass (nothing left to run beside it) and the
+            # optimizer waits for it -- on the side stream the cross-queue hand-over that the final join then has to wait
+            # for cost 80-90 us between its last kernel and the optimizer's first (kernel trace, round 4).
+            ops.stem_conv_wgrad(ctx['stem_images'], dy, self.g[bp + 'conv1.layer.0.weight'])
         else:
             self._wgrad([dy], [st.x], self.g[bp + 'conv1.layer.0.weight'], 3, 1, 1, 1, 0,
                         cin_pad=st.x.shape[-1], dw_taps=st.k * st.k)
 
-    def _bottleneck_bwd(self, saved, dout, accum_target):
+    def _bottleneck_bwd(self, saved, dout, accum_target, partial=None, fuse_prev=None):
+        """partial: first-stage sums of this block's bn3 (from the data gradient that produced dout); fuse_prev: conv3
+        of the PREVIOUS block, whose bn3 receives this block's dx -- returns (dx, its first-stage sums or None)."""
         c1, c2, c3, cd = saved
         # out = relu(bn3(conv3(z2)) + idt): g is the masked gradient shared by both branches
-        dz2, gshared = self._cba_bwd(c3, dout, want_g=True)
-        dz1, _ = self._cba_bwd(c2, dz2)
+        dz2, gshared, st2 = self._cba_bwd(c3, dout, want_g=True, partial=partial, fuse=c2)
+        dz1, _, st1 = self._cba_bwd(c2, dz2, partial=st2, fuse=c1)
         if cd is None:
-            # identity shortcut: dx = g + dgrad(conv1)
-            dx, _ = self._cba_bwd(c1, dz1, dx_out=gshared, dx_accum=True)
-            return dx
+            # identity shortcut: dx = g + dgrad(conv1) -- complete in that launch's epilogue
+            return self._cba_bwd(c1, dz1, partial=st1, dx_out=gshared, dx_accum=True, fuse=fuse_prev)[::2]
         if accum_target is not None:
-            dx, _ = self._cba_bwd(c1, dz1, dx_out=accum_target, dx_accum=True)
+            dx, _, _ = self._cba_bwd(c1, dz1, partial=st1, dx_out=accum_target, dx_accum=True)
         else:
-            dx, _ = self._cba_bwd(c1, dz1)
+            dx, _, _ = self._cba_bwd(c1, dz1, partial=st1)
         self._cba_bwd(cd, gshared, dx_out=dx, dx_accum=True)
-        return dx
+        return dx, None
 
     def _fpn_bwd(self, dfeat):
         f = self.ctx['fpn']

@@ -210,6 +210,41 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
     return outs
 
 
+def conv_gemm_bnbwd(src, w_packed, n_out, kh, kw, pad, out_hw, bn_y, bn_mean, bn_invstd, bn_gamma=None, bn_beta=None,
+                    bn_z=None, out=None, flags=0, mask=None, mode=1, stride=1):
+    """One stride-1 data gradient (mode 1; out_hw = input H, W) whose output dz is the upstream gradient of the
+    BatchNorm (+ ReLU) layer with input bn_y: returns (dz, partial) with partial [m tiles, 2, n_out] = that layer's
+    backward first-stage sums (sum g, sum g * xhat) for bn_train_bwd(partial=...).  Mask from bn_z (stored output) or
+    recomputed from y with bn_gamma / bn_beta."""
+    _chk(src, 'conv src')
+    cs = src.shape[3]
+    nb = src.shape[0]
+    if out is None:
+        out = torch.empty((nb, out_hw[0], out_hw[1], n_out), device=src.device, dtype=torch.float32)
+    if tuple(bn_y.shape) != tuple(out.shape):
+        raise ValueError(f'conv_gemm_bnbwd: bn_y is {tuple(bn_y.shape)}, the output {tuple(out.shape)}')
+    rows = -(-(nb * out_hw[0] * out_hw[1]) // 128)
+    st = torch.empty((rows, 2, n_out), device=src.device, dtype=torch.float32)
+    if mask is not None:
+        flags |= CF_MASK
+
+    def launch():
+        check(lib.sacv_conv2d_gemm_bnbwd(
+            src.data_ptr(), out.data_ptr(), _ptr(mask), nb, src.shape[1], src.shape[2], out_hw[0], out_hw[1],
+            _ptr(w_packed), None, cs, n_out, kh, kw, stride, pad, mode, flags,
+            workspace(_gemm_ws_bytes(), src.device, 'conv_gemm').data_ptr(), st.data_ptr(), _ptr(_chk(bn_y, 'bn_y')),
+            _ptr(bn_z), _ptr(bn_mean), _ptr(bn_invstd), _ptr(bn_gamma), _ptr(bn_beta), _stream()), 'conv2d_gemm_bnbwd')
+
+    if TIMER is not None:
+        pix = nb * (src.shape[1] * src.shape[2] if mode == 1 else out_hw[0] * out_hw[1])
+        TIMER.time(('conv_nt_128x128' if n_out > 64 else 'conv_nt_128x64') + f'|m{mode} k{kh} s{stride} cs{cs} n{n_out} np1 pix{pix} f{flags | 256}',
+                   2.0 * pix * n_out * kh * kw * cs, launch,
+                   nbytes=4.0 * (src.numel() + 2 * out.numel() + w_packed.numel()))
+    else:
+        launch()
+    return out, st
+
+
 # ------------------------------------------------------------------------------------------ Winograd F(2x2,3x3)
 WINO_MAXL = 5
 
@@ -636,12 +671,19 @@ def bn_apply(y, mean, invstd_or_var, gamma, beta, residual=None, relu=False, sta
 
 
 def bn_train_bwd(dz, zmask, y, mean, invstd, gamma, dgamma, dbeta, want_g=False, accumulate=False, dy_out=None,
-                 relu_beta=None):
-    """relu_beta (the BN bias) with zmask=None: the ReLU mask is recomputed from y instead of read from z."""
+                 relu_beta=None, partial=None):
+    """relu_beta (the BN bias) with zmask=None: the ReLU mask is recomputed from y instead of read from z.
+    partial: [rows, 2, C] first-stage sums from the epilogue of the data gradient that produced dz (conv_gemm_bnbwd)."""
     c = y.shape[-1]
     r = y.numel() // c
     dy = dy_out if dy_out is not None else torch.empty_like(y)
     g = torch.empty_like(y) if want_g else None
+    if partial is not None:
+        check(lib.sacv_bn_train_bwd_partial(_ptr(dz), _ptr(zmask), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                            _ptr(relu_beta), _ptr(dy), _ptr(g), _ptr(dgamma), _ptr(dbeta), r, c,
+                                            int(accumulate), _ptr(_chk(partial, 'bn partial sums')), partial.shape[0],
+                                            _bn_ws(r, c, y.device).data_ptr(), _stream()), 'bn_train_bwd_partial')
+        return dy, g
     if y.dtype == BF16:
         check(lib.sacv_bn_train_bwd_bf16(_ptr(dz), _ptr(zmask), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma),
                                          _ptr(relu_beta), _ptr(dy), _ptr(g), _ptr(dgamma), _ptr(dbeta), r, c,

@@ -79,10 +79,57 @@ def test_bottleneck_fwd_bwd(cin, planes, stride, h, w):
     assert rel_l2(nchw(out), out_r.detach()) <= 1e-5
     base = rnd(3, *x.shape)
     for accum in (None, nhwc(base)) if cd is not None else (None,):
-        dx = eng._bottleneck_bwd((c1, c2, c3, cd), nhwc(dout), accum)
+        dx, _ = eng._bottleneck_bwd((c1, c2, c3, cd), nhwc(dout), accum)
         eng._side_join()  # weight gradients run on a side stream; engine.backward joins it, a bare block call does not
         ref = xr.grad if accum is None else xr.grad + base
         assert rel_l2(nchw(dx), ref) <= 1e-4, (accum is not None)
+    for k, pr in params.items():
+        assert rel_l2(g[k].cpu(), pr.grad) <= 1e-4, k
+
+
+@pytest.mark.parametrize('fuse', [True, False])
+def test_two_bottlenecks_bn_backward_partials_from_the_data_gradient(fuse):
+    """A stage's first block (shortcut conv) followed by an identity block: with engine.fuse_bn_bwd the first-stage sums of
+    bn2 / bn1 come from the epilogues of conv3's / conv2's data gradients (mask recomputed from y) and those of the FIRST
+    block's bn3 from the identity block's conv1 data gradient (accumulating epilogue, mask from the stored z) -- against
+    autograd through the oracle's functional blocks, and the fused run against the unfused one."""
+    sd = {}
+    cin, planes, h, w = 64, 64, 23, 37
+    for bi, ci in ((0, cin), (1, planes * 4)):
+        pre = f'backbone.layer1.{bi}'
+        for name, a, b, k in (('conv1', ci, planes, 1), ('conv2', planes, planes, 3), ('conv3', planes, planes * 4, 1)):
+            sd[f'{pre}.{name}.layer.0.weight'] = rnd(zlib.crc32((pre + name).encode()) % 1000, b, a, k, k,
+                                                     std=(2.0 / (a * k * k))**0.5)
+            bn_entries(sd, f'{pre}.{name}', b, 7 + len(name) + 10 * bi)
+    sd['backbone.layer1.0.downsample_conv.layer.0.weight'] = rnd(5, planes * 4, cin, 1, 1, std=(2.0 / cin)**0.5)
+    bn_entries(sd, 'backbone.layer1.0.downsample_conv', planes * 4, 11)
+    x = rnd(1, 2, cin, h, w)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and 'running' not in k}
+    state = {k: v.clone() for k, v in sd.items()}
+    state.update(params)
+    xr = x.clone().requires_grad_(True)
+    cur = xr
+    for bi in (0, 1):
+        pre = f'backbone.layer1.{bi}'
+        y = omodel._cba(state, pre + '.conv1', cur, 1, 0, True, True)
+        y = omodel._cba(state, pre + '.conv2', y, 1, 1, True, True)
+        y = omodel._cba(state, pre + '.conv3', y, 1, 0, False, True)
+        idt = omodel._cba(state, pre + '.downsample_conv', cur, 1, 0, False, True) if bi == 0 else cur
+        cur = F.relu(y + idt)
+    dout = rnd(2, *cur.shape)
+    cur.backward(dout)
+
+    eng, p, g = make_engine(sd)
+    eng.fuse_bn_bwd = fuse
+    z0, s0 = eng._bottleneck_fwd(nhwc(x), 'backbone.layer1.0', 1, True, True)
+    z1, s1 = eng._bottleneck_fwd(z0, 'backbone.layer1.1', 1, True, True)
+    assert rel_l2(nchw(z1), cur.detach()) <= 1e-5
+    d0, st = eng._bottleneck_bwd(s1, nhwc(dout), None, fuse_prev=s0[2])
+    assert (st is not None) == fuse
+    dx, st0 = eng._bottleneck_bwd(s0, d0, None, partial=st)
+    assert st0 is None
+    eng._side_join()
+    assert rel_l2(nchw(dx), xr.grad) <= 1e-4
     for k, pr in params.items():
         assert rel_l2(g[k].cpu(), pr.grad) <= 1e-4, k
 

@@ -393,6 +393,55 @@ def test_batchnorm_train_fwd_bwd(ops, shape, relu, res):
         assert torch.equal(dy2, dyd) and torch.equal(g2, g) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
+@pytest.mark.parametrize('n,cin,h,w,cout,k,zmask', [(2, 256, 50, 67, 64, 1, False), (2, 64, 37, 41, 256, 1, True),
+                                                     (2, 128, 26, 31, 128, 3, False), (2, 512, 13, 21, 128, 1, False)])
+def test_bn_backward_first_stage_in_the_data_gradient_epilogue(ops, n, cin, h, w, cout, k, zmask):
+    """sacv_conv2d_gemm_bnbwd + sacv_bn_train_bwd_partial against the unfused pair (data gradient, then the complete
+    sacv_bn_train_bwd): dz bit-identical (same kernel, one more epilogue option), dgamma / dbeta / dy to fp32 summation
+    noise (the first-stage sums are taken per 128-row tile instead of per row chunk; both are finished in fp64).  `cout`
+    is the conv's output = the data gradient's source; its result dz [.., cin] is the upstream gradient of a BatchNorm
+    layer over cin channels.  zmask: that layer's ReLU follows a residual add (mask from z), the data gradient accumulates
+    into an existing tensor (the shortcut gradient)."""
+    p = k // 2
+    wt = rnd(2, cout, cin, k, k, std=(1.0 / (cin * k * k))**0.5)
+    wd = ops.pack_weight(wt.cuda(), ops.PACK_DGRAD)
+    dy = nhwc(rnd(3, n, cout, h, w))
+    y = nhwc(rnd(4, n, cin, h, w))              # the BatchNorm layer's input (its conv's output)
+    gamma = (1.0 + 0.2 * rnd(5, cin)).cuda()
+    beta = (0.2 * rnd(6, cin)).cuda()
+    mean, invstd = ops.bn_train_stats(y, 1e-5, 0.1, None, None, None)
+    res = nhwc(rnd(7, n, cin, h, w)) if zmask else None
+    z = ops.bn_apply(y, mean, invstd, gamma, beta, res, True)
+    base = nhwc(rnd(8, n, cin, h, w)) if zmask else None
+    flags = ops.CF_ACCUM if zmask else 0
+
+    def grads():
+        return torch.zeros(cin, device='cuda'), torch.zeros(cin, device='cuda')
+    # unfused
+    out0 = base.clone() if zmask else None
+    dz0 = ops.conv_gemm([dy], wd, cin, k, k, 1, p, 1, [(h, w)], flags=flags, outs=[out0] if zmask else None)[0]
+    dg0, db0 = grads()
+    dx0, g0 = ops.bn_train_bwd(dz0, z if zmask else None, y, mean, invstd, gamma, dg0, db0, want_g=True,
+                               relu_beta=None if zmask else beta)
+    # fused
+    out1 = base.clone() if zmask else None
+    dz1, st = ops.conv_gemm_bnbwd(dy, wd, cin, k, k, p, (h, w), y, mean, invstd, bn_gamma=None if zmask else gamma,
+                                  bn_beta=None if zmask else beta, bn_z=z if zmask else None, out=out1, flags=flags)
+    assert torch.equal(dz1, dz0)
+    dg1, db1 = grads()
+    dx1, g1 = ops.bn_train_bwd(dz1, z if zmask else None, y, mean, invstd, gamma, dg1, db1, want_g=True,
+                               relu_beta=None if zmask else beta, partial=st)
+    assert torch.equal(g1, g0)  # the masked upstream gradient comes from the apply pass in both
+    # first-stage sums against fp64
+    gm = g0.reshape(-1, cin).double()
+    xh = ((y.reshape(-1, cin).double() - mean.double()) * invstd.double())
+    assert torch.allclose(st[:, 0].double().sum(0), gm.sum(0), rtol=1e-5, atol=1e-4 * float(gm.abs().sum(0).max()))
+    assert torch.allclose(st[:, 1].double().sum(0), (gm * xh).sum(0), rtol=1e-5, atol=1e-4 * float(gm.abs().sum(0).max()))
+    for a, b in ((dg1, dg0), (db1, db0)):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6
+    assert float((dx1 - dx0).abs().max()) <= 1e-5 * float(dx0.abs().max())
+
+
 def test_batchnorm_eval(ops):
     y = rnd(1, 2, 64, 9, 11)
     gamma, beta, rm, rv = rnd(2, 64) + 1, rnd(3, 64), rnd(4, 64), rnd(5, 64).abs() + 0.5

@@ -469,6 +469,10 @@ def main():
                          'padded square S2 (SURVEY.md 8d)')
     ap.add_argument('--class-table', default='',
                     help='write the per-conv-class roofline table (MFMA and HBM fractions) to this JSON file')
+    ap.add_argument('--emulate-rccl', default='', metavar='WORKGROUPS[:LDS_BYTES[:GBPS]]',
+                    help='one-GPU measurement of the CU reserve (DESIGN.md 5.2): every exchange stage launches a stand-in '
+                         'for its all-reduce kernels -- that many resident workgroups for the duration of an 8-rank ring '
+                         'all-reduce at GBPS GB/s (default 200) -- on its own stream, chained like the real collective')
     ap.add_argument('--engine-set', action='append', default=[], metavar='NAME=VALUE',
                     help='A/B runs: set an attribute of the model\'s executor before the first step, e.g. '
                          '--engine-set fuse_bn_bwd=False (value: a Python literal)')
@@ -547,6 +551,12 @@ def main():
         crit = losses.__dict__['RetinaLoss'](box_loss_type='SmoothL1')
     trainer = DetectionTrainer(net, crit, lr=1e-4, weight_decay=1e-3, process_group=group,
                                transport=os.environ.get('SACV_TRANSPORT', 'torch'))
+    if args.emulate_rccl:
+        if world != 1:
+            raise SystemExit('--emulate-rccl stands in for RCCL on ONE GPU')
+        f = args.emulate_rccl.split(':')
+        trainer.exchanger.emulate = dict(workgroups=int(f[0]), lds_bytes=int(f[1]) if len(f) > 1 else 16384,
+                                         gbps=float(f[2]) if len(f) > 2 else 200.0)
     import ast
     for kv in args.engine_set:
         name, value = kv.split('=', 1)

@@ -356,6 +356,11 @@ int sacv_comm_destroy(void* comm);
 int sacv_allreduce_bucket(void* comm, float* buf, long long count, void* producer_stream);
 /* `consumer_stream` (the optimizer's) waits for every bucket enqueued so far; no host synchronisation */
 int sacv_comm_wait(void* comm, void* consumer_stream);
+/* Measurement aid: `workgroups` resident workgroups (256 threads, lds_bytes of LDS each) that stream `scratch` for `us`
+ * microseconds on `stream` -- a stand-in for RCCL's kernels when the CU reserve (sacv_launch_share) is sized on a box
+ * with one GPU. */
+int sacv_comm_emulate_load(int workgroups, int lds_bytes, float us, float* scratch, long long scratch_bytes,
+                           void* stream);
 /* DDP init_sync / broadcast_buffers: rank `root`'s buf overwrites every rank's, in order on `stream` */
 int sacv_comm_broadcast(void* comm, float* buf, long long count, int root, void* stream);
 

@@ -132,6 +132,7 @@ SIGNATURES = {
     'sacv_comm_destroy': (I, [P]),
     'sacv_allreduce_bucket': (I, [P, P, LL, P]),
     'sacv_comm_wait': (I, [P, P]),
+    'sacv_comm_emulate_load': (I, [I, I, F, P, LL, P]),
     'sacv_comm_broadcast': (I, [P, P, LL, I, P]),
 }
 

@@ -86,7 +86,42 @@ struct SacvComm {
     }                                                                           \
   } while (0)
 
+// Stand-in for RCCL's kernels on a box with ONE GPU (sacv_comm_emulate_load): `workgroups` 256-thread workgroups, each
+// holding `lds` bytes of LDS, that stay resident for `us` microseconds -- they stream a small buffer (a collective's
+// workgroups move bytes, they do not compute) and sleep in between.  Every wave reaches the exit condition: the clock.
+__global__ __launch_bounds__(256) void comm_load_kernel(float* scratch, int n4, long long ticks) {
+  extern __shared__ __attribute__((aligned(16))) float lds_hold[];
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();  // 100 MHz, constant rate
+  float acc = 0.f;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x == 0) lds_hold[0] = 0.f;
+  while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+    if (i >= n4) i -= n4;
+    if (i < 0 || i >= n4) i = 0;
+    const f32x4 v = *reinterpret_cast<const volatile f32x4*>(reinterpret_cast<f32x4*>(scratch) + i);
+    acc += v[0];
+    i += gridDim.x * 256;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (acc == 12345.678f) scratch[0] = acc + lds_hold[0];  // keeps the loads and the LDS allocation alive
+}
+
 SACV_API_BEGIN
+
+// Measurement aid: occupy `workgroups` workgroup slots (256 threads, `lds_bytes` of LDS each) for `us`
+// microseconds on `stream`, reading the `scratch_bytes` of `scratch` round and round -- what an all-reduce's kernels do to
+// the convolution kernels they run beside, on a box that has no second GPU to run RCCL against.
+int sacv_comm_emulate_load(int workgroups, int lds_bytes, float us, float* scratch, long long scratch_bytes,
+                           void* stream) {
+  SACV_CHECK_ARG(workgroups > 0 && workgroups <= 1024 && lds_bytes >= 16 && lds_bytes <= 64 * 1024 && us > 0.f &&
+                     us <= 20000.f && scratch && scratch_bytes >= 16,
+                 "comm_emulate_load: bad arguments");
+  const long long n4 = scratch_bytes / 16;
+  hipLaunchKernelGGL(comm_load_kernel, dim3(workgroups), dim3(256), lds_bytes, (hipStream_t)stream, scratch,
+                     (int)(n4 > (1 << 30) ? (1 << 30) : n4), (long long)(us * 100.0f));
+  SACV_CHECK_LAUNCH("comm_load_kernel");
+  return SACV_OK;
+}
 
 int sacv_comm_unique_id_bytes(void) { return (int)sizeof(ncclUniqueId); }
 

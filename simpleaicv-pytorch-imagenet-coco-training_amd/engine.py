@@ -73,12 +73,9 @@ class DetectorEngine:
         self.fold_bn = True
         self._fold = None
         self._wino_cache = {}
-        import os
         self._side, self._side_busy = None, False  # the weight gradients' stream (see _on_side)
-        if os.environ.get('SACV_WGRAD_STREAM', '1') != '0' and p and next(iter(p.values())).is_cuda:
-            self._side = torch.cuda.Stream()  # (the launch stream at high priority: 27.82 -> 27.62 ms; not adopted)
-            self._side_events = [torch.cuda.Event() for _ in range(64)]
         self._side_evi, self._side_keep = 0, []
+        self.side_stream = self.SIDE_STREAM and bool(p) and next(iter(p.values())).is_cuda
         # Output convolutions whose channel count is not a multiple of 4 (Objects365: 9 x 365 = 3285 class channels,
         # FCOS 365): the kernels move channels as 16-byte vectors, so the engine computes with zero-padded SHADOW copies
         # of the weight / bias (refreshed from the parameters at every forward pass) and shadow gradient buffers (their
@@ -89,8 +86,25 @@ class DetectorEngine:
             name = 'clsregcnt_head.cls_out' if fcos else 'cls_head.cls_out'
             if name + '.weight' in p and p[name + '.weight'].shape[0] % 4 != 0:
                 self._add_shadow(name)
-        # (one switch, SACV_WGRAD_STREAM=0, turns the second stream off: A/B runs and the profile session's serial trace)
+        # (one switch, engine.side_stream = False, turns the second stream off: A/B runs, the profile session's serial trace)
         self._bias_on_side = self._ds_on_side = True
+
+    SIDE_STREAM = True  # default of `side_stream` for executors built from now on (tests build stream-ordered twins)
+
+    @property
+    def side_stream(self):
+        """Weight gradients / shortcut branches on a second HIP stream (_on_side).  Assign False for a stream-ordered
+        executor (bit-identical results; `bench.py --engine-set side_stream=False`)."""
+        return self._side is not None
+
+    @side_stream.setter
+    def side_stream(self, on):
+        if not on:
+            self._side_join()
+            self._side = None
+        elif self._side is None:
+            self._side = torch.cuda.Stream()  # (the launch stream at high priority: 27.82 -> 27.62 ms; not adopted)
+            self._side_events = [torch.cuda.Event() for _ in range(64)]
 
     def _add_shadow(self, name):
         if not self._shadows:  # the dicts are shared with the model / arena: the engine edits copies of its own
@@ -1024,14 +1038,15 @@ class DetectorEngine:
     # gradients on the side stream): each plans for ITS share of a CU's workgroup slots (ops.launch_share) -- together the
     # two kernels fit a CU's LDS and registers, every workgroup of a persistent grid is resident from the start and the
     # stream-K ranges are cut for the workgroups that really run side by side.
-    BWD_SHARE = None  # (nt64, nt128, wino, wgrad) slots per CU during the backward pass; None: plan as if alone
+    # Measured (round 4, same session, 2 x 800x1333; `bench.py --engine-set BWD_SHARE=...`): planning as if alone 27.8 ms;
+    # (2,1,2,1) 29.9; (2,2,2,1) 30.0; (3,2,2,1) 29.7; (2,1,3,1) 28.9; (2,1,2,2) 28.5; (3,2,3,1) 28.8 -- every static partition
+    # loses to over-subscription: the two queues' workgroups take turns on a CU at workgroup granularity (a CU's LDS holds
+    # two conv_tn or three conv_nt workgroups, not both sets) and a kernel that runs in bursts at full occupancy beats one
+    # that shares the matrix pipe all the time.  The knob stays for the CU reserve of multi-GPU runs.
+    BWD_SHARE = None  # (nt64, nt128, wino, wgrad[, cu_reserve]) slots per CU during the backward pass; None: as if alone
 
     def _share_begin(self):
-        import os
         share = self.BWD_SHARE
-        env = os.environ.get('SACV_BWD_SHARE')  # round-4 experiment switch (removed once the default is chosen)
-        if env:
-            share = tuple(int(v) for v in env.split(','))
         if share is None or self._side is None or ops.TIMER is not None:
             return None
         return ops.launch_share(*share)

@@ -33,12 +33,24 @@ class MAEEngine:
         self._panels = None
         # weight gradients on a side HIP stream, as engine.DetectorEngine._on_side (its comment has the contract): every
         # dy handed to a weight gradient here is a fresh bf16 tensor (cast_bf16 / gelu_bwd / attention_bwd outputs)
-        import os
         self._side, self._side_busy = None, False
-        if os.environ.get('SACV_WGRAD_STREAM', '1') != '0' and arena.params.is_cuda:
+        self._side_evi, self._side_keep = 0, []
+        self.side_stream = self.SIDE_STREAM and arena.params.is_cuda
+
+    SIDE_STREAM = True  # default of `side_stream` (see DetectorEngine.side_stream)
+
+    @property
+    def side_stream(self):
+        return self._side is not None
+
+    @side_stream.setter
+    def side_stream(self, on):
+        if not on:
+            self._side_join()
+            self._side = None
+        elif self._side is None:
             self._side = torch.cuda.Stream()
             self._side_events = [torch.cuda.Event() for _ in range(64)]
-        self._side_evi, self._side_keep = 0, []
 
     def _on_side(self, launch, tensors):
         s = self._side

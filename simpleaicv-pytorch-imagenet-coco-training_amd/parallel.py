@@ -101,9 +101,34 @@ class GradExchanger:
             self.world = comm.world
         self.pending = []
         self.enabled = True  # False inside a gradient-accumulation window (DDP.no_sync)
+        # One-GPU measurement aid (bench.py --emulate-rccl): dict(workgroups, lds_bytes, gbps) -- at world
+        # size 1 every stage launches a stand-in for its all-reduce's kernels (sacv_comm_emulate_load: that many resident
+        # workgroups for the time an 8-rank ring all-reduce of the stage would take at `gbps` GB/s) on a stream of its
+        # own, chained exactly like the real collective
+        self.emulate = None
+        self._emu_stream, self._emu_scratch, self._emu_busy = None, None, False
+
+    def _emulate_stage(self, stage):
+        from ._lib import lib, check
+        b, e = self.ranges[stage]
+        if e <= b:
+            return
+        em = self.emulate
+        us = 2.0 * 7 / 8 * (e - b) * 4 / (em.get('gbps', 200.0) * 1e3)
+        if self._emu_stream is None:
+            self._emu_stream = torch.cuda.Stream()
+            self._emu_scratch = torch.zeros(4 << 20, device=self.g.device, dtype=torch.float32)
+        cur = torch.cuda.current_stream()
+        self._emu_stream.wait_stream(cur)
+        check(lib.sacv_comm_emulate_load(int(em['workgroups']), int(em.get('lds_bytes', 16384)), float(us),
+                                         self._emu_scratch.data_ptr(), self._emu_scratch.numel() * 4,
+                                         self._emu_stream.cuda_stream), 'comm_emulate_load')
+        self._emu_busy = True
 
     def stage_done(self, stage):
         """Called by the backward pass when every gradient of `stage` has been enqueued."""
+        if self.world == 1 and self.emulate and self.enabled:
+            return self._emulate_stage(stage)
         if self.world == 1 or not self.enabled:
             return
         b, e = self.ranges[stage]
@@ -118,6 +143,9 @@ class GradExchanger:
 
     def wait(self):
         """Make the current stream wait for all outstanding all-reduces (sums; divide by world)."""
+        if self._emu_busy:
+            torch.cuda.current_stream().wait_stream(self._emu_stream)
+            self._emu_busy = False
         if self.comm is not None:
             if self.pending:
                 self.comm.wait()

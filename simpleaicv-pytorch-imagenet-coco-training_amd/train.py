@@ -133,7 +133,7 @@ class _StepDriver:
     def _stage_cb(self):
         """The engines' per-stage callback, or None when a stage has nothing to do (one rank, no accumulation window):
         the engine then skips the stage's event chaining altogether."""
-        return self._on_stage if (self.world > 1 or self.accum is not None) else None
+        return self._on_stage if (self.world > 1 or self.accum is not None or self.exchanger.emulate) else None
 
     def _on_stage(self, stage):
         """Backward finished the gradients of `stage`: fold in the accumulation window, start the exchange.  Called with

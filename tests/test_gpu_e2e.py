@@ -106,14 +106,15 @@ def test_full_size_against_reference_fixture(golden_dir):
             d = gi.digest(o.detach().cpu().numpy(), 256)
             np.testing.assert_allclose(d['samples'], arrs[f'retina_S1_out{gi_}_l{l}_samples'], rtol=2e-4, atol=2e-6)
     sum(ld.values()).backward()
-    # gradient norms of all 195 tensors vs the reference's fp32 CPU run (ill-conditioned backward, see
-    # test_forward_loss_backward_vs_oracle: 5 % per tensor, 1 % on the median)
+    # gradient norms of all 195 tensors vs the reference's fp32 CPU run.  Gates = 3 x what this run prints (round 4:
+    # median 2.2e-4, max 3.6e-3 -- the stem's BatchNorm parameters, behind 53 batch-statistics layers): a regression
+    # that triples the distance to the reference fails here
     rel = []
     for name, p in net.named_parameters():
         n = float(p.grad.double().norm())
         rel.append(abs(n - meta['grad_norm'][name]) / (meta['grad_norm'][name] + 1e-12))
-        assert rel[-1] <= 5e-2, (name, rel[-1])
-    assert float(np.median(rel)) <= 1e-2, float(np.median(rel))
+        assert rel[-1] <= 1.2e-2, (name, rel[-1])
+    assert float(np.median(rel)) <= 7e-4, float(np.median(rel))
     print('S1 grad-norm rel err: median %.2e max %.2e' % (float(np.median(rel)), max(rel)))
 
 

@@ -15,19 +15,12 @@ from tests import golden_inputs as gi
 
 def _build(kind, side):
     from sacv_amd.detection import models, losses
-    old = os.environ.get('SACV_WGRAD_STREAM')
-    os.environ['SACV_WGRAD_STREAM'] = '1' if side else '0'
-    try:
-        fcos = kind == 'fcos'
-        net = models.__dict__['resnet50_fcos' if fcos else 'resnet50_retinanet'](num_classes=80)
-        net.load_state_dict(omodel.init_retinanet_state(0, fcos=fcos))
-        net = net.cuda().train()
-        assert (net.engine._side is not None) == side
-    finally:
-        if old is None:
-            os.environ.pop('SACV_WGRAD_STREAM', None)
-        else:
-            os.environ['SACV_WGRAD_STREAM'] = old
+    fcos = kind == 'fcos'
+    net = models.__dict__['resnet50_fcos' if fcos else 'resnet50_retinanet'](num_classes=80)
+    net.load_state_dict(omodel.init_retinanet_state(0, fcos=fcos))
+    net = net.cuda().train()
+    net.engine.side_stream = side  # False: the stream-ordered twin
+    assert (net.engine._side is not None) == side
     crit = losses.__dict__['FCOSLoss' if fcos else 'RetinaLoss']()
     return net, crit
 
@@ -82,17 +75,10 @@ def test_classifier_and_mae_side_streams_change_no_bit():
     from sacv_amd.train import ClassificationTrainer
     res = {}
     for side in (False, True):
-        old = os.environ.get('SACV_WGRAD_STREAM')
-        os.environ['SACV_WGRAD_STREAM'] = '1' if side else '0'
-        try:
-            net = backbones.__dict__['resnet50'](num_classes=40)
-            net.load_state_dict(omodel.init_resnet50_cls_state(0, 40), strict=True)
-            net = net.cuda().train()
-        finally:
-            if old is None:
-                os.environ.pop('SACV_WGRAD_STREAM', None)
-            else:
-                os.environ['SACV_WGRAD_STREAM'] = old
+        net = backbones.__dict__['resnet50'](num_classes=40)
+        net.load_state_dict(omodel.init_resnet50_cls_state(0, 40), strict=True)
+        net = net.cuda().train()
+        net.engine.side_stream = side
         tr = ClassificationTrainer(net, closses.__dict__['CELoss'](), lr=1e-3, use_amp=True)
         x = torch.tensor(synth.images(11, 8, 96, 96)).cuda()
         lab = (torch.arange(8) % 40).cuda()

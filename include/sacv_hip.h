@@ -122,6 +122,9 @@ int sacv_wino_wgrad(int nlev, const float* const* dy /*host array*/, int Nb, con
                     const float* V, int Tpad, int Cin, float* dw, int accumulate, int dw_layout, float* workspace,
                     void* stream);
 
+/* pixels per split (`chunk`) that fills the weight-gradient queue's workgroup slots for this problem list: npix[i] =
+ * Nb * Ho * Wo of segment i, N2 = KH * KW * Cin_pad, taps = KH * KW */
+int sacv_conv2d_wgrad_chunk(int nseg, const int* npix /*host*/, int Cout, int N2, int taps);
 long long sacv_conv2d_wgrad_workspace_bytes(int nseg, const int* Nb, const int* Ho, const int* Wo, int Cin_pad,
                                             int Cout, int KH, int KW, int chunk);
 

@@ -37,6 +37,7 @@ SIGNATURES = {
     'sacv_wino_wgrad_workspace_bytes': (LL, [I, I, I]),
     'sacv_wino_wgrad': (I, [I, P, I, P, P, I, P, I, I, P, I, I, P, P]),
     'sacv_wino_gemm': (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    'sacv_conv2d_wgrad_chunk': (I, [I, P, I, I, I]),
     'sacv_conv2d_wgrad_workspace_bytes': (LL, [I, P, P, P, I, I, I, I, I]),
     'sacv_conv2d_wgrad': (I, [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     'sacv_pack_dgrad_batched': (I, [P, P, I, P]),

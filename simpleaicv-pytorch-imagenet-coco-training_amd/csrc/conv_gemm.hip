@@ -1186,6 +1186,15 @@ static int launch_tn(const WgradArgs& a, int chunks, hipStream_t st) {
   return SACV_OK;
 }
 
+// Tile of the weight-gradient GEMM dW[Cout][N2 = taps * Cin]: 128 x 128 (64 where a dimension is that narrow); the 1x1
+// layers take 64 x 64 tiles whatever their widths -- their K (the pixels) is all there is to split, and a 128 x 128 tile
+// cut 32-64 ways leaves a workgroup 4-8 K iterations per 64 KB slab it writes: with 16 KB slabs and four times the K
+// per workgroup the same launches take 51-54 us instead of 57-62 (layer2-4 at 2 x 800 x 1333; scripts/bench_tn_tiles.py).
+static void wgrad_tile(int Cout, int N2, int taps, int* bm, int* bn) {
+  *bm = (Cout <= 64 || taps == 1) ? 64 : 128;
+  *bn = (N2 <= 64 || taps == 1) ? 64 : 128;
+}
+
 int sacv_internal_wgrad_reduce(const float* part, float* dw, int chunks, int Cout, int Cin, int Cin_pad, int KH,
                                int KW, int accumulate, int dw_taps, int dw_layout, void* stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -1371,6 +1380,32 @@ long long sacv_conv2d_gemm_workspace_bytes(void) {
   return 2LL * num_cus() * SACV_NT_BLOCKS_PER_CU * 128 * 128 * (long long)sizeof(float);  // 2 slabs per workgroup
 }
 
+// Pixels per split of sacv_conv2d_wgrad for a problem list (the `chunk` argument): the split count that fills the
+// workgroup slots the weight gradients' queue plans for (sacv_launch_share).  One segment: equal splits, tiles x splits
+// within one co-resident wave of workgroups (512 beats 544 and 1024 with 128-wide tiles; the 64 x 64 tiles of the 1x1
+// layers run four to a CU: 768).  Several segments (pyramid levels sharing a weight): the splits are unequal (short
+// levels), so twice as many, smaller splits balance better (1024 beats 512 by 20 %).
+int sacv_conv2d_wgrad_chunk(int nseg, const int* npix, int Cout, int N2, int taps) {
+  if (nseg < 1 || !npix || Cout <= 0 || N2 <= 0) return -1;
+  int bm, bn;
+  wgrad_tile(Cout, N2, taps, &bm, &bn);
+  int cus = num_cus() - sacv_share.cu_reserve;
+  if (cus < 8) cus = 8;
+  const int per_cu = sacv_share.wgrad_wg_per_cu;  // 2 alone
+  int target = (bm == 64 && bn == 64 && taps == 1) ? cus * per_cu * 3 / 2 : cus * per_cu;
+  if (nseg > 1) target *= 2;
+  const long long tiles = (long long)((Cout + bm - 1) / bm) * ((N2 + bn - 1) / bn);
+  long long total = 0;
+  for (int i = 0; i < nseg; ++i) total += npix[i];
+  long long chunks = target / tiles;
+  const long long max_chunks = (total + 127) / 128;
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  long long chunk = (total + chunks - 1) / chunks;
+  chunk = (chunk + 31) / 32 * 32;
+  return (int)(chunk < 32 ? 32 : chunk);
+}
+
 // Workspace (bytes) needed by sacv_conv2d_wgrad for the given problem list.
 long long sacv_conv2d_wgrad_workspace_bytes(int nseg, const int* Nb, const int* Ho, const int* Wo, int Cin_pad,
                                             int Cout, int KH, int KW, int chunk) {
@@ -1422,8 +1457,10 @@ int sacv_conv2d_wgrad(int nseg, const float* const* dy, const float* const* x, c
   a.pad = pad;
   hipStream_t st = (hipStream_t)stream;
   int rc;
-  if (Cout <= 64)
-    rc = (a.N2 <= 64) ? launch_tn<64, 64>(a, chunks, st) : launch_tn<64, 128>(a, chunks, st);
+  int bm, bn;
+  wgrad_tile(Cout, a.N2, KH * KW, &bm, &bn);
+  if (bm == 64)
+    rc = (bn == 64) ? launch_tn<64, 64>(a, chunks, st) : launch_tn<64, 128>(a, chunks, st);
   else
     rc = (a.N2 <= 64) ? launch_tn<128, 64>(a, chunks, st) : launch_tn<128, 128>(a, chunks, st);
   if (rc != SACV_OK) return rc;

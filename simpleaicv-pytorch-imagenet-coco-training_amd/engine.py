@@ -103,8 +103,11 @@ class DetectorEngine:
             self._side_join()
             self._side = None
         elif self._side is None:
-            self._side = torch.cuda.Stream()  # (the launch stream at high priority: 27.82 -> 27.62 ms; not adopted)
+            # (the launch stream at high priority: 27.82 -> 27.62 ms; not adopted)
+            self._side = torch.cuda.Stream(priority=self.SIDE_PRIORITY)
             self._side_events = [torch.cuda.Event() for _ in range(64)]
+
+    SIDE_PRIORITY = 0  # HIP priority of the weight gradients' stream (lower number = served first)
 
     def _add_shadow(self, name):
         if not self._shadows:  # the dicts are shared with the model / arena: the engine edits copies of its own

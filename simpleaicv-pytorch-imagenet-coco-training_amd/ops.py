@@ -446,8 +446,6 @@ def _conv_gemm_bf16(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bi
     return outs
 
 
-_WGRAD_TARGET_MULTI = 1024
-_WGRAD_TARGET = 512  # = resident workgroups (2/CU): one wave of blocks; 544 or 1024 measured slower
 SHARE_ALONE = (3, 2, 3, 2, 0)
 _share = SHARE_ALONE
 
@@ -456,31 +454,32 @@ def launch_share(nt64=0, nt128=0, wino=0, wgrad=0, cu_reserve=-1):
     """Launch plan of the following launches (include/sacv_hip.h: sacv_launch_share): workgroup slots per CU the
     persistent convolution kernels may plan for, CUs they leave free.  Returns the previous plan (a 5-tuple that can be
     passed back as launch_share(*prev))."""
-    global _share, _WGRAD_TARGET, _WGRAD_TARGET_MULTI
+    global _share
     prev = _share
     cur = tuple(n if n > 0 else o for n, o in zip((nt64, nt128, wino, wgrad), prev[:4])) + \
         (cu_reserve if cu_reserve >= 0 else prev[4],)
     check(lib.sacv_launch_share(*cur), 'launch_share')
     _share = cur
-    # direct weight gradients: the split count is chosen here (one co-resident wave of workgroups)
-    _WGRAD_TARGET = 256 * cur[3]
-    _WGRAD_TARGET_MULTI = 512 * cur[3]
     return prev
 
 
-def _wgrad_chunk(npix, cout, n2, target_blocks=None):
-    """Pixels per split of the weight-gradient GEMM.  npix: pixel count per segment (each segment is split on its
-    own).  One segment: equal splits, as many as keep tiles x splits within ONE co-resident wave of workgroups
-    (measured: 512 beats 544 and 1024).  Several segments (pyramid levels sharing a weight): the splits are unequal
-    (short levels), so twice as many, smaller splits balance better (1024 beats 512 by 20 %)."""
+def _wgrad_chunk(npix, cout, n2, taps):
+    """Pixels per split of the weight-gradient GEMM (planned in the library: sacv_conv2d_wgrad_chunk)."""
     npix = [npix] if isinstance(npix, int) else list(npix)
-    target_blocks = target_blocks or (_WGRAD_TARGET if len(npix) == 1 else _WGRAD_TARGET_MULTI)
+    chunk = lib.sacv_conv2d_wgrad_chunk(len(npix), iarr(npix), cout, n2, taps)
+    if chunk <= 0:
+        raise ValueError('wgrad_chunk: bad problem list')
+    return chunk
+
+
+def _wgrad_chunk_bf16(npix, cout, n2, target_blocks=512):
+    """Pixels per split of the bf16 weight-gradient GEMM (conv_tn_bf16_kernel: 128-wide tiles, 64 where a dimension is
+    that narrow): tiles x splits within one co-resident wave of workgroups."""
     bm = 64 if cout <= 64 else 128
     bn = 64 if n2 <= 64 else 128
     tiles = -(-cout // bm) * -(-n2 // bn)
-    total = sum(npix)
-    chunks = max(1, min(target_blocks // tiles, -(-total // 128)))
-    chunk = -(-total // chunks)
+    chunks = max(1, min(target_blocks // tiles, -(-npix // 128)))
+    chunk = -(-npix // chunks)
     return max(32, -(-chunk // 32) * 32)
 
 
@@ -510,7 +509,7 @@ def conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, accumulate=False, cin_pad=
     nb = [d.shape[0] for d in dys]
     ho = [d.shape[1] for d in dys]
     wo = [d.shape[2] for d in dys]
-    chunk = _wgrad_chunk([b * h * w for b, h, w in zip(nb, ho, wo)], cout, kh * kw * cin_pad)
+    chunk = _wgrad_chunk([b * h * w for b, h, w in zip(nb, ho, wo)], cout, kh * kw * cin_pad, kh * kw)
     nbytes = lib.sacv_conv2d_wgrad_workspace_bytes(n, iarr(nb), iarr(ho), iarr(wo), cin_pad, cout, kh, kw, chunk)
     ws = workspace(nbytes, dys[0].device, 'wgrad')
     def launch():
@@ -534,7 +533,7 @@ def _conv_wgrad_bf16(dys, xs, dw, cin, cin_pad, cout, kh, kw, stride, pad, accum
         raise ValueError('bf16 conv_wgrad: one segment per launch')
     dy, x = _chk(dys[0], 'dy', BF16), _chk(xs[0], 'x', BF16)
     nb, ho, wo = dy.shape[0], dy.shape[1], dy.shape[2]
-    chunk = _wgrad_chunk([nb * ho * wo], cout, kh * kw * cin_pad)
+    chunk = _wgrad_chunk_bf16(nb * ho * wo, cout, kh * kw * cin_pad)
     chunk = max(64, -(-chunk // 64) * 64)
     nbytes = lib.sacv_conv2d_wgrad_bf16_workspace_bytes(nb, ho, wo, cin_pad, cout, kh, kw, chunk)
     ws = workspace(nbytes, dy.device, 'wgrad')

@@ -355,6 +355,14 @@ class DetectorEngine:
     # weight gradients) disappears for 41 of the trunk's 53 layers.  False: every layer runs its own first stage (A/B,
     # tests).
     fuse_bn_bwd = True
+    # Where a layer's weight gradient enters the side stream: right behind the BatchNorm backward that produces its dy
+    # (False: it starts WITH the layer's data gradient -- two matrix-core kernels taking turns on the CUs) or behind the
+    # data gradient's launch (True: it starts when the data gradient has finished, next to the NEXT layer's BatchNorm
+    # backward -- an HBM-bound phase of the launch stream).  Measured (round 4, same session, three runs each): 26.7 ms
+    # with False, 27.45 with True -- two matrix-core kernels that each reach ~0.55 of the peak alone fill each other's
+    # stalls when they share the chip; serialising them loses more than the complementary pairing gains.  For scale: the
+    # step without ANY weight gradient takes 21.56 ms, with all of them in stream order 28.98.
+    wgrad_after_dgrad = False
 
     def _cba_bwd(self, c, dz, need_dx=True, want_g=False, dx_out=None, dx_accum=False, partial=None, fuse=None):
         """Backward of one layer.  Returns (dx, g, st): g is the ReLU-masked upstream gradient; st -- when `fuse` (the
@@ -379,7 +387,8 @@ class DetectorEngine:
                                       flags=[CF_ACCUM if dx_accum else 0],
                                       outs_list=[[dx_out]] if dx_out is not None else None, mode=1)[0][0]
             return dx, gm, None
-        self._wgrad([dy], [c.x], g[wname], cin, c.k, c.k, c.stride, c.pad)
+        if not self.wgrad_after_dgrad:
+            self._wgrad([dy], [c.x], g[wname], cin, c.k, c.k, c.stride, c.pad)
         dx, st = None, None
         if need_dx:
             if (fuse is not None and self.fuse_bn_bwd and not self.amp and c.stride == 1 and fuse.relu
@@ -393,6 +402,8 @@ class DetectorEngine:
                                              flags=CF_ACCUM if dx_accum else 0)
             else:
                 dx = self._dgrad(dy, w, c.x.shape, c.k, c.stride, c.pad, out=dx_out, accumulate=dx_accum)
+        if self.wgrad_after_dgrad:
+            self._wgrad([dy], [c.x], g[wname], cin, c.k, c.k, c.stride, c.pad)
         return dx, gm, st
 
     def _dgrad(self, dy, w, x_shape, k, stride, pad, out=None, accumulate=False, mask=None):

@@ -115,6 +115,16 @@ def launch_ranks(n):
     sys.exit(rc)
 
 
+def apply_engine_settings(args, net):
+    """--engine-set NAME=VALUE: attributes of the model's executor (A/B runs, the profile session's stream-ordered trace)."""
+    import ast
+    for kv in getattr(args, 'engine_set', []):
+        name, value = kv.split('=', 1)
+        if not hasattr(net.engine, name):
+            raise SystemExit(f'--engine-set: the executor has no attribute {name!r}')
+        setattr(net.engine, name, ast.literal_eval(value))
+
+
 def bench_classification(args, rank, world, group, ops, synth):
     """Secondary workload: 0.classification_training/imagenet/resnet50/train_config.py --
     batch 256, 224x224, CELoss, SGD(0.1, 0.9, wd 1e-4) -- in fp32 (the reference recipe runs fp16 autocast)."""
@@ -128,6 +138,7 @@ def bench_classification(args, rank, world, group, ops, synth):
     net = backbones.__dict__['resnet50'](num_classes=1000).cuda().train()
     trainer = ClassificationTrainer(net, losses.__dict__['CELoss'](), lr=0.1, momentum=0.9, weight_decay=1e-4,
                                     process_group=group, use_amp=amp)
+    apply_engine_settings(args, net)
     images = torch.cat([torch.tensor(synth.images(rank * 64 + i, CB // 8, R, R)) for i in range(8)]).cuda()
     labels = torch.tensor((synth.uniform(rank + 99, (CB,)) * 1000).astype(np.int64) % 1000).cuda()
 
@@ -242,6 +253,7 @@ def bench_mae(args, rank, world, group, ops, synth):
     net = models.__dict__['vit_base_patch16_224_mae_pretrain_model']().cuda().train()
     trainer = MAETrainer(net, losses.__dict__['MSELoss'](), lr=6e-4, betas=(0.9, 0.95), weight_decay=5e-2,
                          process_group=group)
+    apply_engine_settings(args, net)
     images = (torch.cat([torch.tensor(synth.images(rank * 64 + i, MB // 8, R, R)) for i in range(8)]) * 4 - 2).cuda()
 
     def sync():
@@ -557,12 +569,7 @@ def main():
         f = args.emulate_rccl.split(':')
         trainer.exchanger.emulate = dict(workgroups=int(f[0]), lds_bytes=int(f[1]) if len(f) > 1 else 16384,
                                          gbps=float(f[2]) if len(f) > 2 else 200.0)
-    import ast
-    for kv in args.engine_set:
-        name, value = kv.split('=', 1)
-        if not hasattr(net.engine, name):
-            raise SystemExit(f'--engine-set: the executor has no attribute {name!r}')
-        setattr(net.engine, name, ast.literal_eval(value))
+    apply_engine_settings(args, net)
     images = torch.tensor(synth.images(rank, BATCH, H, W)).cuda()
     annots = torch.tensor(synth.annotations(rank, BATCH, H, W, boxes_per_image=8)).cuda()
 

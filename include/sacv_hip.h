@@ -35,8 +35,12 @@ int sacv_abi_version(void);
  *   wgrad            slots per CU the split planner of sacv_wino_wgrad fills (alone: 2); sacv_conv2d_wgrad takes its
  *                    split size (`chunk`) from the caller
  *   cu_reserve       CUs every persistent grid leaves free (RCCL's channels)
- * A value <= 0 (cu_reserve: < 0) keeps the current setting.  Results do not depend on the plan (fixed-order sums). */
-int sacv_launch_share(int nt64_wg_per_cu, int nt128_wg_per_cu, int wino_wg_per_cu, int wgrad_wg_per_cu, int cu_reserve);
+ *   split_policy     remainder tiles of sacv_conv2d_gemm (those left after the last full round of the persistent grid):
+ *                    3 = cost model (one workgroup per tile / uniform K split / stream-K), 0 = never split along K
+ * A value <= 0 (cu_reserve, split_policy: < 0) keeps the current setting.  Results of a given plan are deterministic
+ * (fixed-order sums); different plans differ by fp32 summation order. */
+int sacv_launch_share(int nt64_wg_per_cu, int nt128_wg_per_cu, int wino_wg_per_cu, int wgrad_wg_per_cu, int cu_reserve,
+                      int split_policy);
 
 /* ---- convolution (nn.Conv2d: classification/backbones/resnet.py:33-39; detection/models/fpn.py:20-58;
  *      detection/models/head.py:20-33,60-73) -------------------------------------------------------- */

@@ -1099,7 +1099,7 @@ static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w) {
   // Stream-K equalises the work of every CU but costs a second (partial) epilogue in the workgroups whose
   // range crosses a tile boundary and more slabs per tile in the fix-up: measured ~+12 us per launch
   // (~6 K-iterations) over a uniform split, so it wins on the long-K problems (3x3 convs, head towers).
-  constexpr int policy = SACV_SK_POLICY;       // 0 none, 1 uniform only, 2 stream-K only, 3 auto
+  const int policy = sacv_share.split_policy == 0 ? 0 : SACV_SK_POLICY;  // 0 none, 1 uniform only, 2 stream-K only, 3 auto
   constexpr double sk_extra = SACV_SK_EXTRA;
   p.sk_blocks = p.rem;
   double tail = KT + epi;

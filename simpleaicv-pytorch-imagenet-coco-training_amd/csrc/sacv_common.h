@@ -27,6 +27,7 @@ struct SacvShare {
   int wino_wg_per_cu;    // wino_gemm_kernel, narrow items (3 alone; wide items: min(2, this))
   int wgrad_wg_per_cu;   // wino_wgrad_kernel plan (2 alone); conv_tn's split count is the caller's `chunk`
   int cu_reserve;        // CUs every persistent grid leaves free
+  int split_policy;      // remainder tiles of conv_nt: 3 = cost model (uniform K split / stream-K / whole tiles), 0 = whole tiles only
 };
 extern thread_local SacvShare sacv_share;
 

@@ -446,18 +446,18 @@ def _conv_gemm_bf16(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bi
     return outs
 
 
-SHARE_ALONE = (3, 2, 3, 2, 0)
+SHARE_ALONE = (3, 2, 3, 2, 0, 3)
 _share = SHARE_ALONE
 
 
-def launch_share(nt64=0, nt128=0, wino=0, wgrad=0, cu_reserve=-1):
+def launch_share(nt64=0, nt128=0, wino=0, wgrad=0, cu_reserve=-1, split_policy=-1):
     """Launch plan of the following launches (include/sacv_hip.h: sacv_launch_share): workgroup slots per CU the
-    persistent convolution kernels may plan for, CUs they leave free.  Returns the previous plan (a 5-tuple that can be
-    passed back as launch_share(*prev))."""
+    persistent convolution kernels may plan for, CUs they leave free, whether remainder tiles are split along K.
+    Returns the previous plan (a tuple that can be passed back as launch_share(*prev))."""
     global _share
     prev = _share
     cur = tuple(n if n > 0 else o for n, o in zip((nt64, nt128, wino, wgrad), prev[:4])) + \
-        (cu_reserve if cu_reserve >= 0 else prev[4],)
+        (cu_reserve if cu_reserve >= 0 else prev[4], split_policy if split_policy >= 0 else prev[5])
     check(lib.sacv_launch_share(*cur), 'launch_share')
     _share = cur
     return prev

@@ -92,12 +92,15 @@ class ParamArena:
             p.grad = self.grad_views[n]
 
 
+_RUNTIME_ATTRS = ('_arena', '_engine', '_param_list', '_last_outputs', '_co_handle', '_co_params')
+
+
 def deepcopy_without_runtime(self, memo):
     """`copy.deepcopy(model)` -- what the reference's EmaModel does with the model (tools/utils.py:150-153): the copy gets
     the module tree, parameters and buffers; the flat arenas and the executor (HIP streams, events, scratch) are RUNTIME
     state and are rebuilt for the copy (lazily at its first use, or at once when the model sits on the GPU)."""
     import copy
-    runtime = ('_arena', '_engine', '_param_list', '_last_outputs')
+    runtime = _RUNTIME_ATTRS
     new = type(self).__new__(type(self))
     memo[id(self)] = new
     for k, v in self.__dict__.items():
@@ -108,7 +111,6 @@ def deepcopy_without_runtime(self, memo):
     return new
 
 
-_RUNTIME_ATTRS = ('_arena', '_engine', '_param_list', '_last_outputs')
 
 
 def getstate_without_runtime(self):

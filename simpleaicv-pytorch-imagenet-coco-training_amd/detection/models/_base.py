@@ -148,6 +148,8 @@ class HipDetector(nn.Module):
         self._engine = None
         self._param_list = None
         self._last_outputs = None
+        self._co_handle = None
+        self._co_params = None
 
     def _load_backbone(self, path):
         """Name-and-shape matched warm start (simpleAICV/classification/common.py:758-784)."""
@@ -171,6 +173,10 @@ class HipDetector(nn.Module):
         self._engine = DetectorEngine(tensors, self._arena.grad_views, self.num_classes, self.num_anchors,
                                       self.planes, fcos=self._fcos, block=getattr(self.backbone, 'block', 'Bottleneck'),
                                       layers=getattr(self.backbone, 'layer_nums', RESNET50_LAYERS))
+        # operands of the registered operator (custom_ops.py): what torch.compile's graph takes as inputs
+        from ... import custom_ops
+        custom_ops.register_model(self)
+        self._co_params = [p for _, p in self._param_list]
         return self
 
     def _apply(self, fn, recurse=True):
@@ -197,9 +203,18 @@ class HipDetector(nn.Module):
         self._ready()
         return self._engine
 
-    @torch.compiler.disable  # config.use_compile (torch.compile(model), tools/train_detection_model.py:176-178): nothing to trace --
-    # the forward pass is one call into the HIP executor; the compiled wrapper runs it as is
     def forward(self, inputs):
+        """Eager: one autograd node around the executor (_forward_eager).  Under torch.compile (config.use_compile,
+        tools/train_detection_model.py:176-178) the same pass is ONE registered operator, sacv::detector_forward
+        (custom_ops.py), so the tracer captures the model without a graph break."""
+        if torch.compiler.is_compiling():
+            outs = torch.ops.sacv.detector_forward(inputs.float(), self._co_params, self._co_handle, self.training,
+                                                   torch.is_grad_enabled() and self.training)
+            return [list(outs[k:k + 5]) for k in range(0, len(outs), 5)]
+        return self._forward_eager(inputs)
+
+    @torch.compiler.disable
+    def _forward_eager(self, inputs):
         if inputs.device.type != 'cuda':
             raise RuntimeError(f'sacv_amd {type(self).__name__} runs on MI355X only: inputs must be on the GPU '
                                '(no CPU fallback)')

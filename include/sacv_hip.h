@@ -12,7 +12,28 @@
  *     (reference state_dict layout) and are repacked by sacv_pack_weight;
  *   - `stream` is a hipStream_t (0 = default stream); calls only enqueue work, never synchronise;
  *   - return 0 on success, negative on error (-1 bad argument, -2 launch failure,
- *     -3 unsupported); sacv_last_error() returns the message for the calling thread.
+ *     -3 unsupported); sacv_last_error() returns the message for the calling thread;
+ *   - the shared object exports exactly the functions declared here (-fvisibility=hidden + csrc/exports.map;
+ *     tests/test_abi.py compares the dynamic symbol table with this file).  sacv_abi_version() == 3.
+ *
+ * Where the symbol list of SURVEY.md 8(b) went (it was written before the kernels; arguments are positional scalars
+ * and pointers here, not `const sacv_<op>_args*` records -- every call site is a ctypes call, a record would be packed
+ * and unpacked for nothing):
+ *   conv2d_fwd / conv2d_dgrad        sacv_conv2d_gemm (mode 0 / 1; grouped over pyramid levels), sacv_wino_gemm for the
+ *                                    stride-1 3x3 head convolutions, sacv_stem_conv_fwd for the 7x7 stem
+ *   conv2d_wgrad                     sacv_conv2d_wgrad, sacv_wino_wgrad, sacv_stem_conv_wgrad
+ *   bn_train_fwd                     the statistics are an epilogue option of the producing convolution (SACV_CF_STATS)
+ *                                    + sacv_bn_finalize_stats + sacv_bn_apply (sacv_bn_train_stats for a bare tensor)
+ *   bn_train_bwd                     sacv_bn_train_bwd; its first stage can run in the epilogue of the data gradient that
+ *                                    produces the upstream gradient (sacv_conv2d_gemm_bnbwd + sacv_bn_train_bwd_partial)
+ *   sigmoid_permute_fwd / _bwd       no kernels: activations are NHWC, so the reference's permute(0,2,3,1).contiguous()
+ *                                    is a view; sigmoid is SACV_CF_SIGMOID of the output convolution, its backward one
+ *                                    mode of sacv_eltwise
+ *   focal_fwd / focal_bwd            ONE pass: sacv_focal_loss_fwd_bwd writes the loss terms and d loss / d prob
+ *   box_loss_fwd / box_loss_bwd      likewise: sacv_retina_box_loss_fwd_bwd, sacv_fcos_reg_ctr_loss_fwd_bwd
+ *   decode_topk_nms                  sacv_decode_topk_nms, sacv_decode_topk_soft_nms (score scan + selection + box decode + NMS, batched)
+ *   adamw_step                       sacv_adamw_step_gated (both parameter groups, skip gate and clip factor on the device)
+ *   allreduce_bucket                 sacv_allreduce_bucket (RCCL on the communicator's own stream, sacv_comm_*)
  */
 #ifndef SACV_HIP_H
 #define SACV_HIP_H

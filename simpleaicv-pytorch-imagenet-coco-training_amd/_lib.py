@@ -155,7 +155,7 @@ def _load():
     return lib
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 lib = _load()
 if lib.sacv_abi_version() != ABI_VERSION:
     raise ImportError(f'{LIB_PATH} has ABI version {lib.sacv_abi_version()}, this package needs {ABI_VERSION}: rebuild it '

@@ -12,7 +12,7 @@ void sacv_set_error(const char* fmt, ...) {
 }
 
 SACV_API const char* sacv_last_error(void) { return g_err; }
-SACV_API int sacv_abi_version(void) { return 2; }
+SACV_API int sacv_abi_version(void) { return 3; }
 
 thread_local SacvShare sacv_share = {3, 2, 3, 2, 0, 3};
 

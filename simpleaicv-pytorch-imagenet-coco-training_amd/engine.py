@@ -388,7 +388,7 @@ class DetectorEngine:
                                       outs_list=[[dx_out]] if dx_out is not None else None, mode=1)[0][0]
             return dx, gm, None
         if not self.wgrad_after_dgrad:
-            self._wgrad([dy], [c.x], g[wname], cin, c.k, c.k, c.stride, c.pad)
+            self._trunk_wgrad(c, dy, g[wname], cin)
         dx, st = None, None
         if need_dx:
             if (fuse is not None and self.fuse_bn_bwd and not self.amp and c.stride == 1 and fuse.relu
@@ -403,8 +403,21 @@ class DetectorEngine:
             else:
                 dx = self._dgrad(dy, w, c.x.shape, c.k, c.stride, c.pad, out=dx_out, accumulate=dx_accum)
         if self.wgrad_after_dgrad:
-            self._wgrad([dy], [c.x], g[wname], cin, c.k, c.k, c.stride, c.pad)
+            self._trunk_wgrad(c, dy, g[wname], cin)
         return dx, gm, st
+
+    # Weight gradient of the trunk's stride-1 3x3 convolutions on the Winograd path (2.25x fewer matrix-core flops): the
+    # forward pass ran them on the direct kernel and kept no transformed input, so the side stream transforms x itself
+    # (wino_input into its scratch) before the 16 split-K GEMMs.  False: conv_tn for every trunk layer.
+    wino_trunk_wgrad = False
+
+    def _trunk_wgrad(self, c, dy, dw, cin):
+        if (self.wino_trunk_wgrad and self._use_wino() and c.k == 3 and c.stride == 1 and c.pad == 1
+                and ops.wino_wgrad_supported(cin) and dy.shape[3] >= 64):
+            def launch():
+                ops.wino_wgrad([dy], ops.wino_input([c.x], tag='wino_vx'), dw, cin)
+            return self._on_side(launch, [dy, c.x])
+        self._wgrad([dy], [c.x], dw, cin, c.k, c.k, c.stride, c.pad)
 
     def _dgrad(self, dy, w, x_shape, k, stride, pad, out=None, accumulate=False, mask=None):
         cin = w.shape[1]
@@ -456,12 +469,20 @@ class DetectorEngine:
         ctx = {} if keep else None
         self._wino_cache = {}  # Winograd-domain weights are per forward (the optimizer step changes the weights)
         self._shadow_refresh()
+        self._wino_prepared = False
         if keep:
             if self.amp or not self._ds_on_side:
                 self._refresh_dgrad_panels()  # amp: the same launch pair also casts the FORWARD panels
             else:
-                # fp32: the data-gradient panels are read by the backward pass only (which joins the side stream first)
-                self._on_side(self._refresh_dgrad_panels, [])
+                # fp32: the data-gradient panels are read by the backward pass only (which joins the side stream first);
+                # the Winograd-domain weights of the head towers (forward and data-gradient panels, one batched launch)
+                # depend on the weights alone: behind the panels on the side stream, under the trunk's forward pass
+                def prep():
+                    self._refresh_dgrad_panels()
+                    if self._use_wino() and not self.fcos and self._side is not None:
+                        self._wino_prepare(self._retina_wino_names(), True, joined=True)
+                        self._wino_prepared = True
+                self._on_side(prep, [])
         self._fold_prepare(training, keep)
         feats = self._backbone_fwd(images, training, keep, ctx)
         c3f, c4f, c5f = feats[1], feats[2], feats[3]
@@ -672,11 +693,15 @@ class DetectorEngine:
     def _use_wino(self):
         return self.winograd and not self.amp
 
-    def _wino_prepare(self, names, training):
+    def _retina_wino_names(self):
+        return ([f'{t}.{i}.weight' for t, _ in self.RETINA_TOWERS for i in (0, 2, 4, 6)] +
+                [o + '.weight' for _, o in self.RETINA_TOWERS])
+
+    def _wino_prepare(self, names, training, joined=False):
         """All Winograd-domain weights of the head convolutions in ONE launch per pass (forward panels, and the
         data-gradient panels when a backward pass follows) instead of one 5 us launch per weight and direction."""
         jobs, keys = [], []
-        if training:
+        if training and not joined:
             self._side_join()  # the data-gradient panels read below are refreshed on the side stream (forward())
         for n in names:
             w = self.p[n]
@@ -714,8 +739,10 @@ class DetectorEngine:
         kept for a backward, every layer's transformed input V stays alive for its weight gradient."""
         p = self.p
         keep = ctx is not None
-        self._wino_prepare([f'{t}.{i}.weight' for t, _ in self.RETINA_TOWERS for i in (0, 2, 4, 6)] +
-                           [o + '.weight' for _, o in self.RETINA_TOWERS], keep)
+        if self._wino_prepared:
+            self._side_join()  # transformed on the side stream since the start of forward()
+        else:
+            self._wino_prepare(self._retina_wino_names(), keep)
         xs = [feats, feats]
         saved, vsaved = [[], []], [[], []]
         for li, i in enumerate((0, 2, 4, 6)):

@@ -406,14 +406,17 @@ class DetectorEngine:
             self._trunk_wgrad(c, dy, g[wname], cin)
         return dx, gm, st
 
-    # Weight gradient of the trunk's stride-1 3x3 convolutions on the Winograd path (2.25x fewer matrix-core flops): the
-    # forward pass ran them on the direct kernel and kept no transformed input, so the side stream transforms x itself
-    # (wino_input into its scratch) before the 16 split-K GEMMs.  False: conv_tn for every trunk layer.
-    wino_trunk_wgrad = False
+    # Weight gradient of the trunk's stride-1 3x3 convolutions with >= 128 channels on the Winograd path (2.25x fewer
+    # matrix-core flops): the forward pass ran them on the direct kernel and kept no transformed input, so the side
+    # stream transforms x itself (wino_input into its scratch) before the 16 split-K GEMMs.  At 2 x 800 x 1333 (us,
+    # transform included, scripts/bench_wino_wgrad_trunk.py): 128 channels 98 vs 122 for conv_tn, 256: 77 vs 112, 512: 77
+    # vs 125; 64 channels (layer1) 174 vs 138 -- the transforms of the 200 x 334 maps outweigh the saving: conv_tn
+    # there.  Step: 26.79 -> 26.57 ms with all four widths, same-session A/B.  False: conv_tn for every trunk layer.
+    wino_trunk_wgrad = True
 
     def _trunk_wgrad(self, c, dy, dw, cin):
-        if (self.wino_trunk_wgrad and self._use_wino() and c.k == 3 and c.stride == 1 and c.pad == 1
-                and ops.wino_wgrad_supported(cin) and dy.shape[3] >= 64):
+        if (self.wino_trunk_wgrad and self._use_wino() and c.k == 3 and c.stride == 1 and c.pad == 1 and cin >= 128
+                and ops.wino_wgrad_supported(cin) and dy.shape[3] >= 128):
             def launch():
                 ops.wino_wgrad([dy], ops.wino_input([c.x], tag='wino_vx'), dw, cin)
             return self._on_side(launch, [dy, c.x])

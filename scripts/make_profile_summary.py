@@ -19,16 +19,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def read_stats(path):
     rows = []
     for r in csv.DictReader(open(path)):
-        rows.append((r['Name'], int(r['Calls']), float(r['TotalDurationNs']), float(r['AverageNs']), float(r['Percentage'])))
+        rows.append((r['Name'].replace('(anonymous namespace)::', ''), int(r['Calls']), float(r['TotalDurationNs']), float(r['AverageNs']), float(r['Percentage'])))
     return rows
 
 
 # kernels of the forward + data-gradient convolution family (bench.py's conv_nt_* timer records): the direct
 # implicit-GEMM kernel with its split-tile fix-up, and the Winograd path (transforms + GEMM).  A "launch" of the family
 # is one convolution call = one dispatch of a main kernel.
-NT_MAIN = ('conv_nt_kernel', 'wino_gemm_kernel')
+NT_MAIN = ('conv_nt_kernel', 'wino_gemm_kernel', 'stem_conv_kernel')
 NT_AUX = ('conv_fixup_kernel', 'wino_input_kernel', 'wino_weight_kernel')
-TN_FAMILY = ('conv_tn_kernel', 'wgrad_reduce_kernel', 'wino_wgrad_kernel', 'wino_dy_kernel', 'wino_wgrad_reduce_kernel')
+TN_FAMILY = ('conv_tn_kernel', 'wgrad_reduce_kernel', 'wino_wgrad_kernel', 'wino_dy_kernel', 'wino_wgrad_reduce_kernel',
+             'stem_wgrad_kernel', 'wgrad_reduce_stem_kernel')
 
 
 def pmc_per_launch(path, counter, mains, aux=()):
@@ -71,7 +72,8 @@ def hbm_table(stats_by_name, steps, B, H, W, extra, elem_bytes=4):
     gb = lambda f: sum(f(e, relu, res) for e, relu, res in L) * elem_bytes / 1e9
     rows = [
         ('bn_apply_kernel', gb(lambda e, r, s: e * (3 if s else 2)), 'read y, write z (+ the residual input of the 16 block outputs)'),
-        ('bn_bwd_partial_kernel', gb(lambda e, r, s: e * (3 if s else 2)), 'read dz, y (+ z where the ReLU follows a residual add; elsewhere the mask is recomputed from y)'),
+        # (round 4: bn_bwd_partial_kernel runs for 12 of the trunk's 53 layers only -- the others' first stage is an epilogue
+        #  option of the producing data gradient -- so it has no row of its own any more)
         ('bn_bwd_apply_kernel', gb(lambda e, r, s: e * (5 if s else 3)), 'read dz, y (+ z), write dy (+ the masked gradient copy for the residual branch)'),
     ] + extra
     out = []
@@ -90,7 +92,7 @@ def mfma_utilisation(path, tag):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     dur, n, seen = collections.defaultdict(float), collections.Counter(), set()
     for r in csv.DictReader(open(path)):
-        k = r['Kernel_Name'].split('(')[0].replace('void ', '')
+        k = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '')
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         if r['Dispatch_Id'] not in seen:
             seen.add(r['Dispatch_Id'])
@@ -137,17 +139,19 @@ def main():
     fs, n1 = pmc_per_launch(pf, 'FETCH_SIZE', NT_MAIN, NT_AUX)
     ws, n2 = pmc_per_launch(pw, 'WRITE_SIZE', NT_MAIN, NT_AUX)
     traffic = dict(kernel='conv_nt_kernel<128,*,*> + conv_fixup_kernel, wino_gemm_kernel + wino_input_kernel + '
-                          'wino_weight_kernel (per convolution call)', launches=n1, fetch_size_kb_per_launch=fs / n1,
+                          'wino_weight_kernel, stem_conv_kernel (per convolution call)', launches=n1, fetch_size_kb_per_launch=fs / n1,
                    write_size_kb_per_launch=ws / n2, hbm_bytes_per_launch=(2 * fs / n1 + ws / n2) * 1024,
                    note='rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 2 '
                         '--warmup 1; gfx950 correction: FETCH_SIZE counts 64 B per 128-B request, so reads are doubled '
                         '(MI355X_MICROARCH.md, HBM section); KB -> bytes x1024')
     json.dump(traffic, open(os.path.join(prof, f'{tag}_pmc_traffic.json'), 'w'), indent=1)
     bench['roofline']['traffic'] = round(traffic['hbm_bytes_per_launch'])
+    if bench['roofline'].get('algorithmic_bytes_per_launch'):
+        bench['roofline']['traffic_ratio'] = round(bench['roofline']['traffic'] / bench['roofline']['algorithmic_bytes_per_launch'], 2)
     json.dump(bench, open(os.path.join(prof, f'{tag}_bench.json'), 'w'))
     total_ms = sum(r[2] for r in rows) / steps / 1e6
     md = [f'# Round {tag[1:]} profile summary (MI355X, 1 GPU)', '',
-          'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline`',
+          'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --engine-set side_stream=False` (`scripts/profile_session.sh`)',
           f'({steps} steps recorded; raw table: `{tag}_bench_kernel_stats.csv`; un-profiled bench line with CPU baseline: `{tag}_bench.json`;',
           f'PMC HBM-traffic passes for the conv kernel family: `{tag}_pmc_traffic.json`; generated by `scripts/make_profile_summary.py`).', '',
           f'Sum of kernel time per step: {total_ms:.2f} ms; bench ms_per_step {bench["ms_per_step"]} (un-profiled): the step is GPU-bound.', '',
@@ -162,8 +166,10 @@ def main():
     wino_ms, direct_ms = fam(('wino_gemm_kernel', 'wino_input_kernel', 'wino_weight_kernel')), fam(('conv_nt_kernel', 'conv_fixup_kernel'))
     md += ['', '## Roofline per kernel class', '',
            f'* MFMA-bound: convolution forward + data gradient (`conv_nt_kernel` direct, `wino_gemm_kernel` Winograd F(2x2,3x3) for the '
-           f'head 3x3 convolutions) -- bench.py HIP events: {r["achieved"]} ALGORITHMIC TFLOP/s of {r["peak"]} '
-           f'(fp32 matrix) = {r["frac"]}; avg call {r["avg_launch_ms"]} ms, {r["algorithmic_gflop_per_launch"]} algorithmic GFLOP/call '
+           f'head 3x3 convolutions) -- bench.py HIP events: {r["achieved"]} TFLOP/s EXECUTED on the matrix cores of {r["peak"]} '
+           f'(fp32 matrix) = {r["frac"]} (Winograd calls priced at their flops / 2.25); the ALGORITHMIC (direct-convolution) rate of the '
+           f'same launches is {r.get("effective_achieved")} TFLOP/s = {r.get("effective_frac")}; avg call {r["avg_launch_ms"]} ms, '
+           f'{r["algorithmic_gflop_per_launch"]} algorithmic GFLOP/call, PMC traffic / algorithmic bytes = {r.get("traffic_ratio")} '
            f'({r["launches_per_step"]} convolution calls/step). rocprofv3 over the same kernels (incl. fix-up and Winograd transforms): '
            f'{nt_calls:.0f} main-kernel launches/step, {nt_ms:.2f} ms/step (avg {nt_ms / nt_calls:.4f} ms): direct {direct_ms:.2f} ms, '
            f'Winograd {wino_ms:.2f} ms. HBM traffic {traffic["hbm_bytes_per_launch"] / 1e6:.0f} MB/call (PMC).',
@@ -174,7 +180,9 @@ def main():
            '* HBM-bound classes (algorithmic bytes / rocprof time, peak 8 TB/s spec):', '',
            '| kernel | algorithmic GB/step | ms/step | achieved TB/s | frac of 8 TB/s | bytes counted |', '|---|---|---|---|---|---|']
     extra = [('adamw_gated_kernel', 37968692 * 4 * 7 / 1e9, 'read p,g,m,v write p,m,v'),
-             ('im2col_stem_kernel', (2 * 3 * 800 * 1333 + 2 * 400 * 667 * 160) * 4 / 1e9, 'read image, write im2col matrix')]
+             ('im2col_stem_kernel', (2 * 3 * 800 * 1333 + 2 * 400 * 667 * 160) * 4 / 1e9, 'read image, write im2col matrix'),
+             ('wino_input_kernel', 0.0, ''), ('wino_dy_kernel', 0.0, '')]
+    extra = [e for e in extra if e[1] > 0]
     md += hbm_table(by, steps, 2, 800, 1333, extra)
     md += mfma_md
     if overlapped:
@@ -183,7 +191,7 @@ def main():
             f.write(open(overlapped).read())
         ototal = sum(r[2] for r in orow) / steps / 1e6
         md += ['', '## The step as it runs: weight gradients on the side stream', '',
-               'The tables above come from a run with `SACV_WGRAD_STREAM=0` (every kernel in stream order, alone on the chip: the '
+               'The tables above come from a run with `--engine-set side_stream=False` (every kernel in stream order, alone on the chip: the '
                "durations `roofline` is computed from; bench.py's instrumented steps run the same way).  In normal steps the weight "
                'gradients, their reductions, the bias-gradient column sums and the shortcut branch of the forward pass run on a second '
                f'HIP stream.  `rocprofv3 --kernel-trace --stats` of such a run (`{tag}_bench_kernel_stats_overlapped.csv`): the kernel '

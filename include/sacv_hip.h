@@ -14,7 +14,7 @@
  *   - return 0 on success, negative on error (-1 bad argument, -2 launch failure,
  *     -3 unsupported); sacv_last_error() returns the message for the calling thread;
  *   - the shared object exports exactly the functions declared here (-fvisibility=hidden + csrc/exports.map;
- *     tests/test_abi.py compares the dynamic symbol table with this file).  sacv_abi_version() == 3.
+ *     tests/test_abi.py compares the dynamic symbol table with this file).  sacv_abi_version() == 4.
  *
  * Where the symbol list of SURVEY.md 8(b) went (it was written before the kernels; arguments are positional scalars
  * and pointers here, not `const sacv_<op>_args*` records -- every call site is a ctypes call, a record would be packed
@@ -58,10 +58,13 @@ int sacv_abi_version(void);
  *   cu_reserve       CUs every persistent grid leaves free (RCCL's channels)
  *   split_policy     remainder tiles of sacv_conv2d_gemm (those left after the last full round of the persistent grid):
  *                    3 = cost model (one workgroup per tile / uniform K split / stream-K), 0 = never split along K
- * A value <= 0 (cu_reserve, split_policy: < 0) keeps the current setting.  Results of a given plan are deterministic
+ *   wino_big         item shape of sacv_wino_gemm with split operands: 1 = cost model (whole rounds of 128 x 128 items,
+ *                    one per CU, then 64 x 64 items for the remaining rows), 0 = 64 x 64 items only, 2 = every whole
+ *                    128-row tile as 128 x 128 items
+ * A value <= 0 (cu_reserve, split_policy, wino_big: < 0) keeps the current setting.  Results of a given plan are deterministic
  * (fixed-order sums); different plans differ by fp32 summation order. */
 int sacv_launch_share(int nt64_wg_per_cu, int nt128_wg_per_cu, int wino_wg_per_cu, int wgrad_wg_per_cu, int cu_reserve,
-                      int split_policy);
+                      int split_policy, int wino_big);
 
 /* ---- convolution (nn.Conv2d: classification/backbones/resnet.py:33-39; detection/models/fpn.py:20-58;
  *      detection/models/head.py:20-33,60-73) -------------------------------------------------------- */
@@ -115,17 +118,23 @@ int sacv_conv2d_gemm_bnbwd(const float* src, float* dst, const float* mask, int 
 /* ---- Winograd F(2x2,3x3) path of the stride-1 3x3 head convolutions (head.py:20-36, 55-70, 103-141: nn.Conv2d
  *      3x3 / pad 1 over the 5 pyramid levels).  Three steps: weights -> U (once per optimizer step), input -> V,
  *      16 chained GEMMs + output transform + the sacv_conv2d_gemm epilogue in one kernel.  2.25x fewer
- *      matrix-core flops than sacv_conv2d_gemm; same results up to fp32 rounding. ----------------------------- */
+ *      matrix-core flops than sacv_conv2d_gemm; same results up to fp32 rounding.
+ *      `split` (0 / 1) selects the operand form of U and V.  0: fp32 [16][rows][pad_k], multiplied on the fp32 matrix
+ *      pipe.  1: three bf16 planes [16][3][rows][pad_k] with x = hi + mid + lo exactly (hi = bf16(x), mid = bf16(x - hi),
+ *      lo = bf16(x - hi - mid)); the GEMM sums the six products of weight >= 2^-16 on the bf16 pipe (16x the fp32
+ *      pipe's rate) into fp32 accumulators -- what it drops is below the rounding of one fp32 addition, the result has
+ *      the fp32 kernel's error against fp64 (tests/test_gpu_winograd.py).  Operand bytes: 6 per element instead of 4.
+ *      U, V and the `split` argument of the GEMM must agree. --------------------------------------------------- */
 /* tiles of 2x2 output pixels over the pyramid: sum_l Nb * ceil(H[l]/2) * ceil(W[l]/2) */
 int sacv_wino_tiles(int nlev, int Nb, const int* H, const int* W /*host arrays*/);
 /* U[16][pad_n(N)][pad_k(K)] = G w G^T from a GEMM panel [N][9][K] (forward panel; data-gradient panel with flip = 1) */
-int sacv_wino_weights(const float* panel, float* U, int N, int K, int flip, void* stream);
+int sacv_wino_weights(const float* panel, void* U, int N, int K, int flip, int split, void* stream);
 /* njobs (<= 32) such transforms in one launch (all Winograd layers of a model, both directions, once per step) */
-int sacv_wino_weights_batched(int njobs, const float* const* panel /*host arrays*/, float* const* U, const int* N,
-                              const int* K, const int* flip, void* stream);
+int sacv_wino_weights_batched(int njobs, const float* const* panel /*host arrays*/, void* const* U, const int* N,
+                              const int* K, const int* flip, int split, void* stream);
 /* V[16][Tpad][pad_k(C)] = B^T d B of every 4x4 input patch; Tpad = tiles rounded up to a multiple of 64 */
 int sacv_wino_input(int nlev, const float* const* src /*host array*/, int Nb, const int* H, const int* W, int C,
-                    float* V, int Tpad, void* stream);
+                    void* V, int Tpad, int split, void* stream);
 int sacv_wino_stats_rows(int tiles);
 /* operand padding of U / V: K (input channels) to a multiple of 32, N (rows of U) to a multiple of 128, zero-filled */
 int sacv_wino_pad_k(int K);
@@ -133,19 +142,20 @@ int sacv_wino_pad_n(int N);
 /* nprob (1 or 2) independent convolutions over the same pyramid geometry (e.g. layer i of both head towers):
  * dst[p*5 + l] = [Nb][H[l]][W[l]][N[p]]; flags[p] = SACV_CF_* bits; mask[p*5 + l] with SACV_CF_MASK;
  * stats[p] = [sacv_wino_stats_rows][2][N[p]] with SACV_CF_STATS */
-int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, const float* const* V /*host array*/,
-                   const float* const* U /*host array*/, const int* Tpad, const int* K, const int* N,
+int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, const void* const* V /*host array*/,
+                   const void* const* U /*host array*/, const int* Tpad, const int* K, const int* N,
                    const float* const* bias /*host array or NULL*/, float* const* dst /*host array [nprob*5]*/,
                    const float* const* mask /*host array [nprob*5] or NULL*/, float* const* stats /*host array or NULL*/,
-                   const int* flags, void* stream);
+                   const int* flags, int split, void* stream);
 
 /* weight gradient on the same path: dw (+)= G^T [ sum_tiles (A dY A^T) (x) V ] G from V = sacv_wino_input(x) kept
  * from the forward pass and dy[l] = [Nb][H[l]][W[l]][Cout]; 16 split-K GEMMs in one launch + a fixed-order reduction
- * (deterministic).  dw_layout as sacv_conv2d_wgrad.  Cin (padded to 32) must be a multiple of 64. */
+ * (deterministic).  dw_layout as sacv_conv2d_wgrad.  Cin (padded to 32) must be a multiple of 64.  v_split = 1: V is
+ * the split form (the kernel rebuilds the fp32 values from the three planes, exactly: same dw bit for bit). */
 long long sacv_wino_wgrad_workspace_bytes(int Tpad, int Cout, int Cin);
 int sacv_wino_wgrad(int nlev, const float* const* dy /*host array*/, int Nb, const int* H, const int* W, int Cout,
-                    const float* V, int Tpad, int Cin, float* dw, int accumulate, int dw_layout, float* workspace,
-                    void* stream);
+                    const void* V, int v_split, int Tpad, int Cin, float* dw, int accumulate, int dw_layout,
+                    float* workspace, void* stream);
 
 /* pixels per split (`chunk`) that fills the weight-gradient queue's workgroup slots for this problem list: npix[i] =
  * Nb * Ho * Wo of segment i, N2 = KH * KW * Cin_pad, taps = KH * KW */

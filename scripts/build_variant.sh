@@ -1,14 +1,13 @@
 #!/bin/bash
-# Tuning build of libsacv_hip.so with extra compiler defines, for same-session A/B runs (SACV_HIP_LIB=...):
-#   bash scripts/build_variant.sh <name> "-DSACV_W64_DGRAD=0.65"   ->  gpurun_variants/libsacv_<name>.so
+# Tuning build of the library with extra compiler flags on ONE source: bash scripts/build_variant.sh NAME file.hip "-DX=1 ..."
+# -> gpurun_variants/libsacv_NAME.so (use with SACV_HIP_LIB=...; the other objects come from the tree's build)
 set -e
-name=$1; defs=$2
-root=$(cd $(dirname $0)/.. && pwd)
-tmp=/tmp/sacv_variant_$name
-rm -rf $tmp && mkdir -p $tmp
-cp -r $root/simpleaicv-pytorch-imagenet-coco-training_amd/csrc $tmp/csrc
-rm -rf $tmp/csrc/build
-make -C $tmp/csrc -j8 CXXFLAGS="--offload-arch=gfx950 -O3 -fPIC -fvisibility=hidden -ffp-contract=off -std=c++17 -Wno-unused-result $defs" LIB=$tmp/libsacv_hip.so > $tmp/build.log 2>&1 || { tail -20 $tmp/build.log; exit 1; }
-mkdir -p $root/gpurun_variants
-cp $tmp/libsacv_hip.so $root/gpurun_variants/libsacv_$name.so
+name=$1; src=$2; flags=$3
+cd "$(dirname "$0")/../simpleaicv-pytorch-imagenet-coco-training_amd/csrc"
+make -s
+mkdir -p build_var ../../gpurun_variants
+obj=build_var/${src%.hip}_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -fvisibility=hidden -ffp-contract=off -std=c++17 -Wno-unused-result $flags -c $src -o $obj
+others=$(ls build/*.o | grep -v "build/${src%.hip}.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=exports.map -o ../../gpurun_variants/libsacv_$name.so $obj $others -ldl
 echo built gpurun_variants/libsacv_$name.so

@@ -16,7 +16,7 @@ P, I, F, LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 SIGNATURES = {
     'sacv_last_error': (C.c_char_p, []),
     'sacv_abi_version': (I, []),
-    'sacv_launch_share': (I, [I, I, I, I, I, I]),
+    'sacv_launch_share': (I, [I, I, I, I, I, I, I]),
     'sacv_conv2d_gemm': (I, [I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P]),
     'sacv_conv2d_gemm_stats_rows': (I, [I, P, P, P]),
     'sacv_conv2d_gemm_bnbwd': (I, [P, P, P, I, I, I, I, I, P, P, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P, P]),
@@ -27,16 +27,16 @@ SIGNATURES = {
     'sacv_colsum_bf16_partial_rows': (I, [I]),
     'sacv_conv2d_gemm_workspace_bytes': (LL, []),
     'sacv_wino_tiles': (I, [I, I, P, P]),
-    'sacv_wino_weights': (I, [P, P, I, I, I, P]),
-    'sacv_wino_weights_batched': (I, [I, P, P, P, P, P, P]),
-    'sacv_wino_input': (I, [I, P, I, P, P, I, P, I, P]),
+    'sacv_wino_weights': (I, [P, P, I, I, I, I, P]),
+    'sacv_wino_weights_batched': (I, [I, P, P, P, P, P, I, P]),
+    'sacv_wino_input': (I, [I, P, I, P, P, I, P, I, I, P]),
     'sacv_wino_stats_rows': (I, [I]),
     'sacv_linear_bf16': (I, [P, P, P, P, P, LL, I, I, I, P]),
     'sacv_wino_pad_k': (I, [I]),
     'sacv_wino_pad_n': (I, [I]),
     'sacv_wino_wgrad_workspace_bytes': (LL, [I, I, I]),
-    'sacv_wino_wgrad': (I, [I, P, I, P, P, I, P, I, I, P, I, I, P, P]),
-    'sacv_wino_gemm': (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    'sacv_wino_wgrad': (I, [I, P, I, P, P, I, P, I, I, I, P, I, I, P, P]),
+    'sacv_wino_gemm': (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, P]),
     'sacv_conv2d_wgrad_chunk': (I, [I, P, I, I, I]),
     'sacv_conv2d_wgrad_workspace_bytes': (LL, [I, P, P, P, I, I, I, I, I]),
     'sacv_conv2d_wgrad': (I, [I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
@@ -155,7 +155,7 @@ def _load():
     return lib
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 lib = _load()
 if lib.sacv_abi_version() != ABI_VERSION:
     raise ImportError(f'{LIB_PATH} has ABI version {lib.sacv_abi_version()}, this package needs {ABI_VERSION}: rebuild it '

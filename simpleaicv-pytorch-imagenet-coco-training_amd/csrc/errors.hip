@@ -12,14 +12,14 @@ void sacv_set_error(const char* fmt, ...) {
 }
 
 SACV_API const char* sacv_last_error(void) { return g_err; }
-SACV_API int sacv_abi_version(void) { return 3; }
+SACV_API int sacv_abi_version(void) { return 4; }
 
-thread_local SacvShare sacv_share = {3, 2, 3, 2, 0, 3};
+thread_local SacvShare sacv_share = {3, 2, 3, 2, 0, 3, 1};
 
 // Launch plan of the calling host thread's subsequent launches (see SacvShare in sacv_common.h); values <= 0 keep the
-// current setting (cu_reserve, split_policy: < 0).  Defaults (a launch alone on the chip): 3, 2, 3, 2, 0, 3.
+// current setting (cu_reserve, split_policy, wino_big: < 0).  Defaults (a launch alone on the chip): 3, 2, 3, 2, 0, 3, 1.
 SACV_API int sacv_launch_share(int nt64_wg_per_cu, int nt128_wg_per_cu, int wino_wg_per_cu, int wgrad_wg_per_cu,
-                               int cu_reserve, int split_policy) {
+                               int cu_reserve, int split_policy, int wino_big) {
   if (nt64_wg_per_cu > 3 || nt128_wg_per_cu > 2 || wino_wg_per_cu > 3 || wgrad_wg_per_cu > 2 || cu_reserve > 192) {
     sacv_set_error("launch_share: out of range (%d %d %d %d %d)", nt64_wg_per_cu, nt128_wg_per_cu, wino_wg_per_cu,
                    wgrad_wg_per_cu, cu_reserve);
@@ -31,5 +31,6 @@ SACV_API int sacv_launch_share(int nt64_wg_per_cu, int nt128_wg_per_cu, int wino
   if (wgrad_wg_per_cu > 0) sacv_share.wgrad_wg_per_cu = wgrad_wg_per_cu;
   if (cu_reserve >= 0) sacv_share.cu_reserve = cu_reserve;
   if (split_policy >= 0) sacv_share.split_policy = split_policy;
+  if (wino_big >= 0) sacv_share.wino_big = wino_big > 2 ? 2 : wino_big;
   return SACV_OK;
 }

@@ -28,6 +28,8 @@ struct SacvShare {
   int wgrad_wg_per_cu;   // wino_wgrad_kernel plan (2 alone); conv_tn's split count is the caller's `chunk`
   int cu_reserve;        // CUs every persistent grid leaves free
   int split_policy;      // remainder tiles of conv_nt: 3 = cost model (uniform K split / stream-K / whole tiles), 0 = whole tiles only
+  int wino_big;          // split-operand wino_gemm: 1 = cost model chooses how many rows go to 128 x 128 items, 0 = 64 x 64
+                         // items only, 2 = every whole 128-row tile to the big items (tests)
 };
 extern thread_local SacvShare sacv_share;
 

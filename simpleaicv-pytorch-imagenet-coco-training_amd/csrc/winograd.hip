@@ -18,6 +18,16 @@
 //                        kernel (conv_gemm.hip vec_epilogue).
 //
 // Deterministic (no atomics, fixed summation order).
+//
+// SPLIT operands (round 4): the fp32 matrix pipe of gfx950 (v_mfma_f32_32x32x2_f32, 157 TFLOP/s) is the bound of the
+// whole step, the bf16 pipe is 16x faster.  The transform kernels can therefore write U and V as THREE bf16 planes,
+// x = hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): the three round-to-nearest terms
+// carry >= 24 significant bits, so the sum reproduces the fp32 value exactly (the weight-gradient kernel rebuilds V
+// that way, bit for bit).  The GEMM then forms a.b from the six products whose weight is >= 2^-16 (hi.hi, hi.mid,
+// mid.hi, mid.mid, hi.lo, lo.hi; the dropped mid.lo / lo.mid / lo.lo are <= 2^-25 |a.b|, below the rounding of ONE
+// fp32 addition) with v_mfma_f32_32x32x16_bf16 into the same fp32 accumulators: 6 x 32 cycles per 16 K instead of
+// 8 x 64.  Measured against fp64 the error of a K = 256 product sum is that of the fp32 pipe (its accumulation
+// rounding, ~2.5e-7 of the mean magnitude; the dropped terms add 6e-9) -- tests/test_gpu_winograd.py.
 #include "sacv_common.h"
 #include <mutex>
 
@@ -43,24 +53,63 @@
 #ifndef WINO_ISSUE_AT
 #define WINO_ISSUE_AT 0  // -1: DMA issue before the MFMA block, 0..3: after that quarter of the MFMA block
 #endif
+#ifndef WINO_SPLIT_SGB
+#define WINO_SPLIT_SGB 1  // split-operand MFMA block: fragment reads interleaved with the products (sched_group_barrier)
+#endif
 #define WINO_MAXL 5  // pyramid levels per problem
 #define WINO_MAXP 2  // problems (e.g. the two towers of a head) per GEMM launch
 
 static __device__ __attribute__((aligned(16))) float wino_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
+typedef __bf16 wbf16;
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+
+// Element (row, col) inside one bf16 plane of the split form.  The GEMM fetches a stage of 32 K per row = 64 bytes per
+// plane, HALF a 128-byte line: with plain row-major planes every line went L2 -> CU twice (two consecutive stages),
+// and the L2 line rate, not the matrix pipe, bounded the kernel (10 TB/s of useful bytes).  So the planes are stored
+// with the 32-column chunks of a ROW PAIR side by side: [rows / 2][cols / 32][2][32] -- one LDS-DMA instruction (16 rows
+// x 64 bytes) then reads 8 whole lines.  rows is even (padded to 64 / 128), cols a multiple of 32.
+__device__ __forceinline__ size_t wino_split_off(int row, int col, int cols) {
+  return ((size_t)(row >> 1) * (cols >> 5) + (col >> 5)) * 64 + ((row & 1) << 5) + (col & 31);
+}
+
+// One transformed value group (4 consecutive channels, col % 4 == 0) of plane g: fp32 [16][rows][cols] row-major, or
+// the three bf16 planes [16][3][rows][cols] of the split form (layout: wino_split_off).  gs = rows * cols.
+template <bool SPLIT>
+__device__ __forceinline__ void wino_put4(void* base, size_t gs, int g, int row, int col, int cols, const f32x4 v) {
+  if constexpr (!SPLIT) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + (size_t)g * gs + (size_t)row * cols + col) = v;
+  } else {
+    const size_t off = wino_split_off(row, col, cols);
+    wbf16x4 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = (wbf16)v[e];
+      const float r1 = v[e] - (float)h[e];  // exact
+      m[e] = (wbf16)r1;
+      l[e] = (wbf16)(r1 - (float)m[e]);  // exact difference, rounded once
+    }
+    wbf16* b = reinterpret_cast<wbf16*>(base) + (size_t)g * 3 * gs + off;
+    *reinterpret_cast<wbf16x4*>(b) = h;
+    *reinterpret_cast<wbf16x4*>(b + gs) = m;
+    *reinterpret_cast<wbf16x4*>(b + 2 * gs) = l;
+  }
+}
+
 // -------------------------------------------------------------------------------------------- weights
-__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ panel, float* __restrict__ U,
-                                                          int N, int K, int Np, int Kp, int flip) {
+template <bool SPLIT>
+__device__ __forceinline__ void wino_weight_body(const float* __restrict__ panel, void* __restrict__ U, int N, int K,
+                                                  int Np, int Kp, int flip) {
   const int k4n = Kp >> 2;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= Np * k4n) return;
   const int n = idx / k4n, k4 = idx - n * k4n;
   const size_t gs = (size_t)Np * Kp;
-  float* o = U + (size_t)n * Kp + k4 * 4;
   if (n >= N || k4 * 4 >= K) {  // zero padding: the GEMM reads whole 128 x 32 operand tiles without masks
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < 16; ++g) *reinterpret_cast<f32x4*>(o + g * gs) = z;
+    for (int g = 0; g < 16; ++g) wino_put4<SPLIT>(U, gs, g, n, k4 * 4, Kp, z);
     return;
   }
   const float* p = panel + (size_t)n * 9 * K + k4 * 4;
@@ -82,11 +131,17 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 0) * gs) = t[i][0];
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 1) * gs) = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 2) * gs) = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 3) * gs) = t[i][2];
+    wino_put4<SPLIT>(U, gs, i * 4 + 0, n, k4 * 4, Kp, t[i][0]);
+    wino_put4<SPLIT>(U, gs, i * 4 + 1, n, k4 * 4, Kp, 0.5f * (t[i][0] + t[i][1] + t[i][2]));
+    wino_put4<SPLIT>(U, gs, i * 4 + 2, n, k4 * 4, Kp, 0.5f * (t[i][0] - t[i][1] + t[i][2]));
+    wino_put4<SPLIT>(U, gs, i * 4 + 3, n, k4 * 4, Kp, t[i][2]);
   }
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ panel, void* __restrict__ U, int N,
+                                                          int K, int Np, int Kp, int flip) {
+  wino_weight_body<SPLIT>(panel, U, N, K, Np, Kp, flip);
 }
 
 // up to 32 weight transforms in one launch (all Winograd layers of a model, forward and data-gradient panels):
@@ -94,49 +149,14 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
 #define WINO_WBATCH 32
 struct WinoWeightJobs {
   const float* panel[WINO_WBATCH];
-  float* U[WINO_WBATCH];
+  void* U[WINO_WBATCH];
   int N[WINO_WBATCH], K[WINO_WBATCH], flip[WINO_WBATCH];
 };
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void wino_weight_batched_kernel(const WinoWeightJobs j) {
   const int job = blockIdx.y;
-  const int N = j.N[job], K = j.K[job], flip = j.flip[job];
-  const int Np = (N + 127) / 128 * 128, Kp = (K + 31) / 32 * 32;
-  const int k4n = Kp >> 2;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= Np * k4n) return;
-  const int n = idx / k4n, k4 = idx - n * k4n;
-  const size_t gs = (size_t)Np * Kp;
-  float* o = j.U[job] + (size_t)n * Kp + k4 * 4;
-  if (n >= N || k4 * 4 >= K) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int g = 0; g < 16; ++g) *reinterpret_cast<f32x4*>(o + g * gs) = z;
-    return;
-  }
-  const float* p = j.panel[job] + (size_t)n * 9 * K + k4 * 4;
-  f32x4 g[3][3];
-#pragma unroll
-  for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int tap = flip ? (2 - kh) * 3 + (2 - kw) : kh * 3 + kw;
-      g[kh][kw] = *reinterpret_cast<const f32x4*>(p + (size_t)tap * K);
-    }
-  f32x4 t[4][3];
-#pragma unroll
-  for (int kw = 0; kw < 3; ++kw) {
-    t[0][kw] = g[0][kw];
-    t[1][kw] = 0.5f * (g[0][kw] + g[1][kw] + g[2][kw]);
-    t[2][kw] = 0.5f * (g[0][kw] - g[1][kw] + g[2][kw]);
-    t[3][kw] = g[2][kw];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 0) * gs) = t[i][0];
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 1) * gs) = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 2) * gs) = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 3) * gs) = t[i][2];
-  }
+  const int N = j.N[job], K = j.K[job];
+  wino_weight_body<SPLIT>(j.panel[job], j.U[job], N, K, (N + 127) / 128 * 128, (K + 31) / 32 * 32, j.flip[job]);
 }
 
 // -------------------------------------------------------------------------------------------- geometry
@@ -177,21 +197,30 @@ __device__ __forceinline__ WinoTile wino_tile(const WinoGeom& g, int t) {
 struct WinoInArgs {
   WinoGeom g;
   const float* src[WINO_MAXL];
-  float* V;
+  void* V;
   int C, Cp, T, Tpad;
 };
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void wino_input_kernel(const WinoInArgs a) {
   const int c4n = a.Cp >> 2;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long long)a.Tpad * c4n) return;
-  const int t = (int)(idx / c4n), c4 = (int)(idx - (long long)t * c4n);
+  int t = (int)(idx / c4n), c4 = (int)(idx - (long long)t * c4n);
+  if constexpr (SPLIT) {
+    // 16 consecutive threads = the 32-channel chunk of a ROW PAIR = one 128-byte line of every plane (wino_split_off):
+    // with a thread row per tile each store instruction wrote 64-byte half lines (+25 % on the transform's time)
+    const int kcn = a.Cp >> 5;
+    const long long unit = idx >> 4;
+    const int within = (int)(idx & 15);
+    t = 2 * (int)(unit / kcn) + (within >> 3);
+    c4 = (int)(unit % kcn) * 8 + (within & 7);
+  }
   const size_t gs = (size_t)a.Tpad * a.Cp;
-  float* o = a.V + (size_t)t * a.Cp + c4 * 4;
   if (t >= a.T || c4 * 4 >= a.C) {  // padding rows / channels of the GEMM's 64 x 32 operand tiles: zeros
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < 16; ++g) *reinterpret_cast<f32x4*>(o + g * gs) = z;
+    for (int g = 0; g < 16; ++g) wino_put4<SPLIT>(a.V, gs, g, t, c4 * 4, a.Cp, z);
     return;
   }
   const WinoTile tl = wino_tile(a.g, t);
@@ -225,17 +254,17 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const WinoInArgs a) {
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 0) * gs) = u[i][0] - u[i][2];
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 1) * gs) = u[i][1] + u[i][2];
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 2) * gs) = u[i][2] - u[i][1];
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 3) * gs) = u[i][1] - u[i][3];
+    wino_put4<SPLIT>(a.V, gs, i * 4 + 0, t, c4 * 4, a.Cp, u[i][0] - u[i][2]);
+    wino_put4<SPLIT>(a.V, gs, i * 4 + 1, t, c4 * 4, a.Cp, u[i][1] + u[i][2]);
+    wino_put4<SPLIT>(a.V, gs, i * 4 + 2, t, c4 * 4, a.Cp, u[i][2] - u[i][1]);
+    wino_put4<SPLIT>(a.V, gs, i * 4 + 3, t, c4 * 4, a.Cp, u[i][1] - u[i][3]);
   }
 }
 
 // one LDS-DMA wave-instruction: 64 lanes x 16 bytes, per-lane global source, lane-linear LDS destination.  The builtin
 // only exists for the gfx950 device pass (the host pass of the same translation unit must not see it).
 typedef __attribute__((address_space(3))) void* lds_t;
-__device__ __forceinline__ void glds16(const float* src, lds_t dst) {
+__device__ __forceinline__ void glds16(const void* src, lds_t dst) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
 #else
@@ -247,14 +276,15 @@ __device__ __forceinline__ void glds16(const float* src, lds_t dst) {
 // -------------------------------------------------------------------------------------------- GEMM + output transform
 struct WinoProb {
   WinoGeom g;
-  const float* V;     // [16][Tpad][K]
-  const float* U;     // [16][N][K]
+  const void* V;      // fp32 [16][Tpad][K], or the split form: bf16 [16][3][Tpad][K]
+  const void* U;      // fp32 [16][Np][K],   or bf16 [16][3][Np][K]
   const float* bias;  // [N] or null
   float* stats;       // [mtiles][2][N] (WCF_STATS)
   float* dst[WINO_MAXL];         // per level [Nb][H][W][N]
   const float* mask[WINO_MAXL];  // per level, same shape as dst (WCF_MASK)
   int T, Tpad, K, N, Np, flags;  // K: padded to 32; Np: rows of U (N padded to 128)
   int item_begin, ntn;
+  int mt0;  // first M tile (of BM rows) this launch computes
 };
 
 struct WinoArgs {
@@ -275,14 +305,20 @@ struct WinoRow {  // per tile row of the current item (LDS)
 // stages with TWO tiles in flight (counted vmcnt + raw s_barrier, cdna_hip_programming.md 5 "Pipelining across
 // barriers").  WN = waves along N: 2 -> 4 waves of 32 x 64 (<= 256 VGPRs, 2 waves per SIMD with two workgroups per
 // CU), 4 -> 8 waves of 32 x 32 (<= 128 VGPRs, 4 waves per SIMD).
-template <int BM, int BN, int WN, int OCC>
-__global__ __launch_bounds__(128 * WN, OCC) void wino_gemm_kernel(const WinoArgs a) {
-  constexpr int NT = 128 * WN;
+//
+// SPLIT: the operands are three bf16 planes each (file header).  A stage still holds 32 K of BM + BN rows, now as
+// 3 planes x 64 B per row (1.5x the bytes); one LDS-DMA instruction fills 16 rows x 64 B of one plane, lane l = (row
+// l >> 2, 16-byte slot l & 3) fetching logical chunk slot ^ key(row) with key(r) = (r >> 2) & 3: a ds_read_b128
+// fragment read (lane = row, one logical chunk per half-wave) then meets, in each of its 16-lane groups, four rows
+// of every residue mod 4 (= the four 64-byte quarters of the 256-byte bank line) with four different keys.  Two
+// v_mfma_f32_32x32x16_bf16 K steps per stage, six products each.
+template <int BM, int BN, int WN, int OCC, bool SPLIT>
+__global__ __launch_bounds__(2 * BM * WN, OCC) void wino_gemm_kernel(const WinoArgs a) {
+  constexpr int NT = 2 * BM * WN;  // BM / 32 waves along M x WN along N
   constexpr int NW = NT / 64;
-  constexpr int STAGE = (BM + BN) * 32;  // floats per stage (rows of 32 floats, no padding)
-  constexpr int WTM = BM / 2, WTN = BN / WN;
-  constexpr int TM = WTM / 32, TN = WTN / 32;
-  static_assert(TM == 1, "one 32-row MFMA block per wave along M");
+  constexpr int STAGE = SPLIT ? (BM + BN) * 48 : (BM + BN) * 32;  // floats per stage (fp32: rows of 32 floats; split: 3 planes of 64-byte rows)
+  constexpr int WTM = 32, WTN = BN / WN;  // one 32-row MFMA block per wave along M
+  constexpr int TN = WTN / 32;
   constexpr int CS = BN + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   WinoRow* rows = reinterpret_cast<WinoRow*>(smem + 3 * STAGE);
@@ -304,7 +340,7 @@ __global__ __launch_bounds__(128 * WN, OCC) void wino_gemm_kernel(const WinoArgs
     const int pi = (a.nprob > 1 && item >= a.p[1].item_begin) ? 1 : 0;
     const WinoProb& P = a.p[pi];
     const int local = item - P.item_begin;
-    const int mt = local / P.ntn, nt = local - mt * P.ntn;
+    const int mt = P.mt0 + local / P.ntn, nt = local % P.ntn;  // this launch covers the M tiles from mt0 on
     const int m0 = mt * BM, n0 = nt * BN;
     const int K = P.K, N = P.N;
     const int KT = K >> 5;  // K is padded to whole tiles
@@ -371,32 +407,68 @@ __global__ __launch_bounds__(128 * WN, OCC) void wino_gemm_kernel(const WinoArgs
     // logical chunk per half-wave: rows of one parity share a 128-byte bank half, and within each group the eight rows
     // of a parity have eight different keys, so the reads are conflict-free without padding.  (key(r) = r & 7 looks
     // right for 8 consecutive lanes but is 2-way conflicting on the real groups: rows 12-15 meet rows 20-23.)
-    constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;  // 8-row pieces per wave and tile
-    constexpr int NG = PA + PB;                        // LDS-DMA instructions per wave and tile
+    constexpr int RPI = SPLIT ? 16 : 8;                    // rows per LDS-DMA instruction
+    constexpr int PA = BM / RPI / NW, PB = BN / RPI / NW;  // row pieces per wave and tile (and plane)
+    constexpr int NG = (SPLIT ? 3 : 1) * (PA + PB);        // LDS-DMA instructions per wave and tile
+    static_assert(PA >= 1 && PB >= 1, "every wave fetches a piece of both operands");
     static_assert(NG == 6 || NG == 4 || NG == 3, "the counted waits below are written for 6, 4 or 3 DMA instructions");
-    const int prow = lane >> 3;
     // element offsets of this lane's 16 bytes inside a (g, kc) operand tile; the operands are zero-padded to whole
     // tiles (sacv_wino_pad_k / _pad_n), so every load is unconditional: scalar base + 32-bit lane offset
     unsigned aoff[PA], wrow[PB];
+    if constexpr (SPLIT) {
+      const int prow = lane >> 2;
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      const int row = (wid * PA + i) * 8 + prow;
-      aoff[i] = (unsigned)((m0 + row) * K + (((lane & 7) ^ ((row >> 1) & 7)) << 2));
-    }
+      for (int i = 0; i < PA; ++i) {
+        const int row = (wid * PA + i) * 16 + prow;
+        aoff[i] = (unsigned)wino_split_off(m0 + row, ((lane & 3) ^ ((row >> 2) & 3)) << 3, K);
+      }
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      const int row = (wid * PB + i) * 8 + prow;
-      wrow[i] = (unsigned)((n0 + row) * K + (((lane & 7) ^ ((row >> 1) & 7)) << 2));
+      for (int i = 0; i < PB; ++i) {
+        const int row = (wid * PB + i) * 16 + prow;
+        wrow[i] = (unsigned)wino_split_off(n0 + row, ((lane & 3) ^ ((row >> 2) & 3)) << 3, K);
+      }
+    } else {
+      const int prow = lane >> 3;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int row = (wid * PA + i) * 8 + prow;
+        aoff[i] = (unsigned)((m0 + row) * K + (((lane & 7) ^ ((row >> 1) & 7)) << 2));
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int row = (wid * PB + i) * 8 + prow;
+        wrow[i] = (unsigned)((n0 + row) * K + (((lane & 7) ^ ((row >> 1) & 7)) << 2));
+      }
     }
+    const wbf16* Vb = reinterpret_cast<const wbf16*>(P.V);
+    const wbf16* Ub = reinterpret_cast<const wbf16*>(P.U);
+    unsigned vgs32 = (unsigned)vgs, ugs32 = (unsigned)ugs;
+    if constexpr (SPLIT) asm volatile("" : "+s"(Vb), "+s"(Ub), "+s"(vgs32), "+s"(ugs32));
     auto issue = [&](int g, int kc, int st) {
-      const int c0 = kc << 5;
-      const float* v = P.V + (size_t)g * vgs + c0;
-      const float* u = P.U + (size_t)g * ugs + c0;
+      const int c0 = SPLIT ? kc << 6 : kc << 5;  // split: the chunks of a row pair lie side by side (wino_split_off)
       float* base = smem + st * STAGE;
+      if constexpr (SPLIT) {
+        // scalar part in 32-bit element offsets (48 Tpad K < 2^32, checked by the host) on bases that live in SGPRs
+        // for the whole item: a kernel-argument reload here is a scalar-memory wait in the middle of the MFMA stream
+        const wbf16* v = Vb + ((unsigned)g * 3u * vgs32 + (unsigned)c0);
+        const wbf16* u = Ub + ((unsigned)g * 3u * ugs32 + (unsigned)c0);
 #pragma unroll
-      for (int i = 0; i < PA; ++i) glds16(v + aoff[i], (lds_t)(base + (wid * PA + i) * 256));
+        for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-      for (int i = 0; i < PB; ++i) glds16(u + wrow[i], (lds_t)(base + BM * 32 + (wid * PB + i) * 256));
+          for (int i = 0; i < PA; ++i)
+            glds16(v + (pl * vgs32 + aoff[i]), (lds_t)(base + pl * BM * 16 + (wid * PA + i) * 256));
+#pragma unroll
+          for (int i = 0; i < PB; ++i)
+            glds16(u + (pl * ugs32 + wrow[i]), (lds_t)(base + 3 * BM * 16 + pl * BN * 16 + (wid * PB + i) * 256));
+        }
+      } else {
+        const float* v = reinterpret_cast<const float*>(P.V) + (size_t)g * vgs + c0;
+        const float* u = reinterpret_cast<const float*>(P.U) + (size_t)g * ugs + c0;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) glds16(v + aoff[i], (lds_t)(base + (wid * PA + i) * 256));
+#pragma unroll
+        for (int i = 0; i < PB; ++i) glds16(u + wrow[i], (lds_t)(base + BM * 32 + (wid * PB + i) * 256));
+      }
     };
     auto wait_one_in_flight = [&]() {  // all but the youngest tile's DMA instructions of this wave have landed
       if (NG == 6)
@@ -420,7 +492,7 @@ __global__ __launch_bounds__(128 * WN, OCC) void wino_gemm_kernel(const WinoArgs
     wait_one_in_flight();
     __builtin_amdgcn_s_barrier();
 #ifdef WINO_STAMP
-    long long st_acc[5] = {0, 0, 0, 0, 0};
+    long long st_acc[6] = {0, 0, 0, 0, 0, 0};
     long long st_t = (long long)__builtin_amdgcn_s_memtime();
 #define WINO_STAMP_AT(k)                                          \
   do {                                                            \
@@ -453,64 +525,123 @@ __global__ __launch_bounds__(128 * WN, OCC) void wino_gemm_kernel(const WinoArgs
         if (more) issue(ng, nk, st2);
 #endif
         WINO_STAMP_AT(0);
-        const float* cA = smem + cur * STAGE + (wm0 + l31) * 32;
-        const float* cB = smem + cur * STAGE + BM * 32 + (wn0 + l31) * 32;
-#if WINO_FRAG2
-        f32x4 fa[2], fb[2][TN];
-        {
-          const int o = (lh ^ x7) * 4;
-          fa[0] = *reinterpret_cast<const f32x4*>(cA + o);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * 32 + o);
-        }
-#else
-        f32x4 fa[1], fb[1][TN];
+        if constexpr (SPLIT) {
+          // rows of 64 B (16 floats) per plane; the lane's row is wm0 / wn0 + l31, its key (l31 >> 2) & 3
+          const float* cA = smem + cur * STAGE + (wm0 + l31) * 16;
+          const float* cB = smem + cur * STAGE + 3 * BM * 16 + (wn0 + l31) * 16;
+          const int k3 = (l31 >> 2) & 3;
+          wbf16x8 fa[2][3], fb[2][TN][3];
+#ifndef WINO_DIAG_NODMA  // (tuning builds: the matrix work on stale LDS contents, no operand traffic)
+          if (more) issue(ng, nk, st2);  // tile q + 2 into the stage that iteration q - 1 read
+#endif
+          // Fragment reads and products in ONE order, plane by plane (hi, mid, lo), so that the reads can trickle in
+          // between the MFMAs instead of all 9 (TN + 1) x 3 x 2 landing before the first one: right after the barrier
+          // every wave of the workgroup wants its fragments at once, and with all reads up front the matrix pipe idled
+          // for the whole burst (in-kernel stamps: 40 % of a wave's time issuing reads, 27 % in the MFMA block).
+          // Products per K step, largest first: hi.hi, mid.hi, hi.mid, mid.mid, lo.hi, hi.lo (x TN).
+#if WINO_PRIO == 1
+          __builtin_amdgcn_s_setprio(1);  // (before the reads: s_setprio is a scheduling boundary)
 #endif
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-#if WINO_FRAG2
-          const int cb = jj & 1, nbuf = cb ^ 1;
-          if (jj < 3) {
-            const int o = (((jj + 1) * 2 + lh) ^ x7) * 4;
-            fa[nbuf] = *reinterpret_cast<const f32x4*>(cA + o);
+          for (int ks = 0; ks < 2; ++ks) {
+            const int o = ((ks * 2 + lh) ^ k3) * 4;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[nbuf][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * 32 + o);
+            for (int pl = 0; pl < 3; ++pl) {
+              fa[ks][pl] = *reinterpret_cast<const wbf16x8*>(cA + pl * BM * 16 + o);
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                fb[ks][j][pl] = *reinterpret_cast<const wbf16x8*>(cB + pl * BN * 16 + j * 32 * 16 + o);
+            }
           }
-#else
-          constexpr int cb = 0;
-          {
-            const int o = ((jj * 2 + lh) ^ x7) * 4;
-            fa[0] = *reinterpret_cast<const f32x4*>(cA + o);
+#ifdef WINO_STAMP
+          WINO_STAMP_AT(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          WINO_STAMP_AT(5);
+#endif
 #pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            constexpr int pa[6] = {0, 1, 0, 1, 2, 0};
+            constexpr int pb[6] = {0, 0, 1, 1, 0, 2};
+#pragma unroll
+#ifdef WINO_DIAG_NOMFMA  // (tuning builds: the data path without the matrix work; one product keeps the reads alive)
+            for (int t6 = 0; t6 < 1; ++t6)
+#else
+            for (int t6 = 0; t6 < 6; ++t6)
+#endif
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][pa[t6]], fb[ks][j][pb[t6]], acc[j], 0, 0, 0);
+          }
+#if !defined(WINO_STAMP) && !defined(WINO_DIAG_NOMFMA) && WINO_SPLIT_SGB
+          // reads in source order: per K step (A, B_0 .. B_TN-1) of hi, then of mid, then of lo.  The first product
+          // needs TN + 1 of them; then one read per MFMA keeps ahead of the products' needs.
+          __builtin_amdgcn_sched_group_barrier(0x100, TN + 2, 0);
+#pragma unroll
+          for (int m = 0; m < 12 * TN; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (m < 6 * (TN + 1) - (TN + 2)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+#endif
+        } else {
+        const float* cA = smem + cur * STAGE + (wm0 + l31) * 32;
+          const float* cB = smem + cur * STAGE + BM * 32 + (wn0 + l31) * 32;
+  #if WINO_FRAG2
+          f32x4 fa[2], fb[2][TN];
+          {
+            const int o = (lh ^ x7) * 4;
+            fa[0] = *reinterpret_cast<const f32x4*>(cA + o);
+  #pragma unroll
             for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * 32 + o);
           }
-#endif
-#if WINO_PRIO == 1
-          __builtin_amdgcn_s_setprio(1);
-#elif WINO_PRIO == 2
-          __builtin_amdgcn_s_setprio(0);
-#endif
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][e], fb[cb][j][e], acc[j], 0, 0, 0);
-#if WINO_ISSUE_AT >= 0
-          if (jj == WINO_ISSUE_AT && more) issue(ng, nk, st2);
-#endif
-#if WINO_SGB
-#pragma unroll
-          for (int m = 0; m < 4 * TN; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // 1 MFMA
-            if (m < 1 + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read (next fragments)
-            if (WINO_SGB > 1) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // address VALU
+  #else
+          f32x4 fa[1], fb[1][TN];
+  #endif
+  #pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+  #if WINO_FRAG2
+            const int cb = jj & 1, nbuf = cb ^ 1;
+            if (jj < 3) {
+              const int o = (((jj + 1) * 2 + lh) ^ x7) * 4;
+              fa[nbuf] = *reinterpret_cast<const f32x4*>(cA + o);
+  #pragma unroll
+              for (int j = 0; j < TN; ++j) fb[nbuf][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * 32 + o);
+            }
+  #else
+            constexpr int cb = 0;
+            {
+              const int o = ((jj * 2 + lh) ^ x7) * 4;
+              fa[0] = *reinterpret_cast<const f32x4*>(cA + o);
+  #pragma unroll
+              for (int j = 0; j < TN; ++j) fb[0][j] = *reinterpret_cast<const f32x4*>(cB + j * 32 * 32 + o);
+            }
+  #endif
+  #if WINO_PRIO == 1
+            __builtin_amdgcn_s_setprio(1);
+  #elif WINO_PRIO == 2
+            __builtin_amdgcn_s_setprio(0);
+  #endif
+  #pragma unroll
+            for (int e = 0; e < 4; ++e)
+  #pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cb][e], fb[cb][j][e], acc[j], 0, 0, 0);
+  #if WINO_ISSUE_AT >= 0
+            if (jj == WINO_ISSUE_AT && more) issue(ng, nk, st2);
+  #endif
+  #if WINO_SGB
+  #pragma unroll
+            for (int m = 0; m < 4 * TN; ++m) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                  // 1 MFMA
+              if (m < 1 + TN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 LDS read (next fragments)
+              if (WINO_SGB > 1) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // address VALU
+            }
+  #endif
+  #if WINO_PIN
+            // keep the scheduler from hoisting all four quarters' fragment reads to the loop top: with the 128 output
+            // accumulators live that spills one of them, and the spill reloads (vmcnt) drain the DMA ring at every fold
+            __builtin_amdgcn_sched_barrier(0);
+  #endif
           }
-#endif
-#if WINO_PIN
-          // keep the scheduler from hoisting all four quarters' fragment reads to the loop top: with the 128 output
-          // accumulators live that spills one of them, and the spill reloads (vmcnt) drain the DMA ring at every fold
-          __builtin_amdgcn_sched_barrier(0);
-#endif
         }
 #if WINO_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
@@ -538,7 +669,7 @@ __global__ __launch_bounds__(128 * WN, OCC) void wino_gemm_kernel(const WinoArgs
 #ifdef WINO_STAMP
     if (lane == 0 && P.stats) {
       long long* o = reinterpret_cast<long long*>(P.stats) + ((size_t)blockIdx.x * NW + wid) * 8;
-      for (int k = 0; k < 5; ++k) o[k] = st_acc[k];
+      for (int k = 0; k < 6; ++k) o[k] = st_acc[k];
     }
 #endif
 
@@ -621,7 +752,12 @@ __global__ __launch_bounds__(128 * WN, OCC) void wino_gemm_kernel(const WinoArgs
         const int which = c / BN, col = c - which * BN;
         float sum = 0.f;
         for (int l = 0; l < RS; ++l) sum += red[(size_t)(which * RS + l) * BN + col];
-        if (n0 + col < N) P.stats[((size_t)mt * 2 + which) * N + n0 + col] = sum;
+        // statistics rows are per 64 tiles (sacv_wino_stats_rows): a 128-row item owns two of them
+        constexpr int SR = BM / 64;
+        if (n0 + col < N) {
+          P.stats[((size_t)mt * SR * 2 + which) * N + n0 + col] = sum;
+          if (SR == 2 && (mt * SR + 1) * 64 < P.T) P.stats[((size_t)(mt * SR + 1) * 2 + which) * N + n0 + col] = 0.f;
+        }
       }
     }
   }
@@ -680,7 +816,7 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const WinoDyArgs a) {
 
 struct WinoWgradArgs {
   const float* dM;  // [16][Tpad][Cout]
-  const float* V;   // [16][Tpad][Kp]
+  const void* V;    // fp32 [16][Tpad][Kp], or the split form bf16 [16][3][Tpad][Kp] (rebuilt exactly: hi + mid + lo)
   float* part;      // [nchunks][Cout][16 * Kp]
   int Tpad, Cout, Kp;
   int nchunks, chunk;  // tile rows per split (multiple of 32)
@@ -690,7 +826,7 @@ struct WinoWgradArgs {
 // LDS, register prefetch of the next tile, interleaved b64 fragment reads; the operands are plain row-major matrices
 // here (no spatial gather).  A workgroup = (Cout tile, (g, Cin) tile, split of the tile rows); Kp % BN == 0, so a
 // tile never straddles two g.
-template <int BM, int BN>
+template <int BM, int BN, bool VSPLIT>
 __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(const WinoWgradArgs a) {
   constexpr int RA = BM / 32, RB = BN / 32;
   constexpr int WTM = BM / 2, WTN = BN / 2;
@@ -712,7 +848,9 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(const WinoWgradArgs 
   const int m0 = tm * BM, n0 = tn * BN;
   const int g = n0 / a.Kp, c0 = n0 - g * a.Kp;
   const float* __restrict__ dm = a.dM + (size_t)g * a.Tpad * a.Cout;
-  const float* __restrict__ v = a.V + (size_t)g * a.Tpad * a.Kp + c0;
+  const size_t vps = (size_t)a.Tpad * a.Kp;  // one plane of V
+  const float* __restrict__ v = reinterpret_cast<const float*>(a.V) + (size_t)g * vps + c0;
+  const wbf16* __restrict__ v3a = reinterpret_cast<const wbf16*>(a.V) + (size_t)g * 3 * vps;
 
   constexpr int CGA = BM / 4, RSA = 256 / CGA;
   constexpr int CGB = BN / 4, RSB = 256 / CGB;
@@ -730,7 +868,15 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(const WinoWgradArgs 
   };
   auto load_b = [&](int i, int p0) {
     const int pix = p0 + rrb + i * RSB;
-    rb[i] = *reinterpret_cast<const f32x4*>(v + (unsigned)(pix * a.Kp + cb * 4));
+    if constexpr (VSPLIT) {
+      const wbf16* q = v3a + wino_split_off(pix, c0 + cb * 4, a.Kp);
+      const wbf16x4 h = *reinterpret_cast<const wbf16x4*>(q), m = *reinterpret_cast<const wbf16x4*>(q + vps),
+                    l = *reinterpret_cast<const wbf16x4*>(q + 2 * vps);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rb[i][e] = ((float)h[e] + (float)m[e]) + (float)l[e];  // both sums are exact
+    } else {
+      rb[i] = *reinterpret_cast<const f32x4*>(v + (unsigned)(pix * a.Kp + cb * 4));
+    }
   };
   auto store_tile = [&](int buf) {
     float* dA = sA + buf * 32 * BM;
@@ -899,8 +1045,13 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
 #ifndef WINO_WN
 #define WINO_WN 2  // waves along N of the GEMM kernel (tuning builds: -DWINO_WN=4: 8 waves of 32 x 32, same speed)
 #endif
-template __global__ void wino_gemm_kernel<64, 128, WINO_WN, WINO_WN>(const WinoArgs);
-template __global__ void wino_gemm_kernel<64, 64, 2, 3>(const WinoArgs);
+template __global__ void wino_gemm_kernel<64, 128, WINO_WN, WINO_WN, false>(const WinoArgs);
+template __global__ void wino_gemm_kernel<64, 64, 2, 3, false>(const WinoArgs);
+#ifndef WINO_SPLIT_OCC
+#define WINO_SPLIT_OCC 2  // workgroups per CU of the split-operand GEMM (74 KB of LDS each)
+#endif
+template __global__ void wino_gemm_kernel<64, 64, 2, WINO_SPLIT_OCC, true>(const WinoArgs);
+template __global__ void wino_gemm_kernel<128, 128, 2, 1, true>(const WinoArgs);
 
 // -------------------------------------------------------------------------------------------- host side
 static int wino_num_cus() {
@@ -914,6 +1065,15 @@ static int wino_num_cus() {
       cus = prop.multiProcessorCount;
   });
   return cus;
+}
+
+// dynamic LDS limit of one kernel instantiation, set once per process
+template <auto Kern>
+static void wino_set_lds(int lds) {
+  static std::once_flag once;
+  std::call_once(once, [lds] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  });
 }
 
 static int wino_fill_geom(WinoGeom& g, int nlev, int Nb, const int* H, const int* W, const char* who) {
@@ -958,21 +1118,25 @@ int sacv_wino_pad_n(int N) { return (N + 127) / 128 * 128; }
 // U[16][pad_n(N)][pad_k(K)] = G w G^T from a GEMM weight panel [N][9][K] (conv_gemm.hip forward panel: N = Cout,
 // K = Cin; data-gradient panel: N = Cin, K = Cout with flip = 1, the 180-degree rotated kernel of the transposed
 // convolution).
-int sacv_wino_weights(const float* panel, float* U, int N, int K, int flip, void* stream) {
+int sacv_wino_weights(const float* panel, void* U, int N, int K, int flip, int split, void* stream) {
   SACV_CHECK_ARG(panel && U, "wino_weights: null pointer");
   SACV_CHECK_ARG(N > 0 && K > 0 && K % 4 == 0, "wino_weights: N=%d K=%d (K must be a multiple of 4)", N, K);
   const int Np = sacv_wino_pad_n(N), Kp = sacv_wino_pad_k(K);
   SACV_CHECK_ARG((long long)Np * Kp * 16 < (1LL << 30), "wino_weights: panel too large");
   const int total = Np * (Kp / 4);
-  hipLaunchKernelGGL(wino_weight_kernel, dim3(sacv_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, panel, U, N, K,
-                     Np, Kp, flip);
+  if (split)
+    hipLaunchKernelGGL(wino_weight_kernel<true>, dim3(sacv_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, panel, U,
+                       N, K, Np, Kp, flip);
+  else
+    hipLaunchKernelGGL(wino_weight_kernel<false>, dim3(sacv_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, panel, U,
+                       N, K, Np, Kp, flip);
   SACV_CHECK_LAUNCH("wino_weight_kernel");
   return SACV_OK;
 }
 
 // njobs (<= 32) weight transforms in one launch: U[i] = transform of panel[i] ([N[i]][9][K[i]], flip[i])
-int sacv_wino_weights_batched(int njobs, const float* const* panel, float* const* U, const int* N, const int* K,
-                              const int* flip, void* stream) {
+int sacv_wino_weights_batched(int njobs, const float* const* panel, void* const* U, const int* N, const int* K,
+                              const int* flip, int split, void* stream) {
   SACV_CHECK_ARG(njobs >= 1 && njobs <= WINO_WBATCH, "wino_weights_batched: njobs=%d (1..%d)", njobs, WINO_WBATCH);
   WinoWeightJobs j;
   int maxblocks = 0;
@@ -989,15 +1153,18 @@ int sacv_wino_weights_batched(int njobs, const float* const* panel, float* const
                    "wino_weights_batched: panel too large");
     if (i < njobs && sacv_cdiv(total, 256) > maxblocks) maxblocks = sacv_cdiv(total, 256);
   }
-  hipLaunchKernelGGL(wino_weight_batched_kernel, dim3(maxblocks, njobs), dim3(256), 0, (hipStream_t)stream, j);
+  if (split)
+    hipLaunchKernelGGL(wino_weight_batched_kernel<true>, dim3(maxblocks, njobs), dim3(256), 0, (hipStream_t)stream, j);
+  else
+    hipLaunchKernelGGL(wino_weight_batched_kernel<false>, dim3(maxblocks, njobs), dim3(256), 0, (hipStream_t)stream, j);
   SACV_CHECK_LAUNCH("wino_weight_batched_kernel");
   return SACV_OK;
 }
 
 // V[16][Tpad][pad_k(C)] = B^T d B of every 4x4 input patch (pad 1) of the NHWC level tensors
 // src[l] = [Nb][H[l]][W[l]][C].  Tpad = tiles rounded up to a multiple of 64 (padding rows / channels are zero-filled).
-int sacv_wino_input(int nlev, const float* const* src, int Nb, const int* H, const int* W, int C, float* V, int Tpad,
-                    void* stream) {
+int sacv_wino_input(int nlev, const float* const* src, int Nb, const int* H, const int* W, int C, void* V, int Tpad,
+                    int split, void* stream) {
   WinoInArgs a;
   int rc = wino_fill_geom(a.g, nlev, Nb, H, W, "wino_input");
   if (rc != SACV_OK) return rc;
@@ -1016,7 +1183,10 @@ int sacv_wino_input(int nlev, const float* const* src, int Nb, const int* H, con
   a.C = C;
   a.Tpad = Tpad;
   const long long total = (long long)Tpad * (a.Cp / 4);
-  hipLaunchKernelGGL(wino_input_kernel, dim3(sacv_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  if (split)
+    hipLaunchKernelGGL(wino_input_kernel<true>, dim3(sacv_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(wino_input_kernel<false>, dim3(sacv_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, a);
   SACV_CHECK_LAUNCH("wino_input_kernel");
   return SACV_OK;
 }
@@ -1028,9 +1198,10 @@ int sacv_wino_stats_rows(int tiles) { return (tiles + 63) / 64; }
 // Problem p: V[p] = [16][Tpad[p]][pad_k(K[p])], U[p] = [16][pad_n(N[p])][pad_k(K[p])], outputs dst[p*5 + l] = [Nb][H[l]][W[l]][N[p]]
 // (the pyramid geometry nlev / Nb / H / W is shared by the problems), optional bias[p], mask[p*5 + l] (WCF_MASK),
 // stats[p] (WCF_STATS, sacv_wino_stats_rows rows).  flags[p]: the CF_* epilogue bits of sacv_conv2d_gemm.
-int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, const float* const* V,
-                   const float* const* U, const int* Tpad, const int* K, const int* N, const float* const* bias,
-                   float* const* dst, const float* const* mask, float* const* stats, const int* flags, void* stream) {
+int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, const void* const* V,
+                   const void* const* U, const int* Tpad, const int* K, const int* N, const float* const* bias,
+                   float* const* dst, const float* const* mask, float* const* stats, const int* flags, int split,
+                   void* stream) {
   SACV_CHECK_ARG(nprob >= 1 && nprob <= WINO_MAXP, "wino_gemm: nprob %d (1..%d)", nprob, WINO_MAXP);
   WinoArgs a;
   int items = 0;
@@ -1067,6 +1238,7 @@ int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, cons
     P.flags = flags[p];
     P.item_begin = 0;
     P.ntn = 0;
+    P.mt0 = 0;
   }
   a.nprob = nprob;
   // Item shape: 64 tiles x 128 channels at 2 workgroups per CU, or x 64 channels at 3 per CU.  The wide item does 13 %
@@ -1091,7 +1263,7 @@ int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, cons
   const double cost_wide = rounds_cost((double)wide / (occ_w * cus), 0.45, 0.64, 1.0);
   double cost_narrow = 0.845 * rounds_cost((double)narrow_items / (occ_n * cus), 0.5, 0.7, 0.85);
   if (cost_narrow < 0.845) cost_narrow = 0.845;
-  const bool narrow = cost_narrow < cost_wide;
+  const bool narrow = split || cost_narrow < cost_wide;  // the split-operand kernel has the 64-channel item only
   const int bn = narrow ? 64 : 128;
   for (int p = 0; p < nprob; ++p) {
     WinoProb& P = a.p[p];
@@ -1101,17 +1273,94 @@ int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, cons
   }
   a.total_items = items;
   hipStream_t st = (hipStream_t)stream;
+#ifndef WINO_BIG_COST
+#define WINO_BIG_COST 1.05  // duration of a round of 128 x 128 items in units of a round of 64 x 64 items (two per CU)
+#endif
+  if (split) {
+    // Two item shapes.  BIG: 128 tiles x 128 channels, 8 waves of 32 x 64, one workgroup per CU (148 KB of LDS) --
+    // half the operand bytes per flop of the small item, which is what bounds this kernel (the L2 -> LDS rate, not
+    // the matrix pipe).  SMALL: 64 x 64, 4 waves, two per CU.  A launch of a few hundred big items on 256 slots has a
+    // poor last round, so the big kernel takes whole rounds of M tiles and the small kernel the rest of the rows.
+    const int T = a.p[0].T;  // the problems of a launch share the pyramid geometry
+    const int mt128 = a.p[0].Tpad / 128;  // whole 128-row tiles of V (Tpad is a multiple of 64 only)
+    int ntn_big = 0, ntn_small = 0;
+    for (int p = 0; p < nprob; ++p) {
+      ntn_big += (a.p[p].N + 127) / 128;
+      ntn_small += (a.p[p].N + 63) / 64;
+    }
+    const int occ_s = occ_n < WINO_SPLIT_OCC ? occ_n : WINO_SPLIT_OCC;
+    auto plan_cost = [&](int mb) {  // mb M tiles of 128 rows to the big kernel; unit: one small item's duration
+      const long long big = (long long)mb * ntn_big;
+      const int rows_left = T - mb * 128;
+      const long long small = rows_left > 0 ? (long long)((rows_left + 63) / 64) * ntn_small : 0;
+      const double rb = (double)((big + cus - 1) / cus), rs = (double)((small + (long long)occ_s * cus - 1) / (occ_s * cus));
+      return rb * WINO_BIG_COST + rs;
+    };
+    int mb = 0;
+    double best = plan_cost(0);
+    for (int r = 1; r <= 64 && mt128 > 0; ++r) {
+      int cand = (int)((long long)r * cus / ntn_big);
+      if (cand > mt128) cand = mt128;
+      const double c = plan_cost(cand);
+      if (c < best - 1e-9) {
+        best = c;
+        mb = cand;
+      }
+      if (cand == mt128) break;
+    }
+    if (sacv_share.wino_big == 0) mb = 0;
+    if (sacv_share.wino_big == 2) mb = mt128;
+    if (mb > 0) {
+      constexpr int BM = 128, BN = 128;
+      items = 0;
+      for (int p = 0; p < nprob; ++p) {
+        WinoProb& P = a.p[p];
+        P.item_begin = items;
+        P.ntn = (P.N + BN - 1) / BN;
+        P.mt0 = 0;
+        items += mb * P.ntn;
+      }
+      a.total_items = items;
+      const int lds = 3 * (BM + BN) * 48 * 4 + BM * (int)sizeof(WinoRow);
+      static_assert(3 * (BM + BN) * 48 >= BM * (BN + 4), "the epilogue stage must fit in the operand buffers");
+      wino_set_lds<wino_gemm_kernel<BM, BN, 2, 1, true>>(lds);
+      int grid = cus;
+      if (grid > items) grid = items;
+      hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, 2, 1, true>), dim3(grid), dim3(512), lds, st, a);
+      SACV_CHECK_LAUNCH("wino_gemm_kernel (split operands, 128 x 128 items)");
+    }
+    if (mb * 128 < T) {
+      constexpr int BM = 64, BN = 64;
+      items = 0;
+      for (int p = 0; p < nprob; ++p) {
+        WinoProb& P = a.p[p];
+        P.item_begin = items;
+        P.ntn = (P.N + BN - 1) / BN;
+        P.mt0 = mb * 2;
+        items += ((P.T + 63) / 64 - mb * 2) * P.ntn;
+      }
+      a.total_items = items;
+      const int lds = 3 * (BM + BN) * 48 * 4 + BM * (int)sizeof(WinoRow);
+      static_assert(3 * (BM + BN) * 48 >= BM * (BN + 4), "the epilogue stage must fit in the operand buffers");
+      wino_set_lds<wino_gemm_kernel<BM, BN, 2, WINO_SPLIT_OCC, true>>(lds);
+      int grid = cus * occ_s;
+      if (grid > items) grid = items;
+      hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, 2, WINO_SPLIT_OCC, true>), dim3(grid), dim3(256), lds, st, a);
+      SACV_CHECK_LAUNCH("wino_gemm_kernel (split operands)");
+    }
+    return SACV_OK;
+  }
   if (narrow) {
     constexpr int BM = 64, BN = 64;
     const int lds = 3 * (BM + BN) * 32 * 4 + BM * (int)sizeof(WinoRow);
     static std::once_flag attr;
     std::call_once(attr, [lds] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel<BM, BN, 2, 3>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel<BM, BN, 2, 3, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     });
     int grid = cus * occ_n;
     if (grid > items) grid = items;
-    hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, 2, 3>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, 2, 3, false>), dim3(grid), dim3(256), lds, st, a);
     SACV_CHECK_LAUNCH("wino_gemm_kernel");
     return SACV_OK;
   }
@@ -1121,12 +1370,12 @@ int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, cons
   static_assert(2 * (BM + BN) * 32 >= BM * (BN + 4), "the epilogue stage must fit in the operand buffers");
   static std::once_flag attr;
   std::call_once(attr, [lds] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel<BM, BN, WN, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_gemm_kernel<BM, BN, WN, WN, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
   int grid = cus * occ_w;
   if (grid > items) grid = items;
-  hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WN, WN>), dim3(grid), dim3(128 * WN), lds, st, a);
+  hipLaunchKernelGGL((wino_gemm_kernel<BM, BN, WN, WN, false>), dim3(grid), dim3(128 * WN), lds, st, a);
   SACV_CHECK_LAUNCH("wino_gemm_kernel");
   return SACV_OK;
 }
@@ -1167,8 +1416,9 @@ long long sacv_wino_wgrad_workspace_bytes(int Tpad, int Cout, int K) {
 // Weight gradient of a 3x3 / stride 1 / pad 1 convolution over a pyramid: dw (+)= sum over levels x (*) dy, from
 // V = sacv_wino_input(x) (kept from the forward pass) and the output gradients dy[l] = [Nb][H[l]][W[l]][Cout].
 // dw_layout 0: OIHW, 1: [Cout][3][3][Cin] (channels_last).  Cin must be a multiple of 64.
-int sacv_wino_wgrad(int nlev, const float* const* dy, int Nb, const int* H, const int* W, int Cout, const float* V,
-                    int Tpad, int Cin, float* dw, int accumulate, int dw_layout, float* workspace, void* stream) {
+int sacv_wino_wgrad(int nlev, const float* const* dy, int Nb, const int* H, const int* W, int Cout, const void* V,
+                    int v_split, int Tpad, int Cin, float* dw, int accumulate, int dw_layout, float* workspace,
+                    void* stream) {
   WinoDyArgs d;
   int rc = wino_fill_geom(d.g, nlev, Nb, H, W, "wino_wgrad");
   if (rc != SACV_OK) return rc;
@@ -1205,23 +1455,25 @@ int sacv_wino_wgrad(int nlev, const float* const* dy, int Nb, const int* H, cons
   a.Cout = Cout;
   a.Kp = Kp;
   const int grid = ((Cout + 127) / 128) * (16 * Kp / BN) * a.nchunks;
+#define WINO_WGRAD_LAUNCH(BN_, SPLIT_, LDS_)                                                             \
+  do {                                                                                                  \
+    wino_set_lds<wino_wgrad_kernel<128, BN_, SPLIT_>>(LDS_);                                            \
+    hipLaunchKernelGGL((wino_wgrad_kernel<128, BN_, SPLIT_>), dim3(grid), dim3(256), LDS_, st, a);      \
+  } while (0)
   if (BN == 128) {
     const int lds = 2 * 32 * (128 + 128) * 4 > 128 * 132 * 4 ? 2 * 32 * (128 + 128) * 4 : 128 * 132 * 4;
-    static std::once_flag once;
-    std::call_once(once, [lds] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel<128, 128>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    });
-    hipLaunchKernelGGL((wino_wgrad_kernel<128, 128>), dim3(grid), dim3(256), lds, st, a);
+    if (v_split)
+      WINO_WGRAD_LAUNCH(128, true, lds);
+    else
+      WINO_WGRAD_LAUNCH(128, false, lds);
   } else {
     const int lds = 2 * 32 * (128 + 64) * 4 > 128 * 68 * 4 ? 2 * 32 * (128 + 64) * 4 : 128 * 68 * 4;
-    static std::once_flag once;
-    std::call_once(once, [lds] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel<128, 64>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    });
-    hipLaunchKernelGGL((wino_wgrad_kernel<128, 64>), dim3(grid), dim3(256), lds, st, a);
+    if (v_split)
+      WINO_WGRAD_LAUNCH(64, true, lds);
+    else
+      WINO_WGRAD_LAUNCH(64, false, lds);
   }
+#undef WINO_WGRAD_LAUNCH
   SACV_CHECK_LAUNCH("wino_wgrad_kernel");
   const int rtotal = Cout * (Cin / 4);
   hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(sacv_cdiv(rtotal, 16)), dim3(256), 0, st, a.part, dw, a.nchunks, Cout,

@@ -687,14 +687,20 @@ class DetectorEngine:
         if u is None:
             co, ci = w.shape[0], w.shape[1]
             if dgrad:
-                u = ops.wino_weights(self._dgrad_panel(w), ci, co, flip=True)
+                u = ops.wino_weights(self._dgrad_panel(w), ci, co, flip=True, split=self.wino_split)
             else:
-                u = ops.wino_weights(ops.fwd_panel(w), co, ci)
+                u = ops.wino_weights(ops.fwd_panel(w), co, ci, split=self.wino_split)
             self._wino_cache[key] = u
         return u
 
     def _use_wino(self):
         return self.winograd and not self.amp
+
+    # Operand form of the Winograd GEMMs (forward and data gradient): False = fp32 operands on the fp32 matrix pipe;
+    # True = every operand as three bf16 planes whose sum IS the fp32 value, six partial products on the bf16 pipe
+    # into fp32 accumulators (csrc/winograd.hip header: what is dropped lies below fp32 rounding).  The weight gradient
+    # rebuilds the kept V from its planes exactly, so it does not change.
+    wino_split = False
 
     def _retina_wino_names(self):
         return ([f'{t}.{i}.weight' for t, _ in self.RETINA_TOWERS for i in (0, 2, 4, 6)] +
@@ -714,7 +720,7 @@ class DetectorEngine:
             if training:
                 jobs.append((self._dgrad_panel(w), ci, co, True))
                 keys.append((w.data_ptr(), True))
-        for key, u in zip(keys, ops.wino_weights_batched(jobs)):
+        for key, u in zip(keys, ops.wino_weights_batched(jobs, split=self.wino_split)):
             self._wino_cache[key] = u
 
     def _heads_fwd(self, feats, ctx):
@@ -772,12 +778,7 @@ class DetectorEngine:
     def _wino_input(self, xs, keep, tag='wino_v0'):
         """Transformed input V of a 3x3 convolution over the levels xs: a fresh tensor when it is kept for the weight
         gradient of the backward pass, a shared scratch buffer otherwise."""
-        if not keep:
-            return ops.wino_input(xs, tag=tag)
-        nb, c = xs[0].shape[0], xs[0].shape[3]
-        _, tpad = ops.wino_tiles(nb, [(x.shape[1], x.shape[2]) for x in xs])
-        return ops.wino_input(xs, out=torch.empty((16, tpad, ops.wino_pad_k(c)), device=xs[0].device,
-                                                  dtype=torch.float32))
+        return ops.wino_input(xs, tag=tag, split=self.wino_split, keep=keep)
 
     def _wino_inputs(self, xs2, keep, shared=False):
         """Transformed inputs of the two towers' next layer (one transform when both read the same levels)."""

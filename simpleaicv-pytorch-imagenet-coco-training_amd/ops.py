@@ -263,22 +263,45 @@ def wino_pad_n(n):
     return -(-n // 128) * 128
 
 
-def wino_weights(panel, n, k, flip=False, out=None):
+def wino_operand_shape(rows, cols, split):
+    """A transformed operand: fp32 [16][rows][cols], or (split) the three bf16 planes [16][3][rows][cols] whose sum is
+    the fp32 value exactly -- the form the GEMM multiplies on the bf16 matrix pipe (csrc/winograd.hip header)."""
+    return ((16, 3, rows, cols), torch.bfloat16) if split else ((16, rows, cols), torch.float32)
+
+
+def wino_is_split(t):
+    return t.dtype == torch.bfloat16
+
+
+def wino_split_rows(t):
+    """A split operand [16][3][rows][cols] as plain row-major planes.  In memory the 32-column chunks of a row pair lie
+    side by side ([rows / 2][cols / 32][2][32], csrc/winograd.hip wino_split_off: the GEMM's 64-byte stage pieces then
+    fill whole 128-byte lines); the tensor keeps the logical shape, this view undoes the interleave."""
+    g, p, rows, cols = t.shape
+    return t.reshape(g, p, rows // 2, cols // 32, 2, 32).permute(0, 1, 2, 4, 3, 5).reshape(g, p, rows, cols)
+
+
+def wino_weights(panel, n, k, flip=False, out=None, split=False):
     """U[16][pad_n(n)][pad_k(k)] = G w G^T of a GEMM panel [n][9][k] (forward panel; the data-gradient panel with
     flip=True); zero-padded to the GEMM's 128 x 32 operand tiles."""
     if panel.numel() != n * 9 * k:
         raise ValueError(f'wino_weights: panel of {panel.numel()} elements is not [{n}][9][{k}]')
-    shape = (16, wino_pad_n(n), wino_pad_k(k))
-    out = out if out is not None else torch.empty(shape, device=panel.device, dtype=torch.float32)
+    if out is not None:
+        split = wino_is_split(out)
+    shape, dt = wino_operand_shape(wino_pad_n(n), wino_pad_k(k), split)
+    out = out if out is not None else torch.empty(shape, device=panel.device, dtype=dt)
     if tuple(out.shape) != shape:
         raise ValueError(f'wino_weights: out is {tuple(out.shape)}, expected {shape}')
-    check(lib.sacv_wino_weights(_ptr(panel), _ptr(out), n, k, int(flip), _stream()), 'wino_weights')
+    check(lib.sacv_wino_weights(_ptr(panel), _ptr(out), n, k, int(flip), int(split), _stream()), 'wino_weights')
     return out
 
 
-def wino_weights_batched(jobs):
+def wino_weights_batched(jobs, split=False):
     """jobs: list of (panel, n, k, flip) -> list of U tensors, transformed by as few launches as possible (32 jobs each)."""
-    outs = [torch.empty((16, wino_pad_n(n), wino_pad_k(k)), device=p.device, dtype=torch.float32) for p, n, k, _ in jobs]
+    outs = []
+    for p, n, k, _ in jobs:
+        shape, dt = wino_operand_shape(wino_pad_n(n), wino_pad_k(k), split)
+        outs.append(torch.empty(shape, device=p.device, dtype=dt))
     for b in range(0, len(jobs), 32):
         chunk, us = jobs[b:b + 32], outs[b:b + 32]
         for p, n, k, _ in chunk:
@@ -286,23 +309,32 @@ def wino_weights_batched(jobs):
                 raise ValueError(f'wino_weights_batched: panel of {p.numel()} elements is not [{n}][9][{k}]')
         check(lib.sacv_wino_weights_batched(len(chunk), parr([_ptr(p) for p, *_ in chunk]), parr([u.data_ptr() for u in us]),
                                             iarr([n for _, n, _, _ in chunk]), iarr([k for _, _, k, _ in chunk]),
-                                            iarr([int(f) for *_, f in chunk]), _stream()), 'wino_weights_batched')
+                                            iarr([int(f) for *_, f in chunk]), int(split), _stream()),
+              'wino_weights_batched')
     return outs
 
 
-def wino_input(srcs, out=None, tag='wino_v'):
-    """V[16][Tpad][pad_k(C)] = B^T d B over all levels (NHWC fp32, one batch size, one channel count)."""
+def wino_input(srcs, out=None, tag='wino_v', split=False, keep=False):
+    """V[16][Tpad][pad_k(C)] = B^T d B over all levels (NHWC fp32, one batch size, one channel count).  keep: V is a
+    tensor of its own (it outlives the call: the weight gradient reads it), not a tagged scratch buffer."""
     nb, c = srcs[0].shape[0], srcs[0].shape[3]
     hw = [(s.shape[1], s.shape[2]) for s in srcs]
     for s in srcs:
         _chk(s, 'wino_input src')
     t, tpad = wino_tiles(nb, hw)
     cp = wino_pad_k(c)
-    if out is None:
-        out = workspace(16 * tpad * cp * 4, srcs[0].device, tag)[:16 * tpad * cp * 4].view(torch.float32)
-        out = out.view(16, tpad, cp)
+    if out is not None:
+        split = wino_is_split(out)
+    shape, dt = wino_operand_shape(tpad, cp, split)
+    if out is None and keep:
+        out = torch.empty(shape, device=srcs[0].device, dtype=dt)
+    elif out is None:
+        nbytes = 16 * tpad * cp * (6 if split else 4)
+        out = workspace(nbytes, srcs[0].device, tag)[:nbytes].view(dt).view(shape)
+    if tuple(out.shape) != shape:
+        raise ValueError(f'wino_input: out is {tuple(out.shape)}, expected {shape}')
     check(lib.sacv_wino_input(len(srcs), parr([s.data_ptr() for s in srcs]), nb, iarr([h for h, _ in hw]),
-                              iarr([w for _, w in hw]), c, _ptr(out), tpad, _stream()), 'wino_input')
+                              iarr([w for _, w in hw]), c, _ptr(out), tpad, int(split), _stream()), 'wino_input')
     return out
 
 
@@ -312,6 +344,7 @@ def conv3x3_wino(srcs_list, us, n_outs, biases=None, flags=None, masks_list=None
     the same pyramid geometry on the Winograd path.  srcs_list[p]: list of NHWC levels; us[p]: wino_weights(...)
     [16][n_outs[p]][C_p]; flags[p]: CF_* epilogue bits.  `mode` only labels the timer record (0 forward, 1 data
     gradient: the caller passes the flipped data-gradient U).  vs[p]: an already transformed input (wino_input).
+    The operand form (fp32 / three bf16 planes) is that of us[0]; every U and V of the launch has it.
     Returns outs_list (and the per-problem CF_STATS buffers when stats=True)."""
     npb = len(srcs_list)
     first = srcs_list[0]
@@ -337,13 +370,16 @@ def conv3x3_wino(srcs_list, us, n_outs, biases=None, flags=None, masks_list=None
         stats_bufs = [torch.empty((rows, 2, n_outs[p]), device=first[0].device, dtype=torch.float32)
                       for p in range(npb)]
     ks = [srcs_list[p][0].shape[3] for p in range(npb)]
+    split = wino_is_split(us[0])
 
     def pad5(lst):
         return list(lst) + [0] * (WINO_MAXL - len(lst))
 
     def launch():
-        v = [vs[p] if vs is not None and vs[p] is not None else wino_input(srcs_list[p], tag=f'wino_v{p}')
+        v = [vs[p] if vs is not None and vs[p] is not None else wino_input(srcs_list[p], tag=f'wino_v{p}', split=split)
              for p in range(npb)]
+        if any(wino_is_split(x) != split for x in v):
+            raise ValueError('conv3x3_wino: U and V differ in operand form (fp32 / split)')
         dst = sum([pad5([o.data_ptr() for o in outs_list[p]]) for p in range(npb)], [])
         msk = None
         if masks_list is not None and any(m is not None for m in masks_list):
@@ -353,19 +389,20 @@ def conv3x3_wino(srcs_list, us, n_outs, biases=None, flags=None, masks_list=None
             npb, nlev, nb, iarr([h for h, _ in hw]), iarr([w for _, w in hw]),
             parr([x.data_ptr() for x in v]), parr([u.data_ptr() for u in us]), iarr([tpad] * npb), iarr(ks),
             iarr(list(n_outs)), parr([_ptr(b) or 0 for b in biases]), parr(dst), parr(msk) if msk else None,
-            parr([s.data_ptr() for s in stats_bufs]) if stats_bufs else None, iarr(flags), _stream()), 'wino_gemm')
+            parr([s.data_ptr() for s in stats_bufs]) if stats_bufs else None, iarr(flags), int(split), _stream()),
+            'wino_gemm')
 
     for p in range(npb):
-        if tuple(us[p].shape) != (16, wino_pad_n(n_outs[p]), wino_pad_k(ks[p])):
-            raise ValueError(f'conv3x3_wino: U[{p}] is {tuple(us[p].shape)}, expected '
-                             f'(16, {wino_pad_n(n_outs[p])}, {wino_pad_k(ks[p])})')
+        want = wino_operand_shape(wino_pad_n(n_outs[p]), wino_pad_k(ks[p]), split)
+        if (tuple(us[p].shape), us[p].dtype) != want:
+            raise ValueError(f'conv3x3_wino: U[{p}] is {tuple(us[p].shape)} {us[p].dtype}, expected {want}')
     if TIMER is not None:
         pix = sum(nb * h * w for h, w in hw)
         fl = sum(2.0 * pix * n_outs[p] * 9 * ks[p] for p in range(npb))
         nbytes = 4.0 * sum(sum(s.numel() for s in srcs_list[p]) + sum(o.numel() for o in outs_list[p]) +
                            us[p].numel() * 9 / 16 for p in range(npb))
-        TIMER.time(f'conv_nt_wino|m{mode} k3 s1 cs{ks[0]} n{"+".join(str(n) for n in n_outs)} np{nlev} pix{pix} '
-                   f'f{flags[0]}', fl, launch, nbytes=nbytes)
+        TIMER.time(f'conv_nt_wino{"3" if split else ""}|m{mode} k3 s1 cs{ks[0]} n{"+".join(str(n) for n in n_outs)} '
+                   f'np{nlev} pix{pix} f{flags[0]}', fl, launch, nbytes=nbytes)
     else:
         launch()
     if stats:
@@ -381,8 +418,10 @@ def wino_wgrad(dys, v, dw, cin, accumulate=False):
     for d in dys:
         _chk(d, 'wino_wgrad dy')
     t, tpad = wino_tiles(nb, hw)
-    if tuple(v.shape) != (16, tpad, wino_pad_k(cin)):
-        raise ValueError(f'wino_wgrad: V is {tuple(v.shape)}, expected (16, {tpad}, {wino_pad_k(cin)})')
+    v_split = wino_is_split(v)
+    if tuple(v.shape) != wino_operand_shape(tpad, wino_pad_k(cin), v_split)[0]:
+        raise ValueError(f'wino_wgrad: V is {tuple(v.shape)}, expected '
+                         f'{wino_operand_shape(tpad, wino_pad_k(cin), v_split)[0]}')
     if tuple(dw.shape) != (cout, cin, 3, 3):
         raise ValueError(f'wino_wgrad: dw is {tuple(dw.shape)}, expected ({cout}, {cin}, 3, 3)')
     layout = weight_layout(dw)
@@ -390,7 +429,8 @@ def wino_wgrad(dys, v, dw, cin, accumulate=False):
 
     def launch():
         check(lib.sacv_wino_wgrad(len(dys), parr([d.data_ptr() for d in dys]), nb, iarr([h for h, _ in hw]),
-                                  iarr([w for _, w in hw]), cout, _ptr(v), tpad, cin, _ptr(dw), int(accumulate), layout,
+                                  iarr([w for _, w in hw]), cout, _ptr(v), int(v_split), tpad, cin, _ptr(dw),
+                                  int(accumulate), layout,
                                   ws.data_ptr(), _stream()), 'wino_wgrad')
 
     if TIMER is not None:
@@ -446,18 +486,19 @@ def _conv_gemm_bf16(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bi
     return outs
 
 
-SHARE_ALONE = (3, 2, 3, 2, 0, 3)
+SHARE_ALONE = (3, 2, 3, 2, 0, 3, 1)
 _share = SHARE_ALONE
 
 
-def launch_share(nt64=0, nt128=0, wino=0, wgrad=0, cu_reserve=-1, split_policy=-1):
+def launch_share(nt64=0, nt128=0, wino=0, wgrad=0, cu_reserve=-1, split_policy=-1, wino_big=-1):
     """Launch plan of the following launches (include/sacv_hip.h: sacv_launch_share): workgroup slots per CU the
     persistent convolution kernels may plan for, CUs they leave free, whether remainder tiles are split along K.
     Returns the previous plan (a tuple that can be passed back as launch_share(*prev))."""
     global _share
     prev = _share
     cur = tuple(n if n > 0 else o for n, o in zip((nt64, nt128, wino, wgrad), prev[:4])) + \
-        (cu_reserve if cu_reserve >= 0 else prev[4], split_policy if split_policy >= 0 else prev[5])
+        (cu_reserve if cu_reserve >= 0 else prev[4], split_policy if split_policy >= 0 else prev[5],
+         wino_big if wino_big >= 0 else prev[6])
     check(lib.sacv_launch_share(*cur), 'launch_share')
     _share = cur
     return prev

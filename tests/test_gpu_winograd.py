@@ -82,9 +82,52 @@ def test_input_transform_matches_Bt_d_B(ops):
     assert float(v[:, t:].abs().max()) == 0.0 if tpad > t else True
 
 
+def planes_sum(t):
+    """fp32 value of a split operand [16][3][rows][cols]: (hi + mid) + lo, each sum exact in fp32."""
+    from sacv_amd import ops as _ops
+    f = _ops.wino_split_rows(t).float()
+    return (f[:, 0] + f[:, 1]) + f[:, 2]
+
+
+def test_split_operands_are_the_fp32_values_in_three_bf16_terms(ops):
+    """split=True writes U and V as three bf16 planes; their sum reproduces the fp32 transform bit for bit (padding
+    included), hi is the bf16 rounding of the value, and each further term is at most 2^-8 of the previous one."""
+    nb, c = 2, 40
+    xs = [nhwc(rnd(10 + l, nb, c, h, w)) for l, (h, w) in enumerate(LEVELS)]
+    v32, v3 = ops.wino_input(xs, tag='t_v32'), ops.wino_input(xs, tag='t_v3', split=True)
+    assert v3.dtype == torch.bfloat16 and v3.shape == (16, 3) + tuple(v32.shape[1:])
+    assert torch.equal(planes_sum(v3), v32)
+    rows3 = ops.wino_split_rows(v3)
+    assert torch.equal(rows3[:, 0], v32.to(torch.bfloat16))
+    assert float((rows3[:, 1].float().abs() - v32.abs() * 2.0 ** -8).max()) <= 0
+    assert float((rows3[:, 2].float().abs() - v32.abs() * 2.0 ** -16).max()) <= 0
+    w = rnd(1, 36, c, 3, 3, std=0.3)
+    for flip, panel, n, k in ((False, w.permute(0, 2, 3, 1).contiguous().cuda(), 36, c),
+                              (True, w.permute(1, 2, 3, 0).contiguous().cuda(), c, 36)):
+        u32, u3 = ops.wino_weights(panel, n, k, flip=flip), ops.wino_weights(panel, n, k, flip=flip, split=True)
+        assert torch.equal(planes_sum(u3), u32)
+        ub = ops.wino_weights_batched([(panel, n, k, flip)] * 2, split=True)
+        assert torch.equal(ub[0], u3) and torch.equal(ub[1], u3)
+
+
+FORMS = ['fp32', 'split', 'split_big']  # split_big: every whole 128-row tile on the 128 x 128 items of the split kernel
+
+
+@pytest.fixture
+def form_plan(ops, request):
+    """(split, launch plan restored afterwards) for a `form` parameter."""
+    form = request.getfixturevalue('form')
+    prev = ops.launch_share(wino_big=2) if form == 'split_big' else None
+    yield form != 'fp32'
+    if prev is not None:
+        ops.launch_share(*prev)
+
+
+@pytest.mark.parametrize('form', FORMS)
 @pytest.mark.parametrize('cin,cout,flag_name', [(64, 64, 'bias_relu'), (40, 36, 'bias'), (256, 144, 'sigmoid'),
                                                 (64, 260, 'none')])
-def test_forward_vs_fp64_and_direct(ops, cin, cout, flag_name):
+def test_forward_vs_fp64_and_direct(ops, cin, cout, flag_name, form, form_plan):
+    split = form_plan
     nb = 2
     xs = [rnd(20 + l, nb, cin, h, w) for l, (h, w) in enumerate(LEVELS)]
     w = rnd(30, cout, cin, 3, 3, std=(2.0 / (9 * cin)) ** 0.5)
@@ -92,7 +135,7 @@ def test_forward_vs_fp64_and_direct(ops, cin, cout, flag_name):
     flags = {'bias_relu': ops.CF_RELU, 'bias': 0, 'sigmoid': ops.CF_SIGMOID, 'none': 0}[flag_name]
     bias = None if flag_name == 'none' else b.cuda()
     panel = w.permute(0, 2, 3, 1).contiguous().cuda()
-    u = ops.wino_weights(panel, cout, cin)
+    u = ops.wino_weights(panel, cout, cin, split=split)
     srcs = [nhwc(x) for x in xs]
     got = ops.conv3x3_wino([srcs], [u], [cout], biases=[bias], flags=[flags])[0]
     direct = ops.conv_gemm(srcs, panel, cout, 3, 3, 1, 1, 0, LEVELS, bias=bias, flags=flags)
@@ -111,9 +154,11 @@ def test_forward_vs_fp64_and_direct(ops, cin, cout, flag_name):
         assert torch.allclose(nchw(g), nchw(d), rtol=2e-5, atol=2e-5 * float(ref64.abs().max()))
 
 
-def test_data_gradient_mask_stats_accum_two_problems(ops):
+@pytest.mark.parametrize('form', FORMS)
+def test_data_gradient_mask_stats_accum_two_problems(ops, form, form_plan):
     """Two problems of different widths in one launch, data-gradient operands (flipped U), ReLU-mask + column sums on
     the first, accumulate on the second -- the epilogues the head towers use (engine._tower_bwd)."""
+    split = form_plan
     nb, cout, cin = 2, 72, 64
     dys_a = [rnd(40 + l, nb, cout, h, w) for l, (h, w) in enumerate(LEVELS)]
     dys_b = [rnd(50 + l, nb, 36, h, w) for l, (h, w) in enumerate(LEVELS)]
@@ -121,8 +166,8 @@ def test_data_gradient_mask_stats_accum_two_problems(ops):
     wb = rnd(61, 36, cin, 3, 3, std=0.05)
     masks = [rnd(70 + l, nb, cin, h, w) for l, (h, w) in enumerate(LEVELS)]
     prev = [rnd(80 + l, nb, cin, h, w) for l, (h, w) in enumerate(LEVELS)]
-    ua = ops.wino_weights(wa.permute(1, 2, 3, 0).contiguous().cuda(), cin, cout, flip=True)
-    ub = ops.wino_weights(wb.permute(1, 2, 3, 0).contiguous().cuda(), cin, 36, flip=True)
+    ua = ops.wino_weights(wa.permute(1, 2, 3, 0).contiguous().cuda(), cin, cout, flip=True, split=split)
+    ub = ops.wino_weights(wb.permute(1, 2, 3, 0).contiguous().cuda(), cin, 36, flip=True, split=split)
     outs_b = [nhwc(p) for p in prev]
     (ga, gb), (sa, sb) = ops.conv3x3_wino([[nhwc(d) for d in dys_a], [nhwc(d) for d in dys_b]], [ua, ub], [cin, cin],
                                           flags=[ops.CF_MASK, ops.CF_ACCUM],
@@ -145,22 +190,33 @@ def test_data_gradient_mask_stats_accum_two_problems(ops):
     assert rel(sb[:, 0, :].double().sum(0).cpu(), tot) < 1e-5
 
 
-def test_head_tower_shape_is_deterministic(ops):
+@pytest.mark.parametrize('split', [False, True], ids=['fp32', 'split'])
+def test_head_tower_shape_is_deterministic(ops, split):
     """The full-size launch of the headline workload (5 levels of 2 x 800x1333, 256 -> 256): two runs are bit-identical
-    and agree with the direct kernel."""
+    and agree with the direct kernel.  With the operands split into bf16 terms the result is as far from the direct
+    fp32 kernel as the fp32 Winograd kernel is (same gate), and the two Winograd forms are closer to each other."""
     nb, c = 2, 256
     hw = [(100, 167), (50, 84), (25, 42), (13, 21), (7, 11)]
     g = torch.Generator(device='cuda').manual_seed(5)
     srcs = [torch.randn((nb, h, w, c), device='cuda', generator=g) for h, w in hw]
     w = torch.randn((c, 3, 3, c), device='cuda', generator=g) * (2.0 / (9 * c)) ** 0.5
     b = torch.randn(c, device='cuda', generator=g) * 0.1
-    u = ops.wino_weights(w, c, c)
+    u = ops.wino_weights(w, c, c, split=split)
     o1 = ops.conv3x3_wino([srcs], [u], [c], biases=[b], flags=[ops.CF_RELU])[0]
     o2 = ops.conv3x3_wino([srcs], [u], [c], biases=[b], flags=[ops.CF_RELU])[0]
     d = ops.conv_gemm(srcs, w, c, 3, 3, 1, 1, 0, hw, bias=b, flags=ops.CF_RELU)
     for a, bb, dd in zip(o1, o2, d):
         assert torch.equal(a, bb)
         assert rel(a, dd) < 3e-6
+    if split:
+        o32 = ops.conv3x3_wino([srcs], [ops.wino_weights(w, c, c)], [c], biases=[b], flags=[ops.CF_RELU])[0]
+        # against fp64 on the largest level: the split form is no further from the exact result than the fp32 pipe
+        x0 = srcs[0].permute(0, 3, 1, 2).double().cpu()
+        ref = F.conv2d(x0, w.permute(0, 3, 1, 2).double().cpu(), b.double().cpu(), padding=1).relu()
+        e3, e32, ed = rel(nchw(o1[0]), ref), rel(nchw(o32[0]), ref), rel(nchw(d[0]), ref)
+        print(f'head tower layer vs fp64: split {e3:.2e}, fp32 Winograd {e32:.2e}, direct {ed:.2e}')
+        assert e3 < 1.25 * e32 + 1e-8, (e3, e32)
+        assert rel(o1[0], o32[0]) < 1e-6
 
 
 @pytest.mark.parametrize('cin,cout,layout', [(64, 64, 'ohwi'), (128, 72, 'oihw'), (64, 260, 'ohwi')])
@@ -181,6 +237,11 @@ def test_weight_gradient_vs_fp64_and_direct(ops, cin, cout, layout):
     if layout == 'ohwi':
         dw = torch.empty((cout, 3, 3, cin), device='cuda').permute(0, 3, 1, 2)
     ops.wino_wgrad(gys, v, dw, cin)
+    # from the split form of V (what the forward pass keeps when the GEMMs run on the bf16 pipe): the kernel rebuilds
+    # the fp32 values exactly, so the gradient is the same bit for bit
+    dw3 = torch.empty_like(dw)
+    ops.wino_wgrad(gys, ops.wino_input(srcs, tag='test_keep3', split=True), dw3, cin)
+    assert torch.equal(dw3, dw)
     direct = torch.empty_like(dw)
     ops.conv_wgrad(gys, srcs, direct, cin, 3, 3, 1, 1)
     e_w, e_d, e_32 = rel(dw.cpu(), ref), rel(direct.cpu(), ref), rel(ref32, ref)
@@ -205,11 +266,12 @@ def test_detector_step_winograd_matches_direct(name, crit):
     torch.manual_seed(0)
     state0 = (omodel.init_retinanet_state(0) if name == 'resnet50_retinanet'
               else {k: v.clone() for k, v in models.__dict__[name](num_classes=80).state_dict().items()})
-    for wino in (True, False):
+    for wino in ('split', True, False):  # 'split': the Winograd GEMMs on the bf16 pipe (operands as three bf16 terms)
         net = models.__dict__[name](num_classes=80)
         net.load_state_dict(state0)
         net = net.cuda().train()
-        net.engine.winograd = wino
+        net.engine.winograd = bool(wino)
+        net.engine.wino_split = wino == 'split'
         net.engine.WINO_MIN_TILES = 1000  # P3 = 68 x 92 here: 3128 tiles, below the production threshold
         criterion = losses.__dict__[crit]()
         preds = net(images)
@@ -220,12 +282,18 @@ def test_detector_step_winograd_matches_direct(name, crit):
         loss.backward()
         torch.cuda.synchronize()
         out[wino] = (float(loss.detach()), {k: g.clone() for k, g in net.arena.grad_views.items()})
-    lw, gw = out[True]
     ld_, gd = out[False]
-    assert abs(lw - ld_) <= 2e-6 * abs(ld_), (lw, ld_)
-    rels = sorted(((rel(gw[k], gd[k]), k) for k in gd if float(gd[k].double().norm()) > 0), reverse=True)
-    worst, median = rels[0], rels[len(rels) // 2][0]
-    print(f'{name}: Winograd vs direct engine, gradient rel-L2 worst {worst[0]:.2e} ({worst[1]}) median {median:.2e}')
+    for form in (True, 'split'):
+        lw, gw = out[form]
+        assert abs(lw - ld_) <= 2e-6 * abs(ld_), (form, lw, ld_)
+        rels = sorted(((rel(gw[k], gd[k]), k) for k in gd if float(gd[k].double().norm()) > 0), reverse=True)
+        worst, median = rels[0], rels[len(rels) // 2][0]
+        print(f'{name}: Winograd ({"split bf16 terms" if form == "split" else "fp32"}) vs direct engine, gradient '
+              f'rel-L2 worst {worst[0]:.2e} ({worst[1]}) median {median:.2e}')
+        check_gates(name, worst, median)
+
+
+def check_gates(name, worst, median):
     # The two engines' tower activations differ by fp32 rounding.  What that becomes in the gradients is NOT a property of
     # either engine (round 4, scripts/diag_wino_fcos2.py, both engines and both stem kernels against the fp64 oracle on
     # three inputs): a ReLU pre-activation within rounding of zero is masked in one backward pass and not in the other,

@@ -45,7 +45,8 @@ extern "C" {
 const char* sacv_last_error(void);
 int sacv_abi_version(void);
 
-/* Launch plan of the calling host thread's subsequent launches.  The convolution kernels are PERSISTENT: a launch is
+/* Launch plan of the process's subsequent launches (one process drives one GPU; the plan is not per thread: a framework
+ * may run the backward pass on another thread than the forward pass).  The convolution kernels are PERSISTENT: a launch is
  * sized to the workgroup slots it expects to own (slots per CU x CUs) and its tiles / stream-K ranges are cut for exactly
  * that many co-resident workgroups.  A caller that runs a second queue beside the launch stream -- the weight gradients on
  * a side HIP stream (the reference gets the same overlap from cuDNN + NCCL kernels co-running, tools/utils.py:178-180),
@@ -61,10 +62,14 @@ int sacv_abi_version(void);
  *   wino_big         item shape of sacv_wino_gemm with split operands: 1 = cost model (whole rounds of 128 x 128 items,
  *                    one per CU, then 64 x 64 items for the remaining rows), 0 = 64 x 64 items only, 2 = every whole
  *                    128-row tile as 128 x 128 items
- * A value <= 0 (cu_reserve, split_policy, wino_big: < 0) keeps the current setting.  Results of a given plan are deterministic
+ *   nt_split         sacv_conv2d_gemm on the bf16 matrix pipe: the gathered fp32 operands are split into three bf16
+ *                    terms (x = hi + mid + lo exactly) when they are stored to LDS and every product is formed from the
+ *                    six partial products of weight >= 2^-16 in fp32 accumulators -- fp32 results (what is dropped is
+ *                    below the rounding of one fp32 addition) at 6 x 32 instead of 8 x 64 matrix-pipe cycles per 16 K
+ * A value <= 0 (cu_reserve, split_policy, wino_big, nt_split: < 0) keeps the current setting.  Results of a given plan are deterministic
  * (fixed-order sums); different plans differ by fp32 summation order. */
 int sacv_launch_share(int nt64_wg_per_cu, int nt128_wg_per_cu, int wino_wg_per_cu, int wgrad_wg_per_cu, int cu_reserve,
-                      int split_policy, int wino_big);
+                      int split_policy, int wino_big, int nt_split);
 
 /* ---- convolution (nn.Conv2d: classification/backbones/resnet.py:33-39; detection/models/fpn.py:20-58;
  *      detection/models/head.py:20-33,60-73) -------------------------------------------------------- */
@@ -151,7 +156,9 @@ int sacv_wino_gemm(int nprob, int nlev, int Nb, const int* H, const int* W, cons
 /* weight gradient on the same path: dw (+)= G^T [ sum_tiles (A dY A^T) (x) V ] G from V = sacv_wino_input(x) kept
  * from the forward pass and dy[l] = [Nb][H[l]][W[l]][Cout]; 16 split-K GEMMs in one launch + a fixed-order reduction
  * (deterministic).  dw_layout as sacv_conv2d_wgrad.  Cin (padded to 32) must be a multiple of 64.  v_split = 1: V is
- * the split form (the kernel rebuilds the fp32 values from the three planes, exactly: same dw bit for bit). */
+ * the split form and the kernel rebuilds the fp32 values from the three planes, exactly: same dw bit for bit as with
+ * v_split = 0.  v_split = 2: V is the split form and the GEMMs run on the bf16 pipe (A dY A^T is split the same way,
+ * six products into fp32 accumulators; Cout % 8 == 0).  The workspace holds either form of the transformed dy. */
 long long sacv_wino_wgrad_workspace_bytes(int Tpad, int Cout, int Cin);
 int sacv_wino_wgrad(int nlev, const float* const* dy /*host array*/, int Nb, const int* H, const int* W, int Cout,
                     const void* V, int v_split, int Tpad, int Cin, float* dw, int accumulate, int dw_layout,

@@ -231,7 +231,20 @@ __device__ __forceinline__ int sk_range_begin(const ConvArgs& a, int KT, int b) 
 // OCC = workgroups per CU the launch bounds allow for; SWZ = unpadded LDS rows (32 floats) with the 16-byte chunks
 // XOR-swizzled by key (row >> 1) & 7 (exact for the lane groups of ds_read_b128, as in winograd.hip) instead of rows
 // padded to 36 floats: the 128 x 64 variant then needs 48 KB and three workgroups fit a CU.
-template <int BM, int BN, int MODE, int WN, int OCC = WN, bool SWZ = false>
+typedef __bf16 cbf16;
+typedef __bf16 cbf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+
+// SP (split operands, round 4): the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, 157 TFLOP/s) bounds this kernel; the
+// bf16 pipe is 16x faster.  With SP the gathered fp32 values are split WHEN THEY ARE STORED TO LDS into three bf16 terms,
+// x = hi + mid + lo exactly (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid): three round-to-nearest terms
+// carry >= 24 significant bits), and a.b is formed from the six products of weight >= 2^-16 (hi.hi, mid.hi, hi.mid,
+// mid.mid, lo.hi, hi.lo) with v_mfma_f32_32x32x16_bf16 into the same fp32 accumulators: 6 x 32 cycles per 16 K instead
+// of 8 x 64.  What is dropped (mid.lo, lo.mid, lo.lo <= 2^-25 |a.b|) lies below the rounding of one fp32 addition;
+// against fp64 the results carry the error of the fp32 pipe (tests/test_gpu_kernels.py, test_gpu_winograd.py for the
+// same scheme in the Winograd GEMM).  Global traffic is unchanged (fp32 tensors), the LDS image is 1.5x the bytes:
+// [2 buffers][3 planes][rows][32 bf16], 16-byte chunks XOR-swizzled by (row >> 2) & 3 for the ds_read_b128 fragments.
+template <int BM, int BN, int MODE, int WN, int OCC = WN, bool SWZ = false, bool SP = false>
 __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a) {
   constexpr int LS = SWZ ? 32 : 36;
   constexpr int NT = 128 * WN;                 // 2 x WN waves
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
   constexpr int TM = WTM / 32, TN = WTN / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;
-  float* sB = smem + 2 * BM * LS;
+  float* sB = smem + (SP ? 2 * 3 * BM * 16 : 2 * BM * LS);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -386,7 +399,31 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
 #pragma unroll
     for (int i = 0; i < RB; ++i) load_b(i);
   };
+  // SP: 4 consecutive K of one row -> three 8-byte stores (planes hi, mid, lo)
+  auto put3 = [&](float* img, int rows, int row, const f32x4 v) {
+    cbf16x4 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = (cbf16)v[e];
+      const float r1 = v[e] - (float)h[e];  // exact
+      m[e] = (cbf16)r1;
+      l[e] = (cbf16)(r1 - (float)m[e]);  // exact difference, rounded once
+    }
+    float* d = img + row * 16 + ((((kq >> 1) ^ ((row >> 2) & 3)) << 2) + ((kq & 1) << 1));
+    *reinterpret_cast<cbf16x4*>(d) = h;
+    *reinterpret_cast<cbf16x4*>(d + rows * 16) = m;
+    *reinterpret_cast<cbf16x4*>(d + 2 * rows * 16) = l;
+  };
   auto store_tile = [&](int buf) {
+    if constexpr (SP) {
+      float* dA = sA + buf * 3 * BM * 16;
+      float* dB = sB + buf * 3 * BN * 16;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) put3(dA, BM, r0 + RPP * i, ra[i]);
+#pragma unroll
+      for (int i = 0; i < RB; ++i) put3(dB, BN, r0 + RPP * i, rb[i]);
+      return;
+    }
     float* dA = sA + buf * BM * LS;
     float* dB = sB + buf * BN * LS;
 #pragma unroll
@@ -444,6 +481,62 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
       const bool have_next = !last || more;
       if (last && more) setup(sidx + 1);  // switch the gather state to the next segment
       load_begin(last ? k_begin : kt + 1, have_next && !SACV_ABL(1024));
+      if constexpr (SP) {
+        const float* pA = sA + cur * 3 * BM * 16 + (wm0 + l31) * 16;
+        const float* pB = sB + cur * 3 * BN * 16 + (wn0 + l31) * 16;
+        const int k3 = (l31 >> 2) & 3;  // swizzle key of this lane's fragment rows (wm0, wn0, i * 32: multiples of 16)
+        cbf16x8 fa[2][3][TM], fb[2][3][TN];
+        // reads and products in one order -- K step, plane (hi, mid, lo), A blocks then B blocks -- so that the reads
+        // trickle in between the MFMAs; products per K step: hi.hi, mid.hi, hi.mid, mid.mid, lo.hi, hi.lo
+        // the next slab's gathers first: the MFMA block of a slab is only 768 cycles per wave, all of it is needed to
+        // cover the loads
+#pragma unroll
+        for (int i = 0; i < RA; ++i) load_a(i);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) load_b(i);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int o = ((ks * 2 + lh) ^ k3) * 4;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+              fa[ks][pl][i] = *reinterpret_cast<const cbf16x8*>(pA + pl * BM * 16 + i * 32 * 16 + o);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              fb[ks][pl][j] = *reinterpret_cast<const cbf16x8*>(pB + pl * BN * 16 + j * 32 * 16 + o);
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          constexpr int pa[6] = {0, 1, 0, 1, 2, 0};
+          constexpr int pb[6] = {0, 0, 1, 1, 0, 2};
+#pragma unroll
+          for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][pa[t6]][i], fb[ks][pb[t6]][j], acc[i][j], 0, 0, 0);
+        }
+#ifndef SACV_NO_SGB
+        {
+          constexpr int NRD = 6 * (TM + TN), NMF = 12 * TM * TN, PRE = TM + TN + 1;
+          __builtin_amdgcn_sched_group_barrier(0x100, PRE, 0);
+#pragma unroll
+          for (int m = 0; m < NMF; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         // 1 MFMA
+            if (m < NRD - PRE) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 LDS read
+          }
+        }
+#endif
+        __builtin_amdgcn_s_setprio(0);
+        if (!last) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        continue;
+      }
       const float* cA = sA + (SACV_ABL(8192) ? 0 : cur * BM * LS + (wm0 + l31) * LS + (SWZ ? 0 : 4 * lh));
       const float* cB = sB + (SACV_ABL(8192) ? 0 : cur * BN * LS + (wn0 + l31) * LS + (SWZ ? 0 : 4 * lh));
       // float offset of the 16-byte chunk (2 * quarter + lh) of this lane's fragment row (wm0, wn0, i * 32: multiples of 16)
@@ -1139,26 +1232,34 @@ static int nt_slots(int bn) {
   return cus * per_cu;
 }
 
-template <int BM, int BN, int MODE, int WN, int OCC = SACV_NT_BLOCKS_PER_CU, bool SWZ = false>
+// the split-operand form of the 128 x 64 kernel: 74 KB of LDS, two workgroups per CU
+static int nt_slots_split() {
+  const int per_cu = sacv_share.nt64_wg_per_cu < 2 ? sacv_share.nt64_wg_per_cu : 2;
+  int cus = num_cus() - sacv_share.cu_reserve;
+  if (cus < 8) cus = 8;
+  return cus * per_cu;
+}
+
+template <int BM, int BN, int MODE, int WN, int OCC = SACV_NT_BLOCKS_PER_CU, bool SWZ = false, bool SP = false>
 static int launch_nt(ConvArgs& a, const NtPlan& plan, float* workspace, hipStream_t st) {
-  int grid = nt_slots(BN);
+  int grid = SP ? nt_slots_split() : nt_slots(BN);
   a.grid = grid;
   a.base = plan.base;
   a.rem_tiles = plan.rem;
   a.sk_blocks = plan.sk_blocks;
   a.partial = workspace;
-  size_t lds = (size_t)2 * (BM + BN) * (SWZ ? 32 : 36) * sizeof(float);
+  size_t lds = SP ? (size_t)2 * 3 * (BM + BN) * 16 * sizeof(float) : (size_t)2 * (BM + BN) * (SWZ ? 32 : 36) * sizeof(float);
   size_t lds_epi = ((size_t)BM * (BN + 4) + 2 * (128 * WN / (BN / 4)) * BN) * sizeof(float);
   if (lds_epi > lds) lds = lds_epi;
   static std::once_flag attr_once;  // one per template instance; lds is a compile-time function of it
   std::call_once(attr_once, [lds] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN, MODE, WN, OCC, SWZ>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN, MODE, WN, OCC, SWZ, SP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   int launch_blocks = a.base > 0 ? grid : a.sk_blocks;
   SACV_CHECK_ARG(a.sk_blocks <= grid && (a.sk_blocks == 0 || a.sk_blocks >= a.rem_tiles),
                  "conv2d_gemm: stream-K plan outside the workspace (%d ranges)", a.sk_blocks);
-  hipLaunchKernelGGL((conv_nt_kernel<BM, BN, MODE, WN, OCC, SWZ>), dim3(launch_blocks), dim3(128 * WN), lds, st, a);
+  hipLaunchKernelGGL((conv_nt_kernel<BM, BN, MODE, WN, OCC, SWZ, SP>), dim3(launch_blocks), dim3(128 * WN), lds, st, a);
   SACV_CHECK_LAUNCH("conv_nt_kernel");
   if (a.sk_blocks > a.rem_tiles) {
     if (a.flags & (CF_STATS | CF_BNBWD))
@@ -1333,6 +1434,11 @@ static int conv2d_gemm_impl(int nprob, const float* const* src, float* const* ds
 #define SACV_W64_DGRAD 0.8  // tuning builds only (scripts/build_variant.sh): relative K-iteration cost in mode 1
 #endif
   NtPlan p64 = plan_nt(tiles * ((N + 63) / 64), KT, nt_slots(64), ws, mode == 1 ? SACV_W64_DGRAD : 0.8);
+  if (sacv_share.nt_split) {
+    NtPlan ps = plan_nt(tiles * ((N + 63) / 64), KT, nt_slots_split(), ws, 1.0);
+    return mode == 0 ? launch_nt<128, 64, 0, 2, 2, true, true>(a, ps, workspace, st)
+                     : launch_nt<128, 64, 1, 2, 2, true, true>(a, ps, workspace, st);
+  }
   const bool use64 = (N <= 64) || (p64.cost < p128.cost);
   if (use64)
     return mode == 0 ? launch_nt<128, 64, 0, 2, 3, true>(a, p64, workspace, st)

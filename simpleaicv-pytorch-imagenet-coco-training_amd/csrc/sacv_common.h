@@ -30,8 +30,9 @@ struct SacvShare {
   int split_policy;      // remainder tiles of conv_nt: 3 = cost model (uniform K split / stream-K / whole tiles), 0 = whole tiles only
   int wino_big;          // split-operand wino_gemm: 1 = cost model chooses how many rows go to 128 x 128 items, 0 = 64 x 64
                          // items only, 2 = every whole 128-row tile to the big items (tests)
+  int nt_split;          // conv_nt: 1 = operands split into three bf16 terms at the LDS store, products on the bf16 pipe
 };
-extern thread_local SacvShare sacv_share;
+extern SacvShare sacv_share;  // process-wide (errors.hip)
 
 #define SACV_CHECK_ARG(cond, ...)          \
   do {                                     \

@@ -769,21 +769,43 @@ __global__ __launch_bounds__(2 * BM * WN, OCC) void wino_gemm_kernel(const WinoA
 struct WinoDyArgs {
   WinoGeom g;
   const float* dy[WINO_MAXL];  // per level [Nb][H][W][N]
-  float* dM;                   // [16][Tpad][N]
+  void* dM;                    // fp32 [16][Tpad][N], or three bf16 planes [16][3][Tpad][N] (plain rows)
   int N, T, Tpad;
 };
 
+// (A dY A^T)[g] of one tile, 4 channels: fp32, or hi / mid / lo bf16 planes (x = hi + mid + lo exactly)
+template <bool SPLIT>
+__device__ __forceinline__ void wino_put_dm(void* base, size_t gs, int g, size_t off, const f32x4 v) {
+  if constexpr (!SPLIT) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + (size_t)g * gs + off) = v;
+  } else {
+    wbf16x4 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = (wbf16)v[e];
+      const float r1 = v[e] - (float)h[e];
+      m[e] = (wbf16)r1;
+      l[e] = (wbf16)(r1 - (float)m[e]);
+    }
+    wbf16* b = reinterpret_cast<wbf16*>(base) + (size_t)g * 3 * gs + off;
+    *reinterpret_cast<wbf16x4*>(b) = h;
+    *reinterpret_cast<wbf16x4*>(b + gs) = m;
+    *reinterpret_cast<wbf16x4*>(b + 2 * gs) = l;
+  }
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void wino_dy_kernel(const WinoDyArgs a) {
   const int c4n = a.N >> 2;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long long)a.Tpad * c4n) return;
   const int t = (int)(idx / c4n), c4 = (int)(idx - (long long)t * c4n);
   const size_t gs = (size_t)a.Tpad * a.N;
-  float* o = a.dM + (size_t)t * a.N + c4 * 4;
+  const size_t off = (size_t)t * a.N + c4 * 4;
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   if (t >= a.T) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) *reinterpret_cast<f32x4*>(o + g * gs) = z;
+    for (int g = 0; g < 16; ++g) wino_put_dm<SPLIT>(a.dM, gs, g, off, z);
     return;
   }
   const WinoTile tl = wino_tile(a.g, t);
@@ -807,15 +829,15 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const WinoDyArgs a) {
   const f32x4 r[4][2] = {{d00, d01}, {d00 + d10, d01 + d11}, {d00 - d10, d01 - d11}, {-d10, -d11}};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 0) * gs) = r[i][0];
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 1) * gs) = r[i][0] + r[i][1];
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 2) * gs) = r[i][0] - r[i][1];
-    *reinterpret_cast<f32x4*>(o + (size_t)(i * 4 + 3) * gs) = -r[i][1];
+    wino_put_dm<SPLIT>(a.dM, gs, i * 4 + 0, off, r[i][0]);
+    wino_put_dm<SPLIT>(a.dM, gs, i * 4 + 1, off, r[i][0] + r[i][1]);
+    wino_put_dm<SPLIT>(a.dM, gs, i * 4 + 2, off, r[i][0] - r[i][1]);
+    wino_put_dm<SPLIT>(a.dM, gs, i * 4 + 3, off, -r[i][1]);
   }
 }
 
 struct WinoWgradArgs {
-  const float* dM;  // [16][Tpad][Cout]
+  const void* dM;   // fp32 [16][Tpad][Cout]; wino_wgrad3_kernel: bf16 [16][3][Tpad][Cout]
   const void* V;    // fp32 [16][Tpad][Kp], or the split form bf16 [16][3][Tpad][Kp] (rebuilt exactly: hi + mid + lo)
   float* part;      // [nchunks][Cout][16 * Kp]
   int Tpad, Cout, Kp;
@@ -847,7 +869,7 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(const WinoWgradArgs 
   const int pix1 = min(pix0 + a.chunk, a.Tpad);
   const int m0 = tm * BM, n0 = tn * BN;
   const int g = n0 / a.Kp, c0 = n0 - g * a.Kp;
-  const float* __restrict__ dm = a.dM + (size_t)g * a.Tpad * a.Cout;
+  const float* __restrict__ dm = reinterpret_cast<const float*>(a.dM) + (size_t)g * a.Tpad * a.Cout;
   const size_t vps = (size_t)a.Tpad * a.Kp;  // one plane of V
   const float* __restrict__ v = reinterpret_cast<const float*>(a.V) + (size_t)g * vps + c0;
   const wbf16* __restrict__ v3a = reinterpret_cast<const wbf16*>(a.V) + (size_t)g * 3 * vps;
@@ -975,6 +997,171 @@ __global__ __launch_bounds__(256, 2) void wino_wgrad_kernel(const WinoWgradArgs 
         const int col = wn0 + (TN == 2 ? 2 * l31 + j : l31);
         stage[row * CS + col] = acc[i][j][r];
       }
+  __syncthreads();
+  float* __restrict__ part = a.part + (size_t)ck * a.Cout * N2;
+  constexpr int CG = BN / 4, RS = 256 / CG;
+  const int c4 = tid % CG, rr = tid / CG;
+  const int n = n0 + c4 * 4;
+#pragma unroll 4
+  for (int row = rr; row < BM; row += RS) {
+    const int m = m0 + row;
+    if (m < a.Cout)
+      *reinterpret_cast<f32x4*>(part + (size_t)m * N2 + n) = *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4);
+  }
+}
+
+// The same split-K GEMMs on the bf16 pipe: dM and V as three bf16 planes each (exact, file header), six products per
+// 16 tiles of K into fp32 accumulators.  The contraction runs over TILES, the slow index of both operands, so the
+// operand images in LDS are [16 tiles][channels] and the fragments come from the transposing LDS read
+// (ds_read_b64_tr_b16, as conv_tn_bf16_kernel of conv_bf16.hip: per 16-lane group a block of 4 tile rows x 16 channels;
+// lane 4q + p addresses row q, channels 4p..4p+3 and receives channel (lane & 15) of rows 0..3).  Rows are padded by
+// 64 bytes: the four rows of a read fall on disjoint banks.  Tiles of 16 K double-buffered in LDS (61 KB for the
+// 128 x 128 item, two workgroups per CU), the next tile's 6 x 16 bytes per thread prefetched into registers.
+typedef short ws16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int wu32x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void wino_wgrad3_kernel(const WinoWgradArgs a) {
+  constexpr int RSA = BM * 2 + 64, RSB = BN * 2 + 64;  // row strides in bytes
+  constexpr int CGA = BM / 8, CGB = BN / 8;            // 16-byte chunks per tile row
+  constexpr int LA = (3 * 16 * CGA + 255) / 256, LB = (3 * 16 * CGB + 255) / 256;  // loads per thread and K tile
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int IMG_A = 3 * 16 * RSA, IMG_B = 3 * 16 * RSB;  // bytes of one buffer: [3 planes][16 rows][RS]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  unsigned char* sA = smem3;              // [2][IMG_A]
+  unsigned char* sB = smem3 + 2 * IMG_A;  // [2][IMG_B]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int N2 = 16 * a.Kp;
+  const int ntm = (a.Cout + BM - 1) / BM;
+  const int ntn = N2 / BN;
+  int bid = blockIdx.x;
+  const int tm = bid % ntm;
+  bid /= ntm;
+  const int tn = bid % ntn;
+  const int ck = bid / ntn;
+  const int pix0 = ck * a.chunk;
+  const int pix1 = min(pix0 + a.chunk, a.Tpad);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int g = n0 / a.Kp, c0 = n0 - g * a.Kp;
+  const size_t dps = (size_t)a.Tpad * a.Cout, vps = (size_t)a.Tpad * a.Kp;  // one plane
+  const wbf16* __restrict__ dm = reinterpret_cast<const wbf16*>(a.dM) + (size_t)g * 3 * dps;
+  const wbf16* __restrict__ v3 = reinterpret_cast<const wbf16*>(a.V) + (size_t)g * 3 * vps;
+
+  // this thread's chunks of a K tile: (plane, row, 16-byte chunk) of A (dM, plain rows) and B (V, wino_split_off)
+  int a_pl[LA], a_row[LA], a_col[LA], b_pl[LB], b_row[LB], b_col[LB];
+  bool a_ok[LA], b_ok[LB];
+#pragma unroll
+  for (int i = 0; i < LA; ++i) {
+    const int idx = tid + i * 256;
+    a_pl[i] = idx / (16 * CGA);
+    const int rem = idx - a_pl[i] * 16 * CGA;
+    a_row[i] = rem / CGA;
+    a_col[i] = (rem - a_row[i] * CGA) * 8;
+    a_ok[i] = idx < 3 * 16 * CGA && m0 + a_col[i] < a.Cout;  // Cout % 8 == 0
+  }
+#pragma unroll
+  for (int i = 0; i < LB; ++i) {
+    const int idx = tid + i * 256;
+    b_pl[i] = idx / (16 * CGB);
+    const int rem = idx - b_pl[i] * 16 * CGB;
+    b_row[i] = rem / CGB;
+    b_col[i] = (rem - b_row[i] * CGB) * 8;
+    b_ok[i] = idx < 3 * 16 * CGB;
+  }
+  wu32x4 ra[LA], rb[LB];
+  auto load_tile = [&](int p0) {
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+      const void* ptr = a_ok[i] ? (const void*)(dm + a_pl[i] * dps + (size_t)(p0 + a_row[i]) * a.Cout + m0 + a_col[i])
+                                : (const void*)wino_zero16;
+      ra[i] = *reinterpret_cast<const wu32x4*>(ptr);
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+      const void* ptr = b_ok[i] ? (const void*)(v3 + b_pl[i] * vps + wino_split_off(p0 + b_row[i], c0 + b_col[i], a.Kp))
+                                : (const void*)wino_zero16;
+      rb[i] = *reinterpret_cast<const wu32x4*>(ptr);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LA; ++i)
+      if (3 * 16 * CGA % 256 == 0 || tid + i * 256 < 3 * 16 * CGA)
+        *reinterpret_cast<wu32x4*>(sA + buf * IMG_A + (a_pl[i] * 16 + a_row[i]) * RSA + a_col[i] * 2) = ra[i];
+#pragma unroll
+    for (int i = 0; i < LB; ++i)
+      if (3 * 16 * CGB % 256 == 0 || tid + i * 256 < 3 * 16 * CGB)
+        *reinterpret_cast<wu32x4*>(sB + buf * IMG_B + (b_pl[i] * 16 + b_row[i]) * RSB + b_col[i] * 2) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int tr_row = 8 * (tg >> 1) + tq;      // + 4 for the second read
+  const int tr_col = 16 * (tg & 1) + 4 * tp;  // channel inside the 32-wide MFMA block
+
+  const int KT = (pix1 - pix0) >> 4;  // chunk and Tpad are multiples of 32
+  if (KT > 0) {
+    load_tile(pix0);
+    store_tile(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool last = kt + 1 == KT;
+    if (!last) load_tile(pix0 + ((kt + 1) << 4));
+    const unsigned char* cA = sA + cur * IMG_A + tr_row * RSA + (wm0 + tr_col) * 2;
+    const unsigned char* cB = sB + cur * IMG_B + tr_row * RSB + (wn0 + tr_col) * 2;
+    wbf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const unsigned char* pA = cA + pl * 16 * RSA + i * 64;
+        union { ws16x4 s[2]; wbf16x8 v; } u;
+        u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4*)(pA));
+        u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4*)(pA + 4 * RSA));
+        fa[pl][i] = u.v;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const unsigned char* pB = cB + pl * 16 * RSB + j * 64;
+        union { ws16x4 s[2]; wbf16x8 v; } u;
+        u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4*)(pB));
+        u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ws16x4*)(pB + 4 * RSB));
+        fb[pl][j] = u.v;
+      }
+    }
+    constexpr int pa[6] = {0, 1, 0, 1, 2, 0};
+    constexpr int pb[6] = {0, 0, 1, 1, 0, 2};
+#pragma unroll
+    for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa[t6]][i], fb[pb[t6]][j], acc[i][j], 0, 0, 0);
+    if (!last) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  constexpr int CS = BN + 4;
+  float* stage = reinterpret_cast<float*>(smem3);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CS + wn0 + j * 32 + l31] = acc[i][j][r];
   __syncthreads();
   float* __restrict__ part = a.part + (size_t)ck * a.Cout * N2;
   constexpr int CG = BN / 4, RS = 256 / CG;
@@ -1410,7 +1597,8 @@ long long sacv_wino_wgrad_workspace_bytes(int Tpad, int Cout, int K) {
   const int Kp = sacv_wino_pad_k(K);
   int BN, chunk;
   const int n = wino_wgrad_plan(Tpad, Cout, Kp, &BN, &chunk);
-  return 4LL * ((long long)16 * Tpad * Cout + (long long)n * Cout * 16 * Kp);
+  // dM: fp32 [16][Tpad][Cout] or three bf16 planes (6 bytes per element: sized for those), then the fp32 slabs
+  return 6LL * 16 * Tpad * Cout + 4LL * n * Cout * 16 * Kp;
 }
 
 // Weight gradient of a 3x3 / stride 1 / pad 1 convolution over a pyramid: dw (+)= sum over levels x (*) dy, from
@@ -1438,11 +1626,17 @@ int sacv_wino_wgrad(int nlev, const float* const* dy, int Nb, const int* H, cons
     SACV_CHECK_ARG(l >= nlev || (long long)Nb * H[l] * W[l] * Cout < (1LL << 30), "wino_wgrad: level too large");
   }
   hipStream_t st = (hipStream_t)stream;
+  SACV_CHECK_ARG(v_split >= 0 && v_split <= 2, "wino_wgrad: v_split=%d (0 fp32 V, 1 split V / fp32 pipe, 2 bf16 pipe)", v_split);
+  const bool pipe16 = v_split == 2;
+  SACV_CHECK_ARG(!pipe16 || Cout % 8 == 0, "wino_wgrad: the bf16-pipe form needs Cout %% 8 == 0 (Cout=%d)", Cout);
   d.dM = workspace;
   d.N = Cout;
   d.Tpad = Tpad;
   const long long total = (long long)Tpad * (Cout / 4);
-  hipLaunchKernelGGL(wino_dy_kernel, dim3(sacv_cdiv(total, 256)), dim3(256), 0, st, d);
+  if (pipe16)
+    hipLaunchKernelGGL(wino_dy_kernel<true>, dim3(sacv_cdiv(total, 256)), dim3(256), 0, st, d);
+  else
+    hipLaunchKernelGGL(wino_dy_kernel<false>, dim3(sacv_cdiv(total, 256)), dim3(256), 0, st, d);
   SACV_CHECK_LAUNCH("wino_dy_kernel");
 
   WinoWgradArgs a;
@@ -1450,7 +1644,7 @@ int sacv_wino_wgrad(int nlev, const float* const* dy, int Nb, const int* H, cons
   a.nchunks = wino_wgrad_plan(Tpad, Cout, Kp, &BN, &a.chunk);
   a.dM = workspace;
   a.V = V;
-  a.part = workspace + (size_t)16 * Tpad * Cout;
+  a.part = workspace + ((size_t)16 * Tpad * Cout * 3 + 1) / 2;  // behind dM in either form (6 bytes per element)
   a.Tpad = Tpad;
   a.Cout = Cout;
   a.Kp = Kp;
@@ -1460,7 +1654,19 @@ int sacv_wino_wgrad(int nlev, const float* const* dy, int Nb, const int* H, cons
     wino_set_lds<wino_wgrad_kernel<128, BN_, SPLIT_>>(LDS_);                                            \
     hipLaunchKernelGGL((wino_wgrad_kernel<128, BN_, SPLIT_>), dim3(grid), dim3(256), LDS_, st, a);      \
   } while (0)
-  if (BN == 128) {
+  if (pipe16) {
+    if (BN == 128) {
+      const int img = 2 * 3 * 16 * ((128 * 2 + 64) + (128 * 2 + 64));
+      const int lds = img > 128 * 132 * 4 ? img : 128 * 132 * 4;
+      wino_set_lds<wino_wgrad3_kernel<128, 128>>(lds);
+      hipLaunchKernelGGL((wino_wgrad3_kernel<128, 128>), dim3(grid), dim3(256), lds, st, a);
+    } else {
+      const int img = 2 * 3 * 16 * ((128 * 2 + 64) + (64 * 2 + 64));
+      const int lds = img > 128 * 68 * 4 ? img : 128 * 68 * 4;
+      wino_set_lds<wino_wgrad3_kernel<128, 64>>(lds);
+      hipLaunchKernelGGL((wino_wgrad3_kernel<128, 64>), dim3(grid), dim3(256), lds, st, a);
+    }
+  } else if (BN == 128) {
     const int lds = 2 * 32 * (128 + 128) * 4 > 128 * 132 * 4 ? 2 * 32 * (128 + 128) * 4 : 128 * 132 * 4;
     if (v_split)
       WINO_WGRAD_LAUNCH(128, true, lds);

@@ -418,7 +418,7 @@ class DetectorEngine:
         if (self.wino_trunk_wgrad and self._use_wino() and c.k == 3 and c.stride == 1 and c.pad == 1 and cin >= 128
                 and ops.wino_wgrad_supported(cin) and dy.shape[3] >= 128):
             def launch():
-                ops.wino_wgrad([dy], ops.wino_input([c.x], tag='wino_vx'), dw, cin)
+                ops.wino_wgrad([dy], ops.wino_input([c.x], tag='wino_vx', split=self.wino_split), dw, cin)
             return self._on_side(launch, [dy, c.x])
         self._wgrad([dy], [c.x], dw, cin, c.k, c.k, c.stride, c.pad)
 
@@ -470,6 +470,7 @@ class DetectorEngine:
     def forward(self, images, training=True, keep=True):
         """images: logical [B,3,H,W] fp32 (any strides).  Returns (cls_levels, reg_levels)."""
         ctx = {} if keep else None
+        self._apply_plan()
         self._wino_cache = {}  # Winograd-domain weights are per forward (the optimizer step changes the weights)
         self._shadow_refresh()
         self._wino_prepared = False
@@ -700,7 +701,16 @@ class DetectorEngine:
     # True = every operand as three bf16 planes whose sum IS the fp32 value, six partial products on the bf16 pipe
     # into fp32 accumulators (csrc/winograd.hip header: what is dropped lies below fp32 rounding).  The weight gradient
     # rebuilds the kept V from its planes exactly, so it does not change.
-    wino_split = False
+    _wino_prepared = False  # forward() prepared this pass's Winograd-domain weights on the side stream
+    wino_split = True
+    # The same operand form for the direct convolutions (sacv_conv2d_gemm: the split happens when the gathered fp32
+    # values are stored to LDS, nothing changes in memory).  It is part of the calling thread's launch plan
+    # (ops.launch_share(nt_split=...)); forward() / backward() set it from this attribute.
+    conv_split = True
+
+    def _apply_plan(self):
+        if not self.amp and ops.current_share()[7] != int(self.conv_split):
+            ops.launch_share(nt_split=int(self.conv_split))
 
     def _retina_wino_names(self):
         return ([f'{t}.{i}.weight' for t, _ in self.RETINA_TOWERS for i in (0, 2, 4, 6)] +
@@ -1073,6 +1083,7 @@ class DetectorEngine:
         if ctx is None:
             raise RuntimeError('backward() without a preceding forward(keep=True)')
         self._side_join()  # the forward pass's side-stream work (data-gradient panels) is complete
+        self._apply_plan()
         prev_share = self._share_begin()
         try:
             self._backward(dcls_levels, dreg_levels, dctr_levels, grad_scale, on_stage)
@@ -1231,6 +1242,7 @@ class ClassifierEngine(DetectorEngine):
     def forward(self, images, training=True, keep=True):
         """images logical [B,3,H,W] -> logits [B, num_classes]"""
         ctx = {} if keep else None
+        self._apply_plan()
         self._wino_cache = {}  # Winograd-domain weights are per forward (see DetectorEngine.forward)
         if keep:
             self._refresh_dgrad_panels()
@@ -1276,6 +1288,7 @@ class ClassifierEngine(DetectorEngine):
         if ctx is None:
             raise RuntimeError('backward() without a preceding forward(keep=True)')
         self._side_join()
+        self._apply_plan()
         w = ctx['fc_w']
         nout, nin = self.p['fc.weight'].shape
         npad = w.shape[0]

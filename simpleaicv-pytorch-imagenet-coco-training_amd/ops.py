@@ -410,15 +410,19 @@ def conv3x3_wino(srcs_list, us, n_outs, biases=None, flags=None, masks_list=None
     return outs_list
 
 
-def wino_wgrad(dys, v, dw, cin, accumulate=False):
+def wino_wgrad(dys, v, dw, cin, accumulate=False, exact=False):
     """dw (logical OIHW view, stored OIHW or channels_last) (+)= x (*) dy of a 3x3 / stride 1 / pad 1 convolution over
-    the pyramid, from v = wino_input(x) of the forward pass and the per-level output gradients dys."""
+    the pyramid, from v = wino_input(x) of the forward pass and the per-level output gradients dys.  A split V (three
+    bf16 planes) sends the GEMMs to the bf16 matrix pipe (the transformed dy is split the same way; six products,
+    fp32 accumulators); exact=True rebuilds the fp32 V from its planes and runs the fp32 pipe instead -- the same
+    bits as with an fp32 V."""
     nb, cout = dys[0].shape[0], dys[0].shape[3]
     hw = [(d.shape[1], d.shape[2]) for d in dys]
     for d in dys:
         _chk(d, 'wino_wgrad dy')
     t, tpad = wino_tiles(nb, hw)
     v_split = wino_is_split(v)
+    form = 0 if not v_split else (1 if exact or cout % 8 else 2)
     if tuple(v.shape) != wino_operand_shape(tpad, wino_pad_k(cin), v_split)[0]:
         raise ValueError(f'wino_wgrad: V is {tuple(v.shape)}, expected '
                          f'{wino_operand_shape(tpad, wino_pad_k(cin), v_split)[0]}')
@@ -429,13 +433,14 @@ def wino_wgrad(dys, v, dw, cin, accumulate=False):
 
     def launch():
         check(lib.sacv_wino_wgrad(len(dys), parr([d.data_ptr() for d in dys]), nb, iarr([h for h, _ in hw]),
-                                  iarr([w for _, w in hw]), cout, _ptr(v), int(v_split), tpad, cin, _ptr(dw),
+                                  iarr([w for _, w in hw]), cout, _ptr(v), form, tpad, cin, _ptr(dw),
                                   int(accumulate), layout,
                                   ws.data_ptr(), _stream()), 'wino_wgrad')
 
     if TIMER is not None:
         pix = sum(nb * h * w for h, w in hw)
-        TIMER.time(f'conv_tn_wino|k3 s1 ci{cin} co{cout} np{len(dys)}', 2.0 * pix * cout * 9 * cin, launch)
+        TIMER.time(f'conv_tn_wino{"3" if form == 2 else ""}|k3 s1 ci{cin} co{cout} np{len(dys)}',
+                   2.0 * pix * cout * 9 * cin, launch)
     else:
         launch()
     return dw
@@ -486,11 +491,16 @@ def _conv_gemm_bf16(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bi
     return outs
 
 
-SHARE_ALONE = (3, 2, 3, 2, 0, 3, 1)
+SHARE_ALONE = (3, 2, 3, 2, 0, 3, 1, 0)
 _share = SHARE_ALONE
 
 
-def launch_share(nt64=0, nt128=0, wino=0, wgrad=0, cu_reserve=-1, split_policy=-1, wino_big=-1):
+def current_share():
+    """The launch plan in force (the tuple launch_share returns / accepts)."""
+    return _share
+
+
+def launch_share(nt64=0, nt128=0, wino=0, wgrad=0, cu_reserve=-1, split_policy=-1, wino_big=-1, nt_split=-1):
     """Launch plan of the following launches (include/sacv_hip.h: sacv_launch_share): workgroup slots per CU the
     persistent convolution kernels may plan for, CUs they leave free, whether remainder tiles are split along K.
     Returns the previous plan (a tuple that can be passed back as launch_share(*prev))."""
@@ -498,7 +508,7 @@ def launch_share(nt64=0, nt128=0, wino=0, wgrad=0, cu_reserve=-1, split_policy=-
     prev = _share
     cur = tuple(n if n > 0 else o for n, o in zip((nt64, nt128, wino, wgrad), prev[:4])) + \
         (cu_reserve if cu_reserve >= 0 else prev[4], split_policy if split_policy >= 0 else prev[5],
-         wino_big if wino_big >= 0 else prev[6])
+         wino_big if wino_big >= 0 else prev[6], nt_split if nt_split >= 0 else prev[7])
     check(lib.sacv_launch_share(*cur), 'launch_share')
     _share = cur
     return prev

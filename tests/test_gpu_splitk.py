@@ -18,6 +18,16 @@ def ops():
     return o
 
 
+@pytest.fixture(autouse=True, params=['fp32_pipe', 'bf16x3_pipe'])
+def matrix_pipe(request, ops):
+    """Every test of this module runs twice: sacv_conv2d_gemm on the fp32 matrix pipe, and with the operands split into
+    three bf16 terms at the LDS store (six products on the bf16 pipe, fp32 accumulators; csrc/conv_gemm.hip SP) -- the
+    same tolerances: the split form carries the fp32 pipe's error."""
+    prev = ops.launch_share(nt_split=int(request.param == 'bf16x3_pipe'))
+    yield request.param
+    ops.launch_share(*prev)
+
+
 def rnd(seed, *shape, std=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * std

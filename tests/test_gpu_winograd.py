@@ -237,16 +237,24 @@ def test_weight_gradient_vs_fp64_and_direct(ops, cin, cout, layout):
     if layout == 'ohwi':
         dw = torch.empty((cout, 3, 3, cin), device='cuda').permute(0, 3, 1, 2)
     ops.wino_wgrad(gys, v, dw, cin)
-    # from the split form of V (what the forward pass keeps when the GEMMs run on the bf16 pipe): the kernel rebuilds
-    # the fp32 values exactly, so the gradient is the same bit for bit
-    dw3 = torch.empty_like(dw)
-    ops.wino_wgrad(gys, ops.wino_input(srcs, tag='test_keep3', split=True), dw3, cin)
-    assert torch.equal(dw3, dw)
     direct = torch.empty_like(dw)
     ops.conv_wgrad(gys, srcs, direct, cin, 3, 3, 1, 1)
     e_w, e_d, e_32 = rel(dw.cpu(), ref), rel(direct.cpu(), ref), rel(ref32, ref)
     assert e_w < 4 * max(e_d, e_32) + 1e-7, (e_w, e_d, e_32)
     assert e_w < 3e-6, e_w
+    # from the split form of V (what the forward pass keeps when the GEMMs run on the bf16 pipe): the kernel rebuilds
+    # the fp32 values exactly, so the gradient is the same bit for bit
+    dw3 = torch.empty_like(dw)
+    v3 = ops.wino_input(srcs, tag='test_keep3', split=True)
+    ops.wino_wgrad(gys, v3, dw3, cin, exact=True)
+    assert torch.equal(dw3, dw)
+    # ... and on the bf16 pipe (transformed dy split the same way, six products into fp32 accumulators): the error of
+    # the fp32 kernels against fp64, not more
+    ops.wino_wgrad(gys, v3, dw3, cin)
+    e_3 = rel(dw3.cpu(), ref)
+    assert e_3 < 1.25 * max(rel(dw.cpu(), ref), e_d, e_32) + 1e-7 and e_3 < 3e-6, (e_3, rel(dw.cpu(), ref), e_d, e_32)
+    ops.wino_wgrad(gys, v3, dw3, cin, accumulate=True)
+    assert rel(dw3.cpu(), 2 * ref) < 3e-6
     ops.wino_wgrad(gys, v, dw, cin, accumulate=True)
     assert rel(dw.cpu(), 2 * ref) < 3e-6
 
@@ -254,41 +262,49 @@ def test_weight_gradient_vs_fp64_and_direct(ops, cin, cout, layout):
 @pytest.mark.parametrize('name,crit', [('resnet50_retinanet', 'RetinaLoss'), ('resnet50_fcos', 'FCOSLoss')])
 def test_detector_step_winograd_matches_direct(name, crit):
     """The whole training forward + backward with the head / P3 convolutions on the Winograd path against the same
-    model on the direct kernels only (engine.winograd = False): losses within 2e-6 relative, every gradient tensor
-    within 1e-3 relative L2 (two fp32 summation orders of the same sums; the direct path is the one pinned to the
-    reference fixtures in test_gpu_fullsize / test_gpu_pinned / test_gpu_trainer)."""
+    model on the direct kernels only (engine.winograd = False): losses within 2e-6 relative, gradient tensors within the
+    gates of check_gates -- once with every GEMM on the fp32 matrix pipe and once with every GEMM on the bf16 pipe
+    (operands as three bf16 terms: engine.wino_split / engine.conv_split).  The comparison is made WITHIN a pipe: the
+    trunk then rounds the same way in both runs and the difference is what the head convolutions' form contributes.
+    ACROSS the pipes the same model's gradients differ by 2-3 % -- and so does either of them from the fp64 oracle
+    (scripts/diag_split_vs_fp64.py, round 4, 544 x 736, two inputs: median tensor fp32 pipe 2.7e-2 / 2.5e-2, split
+    2.8e-2 / 2.3e-2 from the exact gradient; max 3.7e-2 / 4.0e-2 and 3.8e-2 / 3.7e-2): at random initialisation this step
+    is chaotic at that level in fp32, whatever computes it.  Each kernel's own error against fp64 is pinned in
+    test_gpu_kernels.py / this file (same as the fp32 pipe's), the engines against the reference fixtures in
+    test_gpu_pinned.py / test_gpu_e2e.py."""
     from oracle import model as omodel
     from sacv_amd.detection import models, losses
     H, W = 544, 736  # P3 = 68 x 92: enough tiles for the P3 smoothing conv to take the Winograd path as well
     images = torch.tensor(synth.images(7, 2, H, W)).cuda()
     annots = torch.tensor(synth.annotations(8, 2, H, W, boxes_per_image=6)).cuda()
-    out = {}
     torch.manual_seed(0)
     state0 = (omodel.init_retinanet_state(0) if name == 'resnet50_retinanet'
               else {k: v.clone() for k, v in models.__dict__[name](num_classes=80).state_dict().items()})
-    for wino in ('split', True, False):  # 'split': the Winograd GEMMs on the bf16 pipe (operands as three bf16 terms)
-        net = models.__dict__[name](num_classes=80)
-        net.load_state_dict(state0)
-        net = net.cuda().train()
-        net.engine.winograd = bool(wino)
-        net.engine.wino_split = wino == 'split'
-        net.engine.WINO_MIN_TILES = 1000  # P3 = 68 x 92 here: 3128 tiles, below the production threshold
-        criterion = losses.__dict__[crit]()
-        preds = net(images)
-        if wino:  # the context of the kept forward pass lives until backward() consumes it
-            assert any(k.startswith('wino_v:') for k in net.engine.ctx), 'P3 smoothing conv not on the Winograd path'
-        ld = criterion(preds, annots)
-        loss = sum(ld.values())
-        loss.backward()
-        torch.cuda.synchronize()
-        out[wino] = (float(loss.detach()), {k: g.clone() for k, g in net.arena.grad_views.items()})
-    ld_, gd = out[False]
-    for form in (True, 'split'):
-        lw, gw = out[form]
-        assert abs(lw - ld_) <= 2e-6 * abs(ld_), (form, lw, ld_)
+    for split in (False, True):
+        out = {}
+        for wino in (True, False):
+            net = models.__dict__[name](num_classes=80)
+            net.load_state_dict(state0)
+            net = net.cuda().train()
+            net.engine.winograd = wino
+            net.engine.wino_split = split
+            net.engine.conv_split = split
+            net.engine.WINO_MIN_TILES = 1000  # P3 = 68 x 92 here: 3128 tiles, below the production threshold
+            criterion = losses.__dict__[crit]()
+            preds = net(images)
+            if wino:  # the context of the kept forward pass lives until backward() consumes it
+                assert any(k.startswith('wino_v:') for k in net.engine.ctx), 'P3 smoothing conv not on the Winograd path'
+            ld = criterion(preds, annots)
+            loss = sum(ld.values())
+            loss.backward()
+            torch.cuda.synchronize()
+            out[wino] = (float(loss.detach()), {k: g.clone() for k, g in net.arena.grad_views.items()})
+        lw, gw = out[True]
+        ld_, gd = out[False]
+        assert abs(lw - ld_) <= 2e-6 * abs(ld_), (split, lw, ld_)
         rels = sorted(((rel(gw[k], gd[k]), k) for k in gd if float(gd[k].double().norm()) > 0), reverse=True)
         worst, median = rels[0], rels[len(rels) // 2][0]
-        print(f'{name}: Winograd ({"split bf16 terms" if form == "split" else "fp32"}) vs direct engine, gradient '
+        print(f'{name} ({"bf16 pipe, split operands" if split else "fp32 pipe"}): Winograd vs direct heads, gradient '
               f'rel-L2 worst {worst[0]:.2e} ({worst[1]}) median {median:.2e}')
         check_gates(name, worst, median)
 

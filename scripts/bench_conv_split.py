@@ -70,3 +70,17 @@ for h, w, cin, cout, k in SHAPES:
         line += f'  err {e:.2e}'
     line += f'  split-vs-fp32 {float((outs[1] - outs[0]).norm() / outs[0].norm()):.2e}'
     print(line, flush=True)
+    # weight gradient
+    line = f'    weight gradient:'
+    outs = {}
+    for sp in (0, 1):
+        prev = ops.launch_share(nt_split=sp)
+        dw = torch.empty((cout, k, k, cin), device='cuda').permute(0, 3, 1, 2)
+        f = lambda: ops.conv_wgrad([dy], [x], dw, cin, k, k, 1, k // 2)
+        t = timeit(f)
+        f()
+        outs[sp] = dw.clone()
+        ops.launch_share(*prev)
+        line += f'  {"split" if sp else "fp32"} {t:7.1f} us'
+    line += f'  split-vs-fp32 {float((outs[1] - outs[0]).norm() / outs[0].norm()):.2e}'
+    print(line, flush=True)

@@ -935,6 +935,223 @@ __global__ __launch_bounds__(256, 2) void conv_tn_kernel(const WgradArgs a) {
   }
 }
 
+// The weight-gradient GEMM on the bf16 pipe (split operands, see conv_nt_kernel SP): the gathered fp32 values of dy and
+// x are split into three bf16 terms when they are stored to LDS (global traffic unchanged) and the six products per K
+// step run on v_mfma_f32_32x32x16_bf16.  The contraction index is the PIXEL, the slow index of both operands, so the
+// LDS images are [KR pixel rows][channels] bf16 per plane and the fragments come from the transposing LDS read
+// (ds_read_b64_tr_b16; conv_tn_bf16_kernel of conv_bf16.hip has the lane mapping), rows padded by 64 bytes.  KR = 32
+// pixel rows per tile for the 64 x 64 item (73.7 KB double-buffered, two workgroups per CU), 16 for the wider items.
+typedef short cs16x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_tn3_kernel(const WgradArgs a) {
+  constexpr int KR = (BM + BN <= 128) ? 32 : 16;          // pixel rows per K tile
+  constexpr int RSA_B = BM * 2 + 64, RSB_B = BN * 2 + 64;  // LDS row strides in bytes
+  constexpr int CGA = BM / 4, RSA = 256 / CGA;            // f32x4 column groups of a row, rows per pass
+  constexpr int CGB = BN / 4, RSB = 256 / CGB;
+  constexpr int RA = KR / RSA, RB = KR / RSB;             // f32x4 per thread and tile
+  static_assert(RA >= 1 && RB >= 1, "a tile row pass per operand");
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int IMG_A = 3 * KR * RSA_B, IMG_B = 3 * KR * RSB_B;  // bytes of one buffer [3 planes][KR][row]
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+  unsigned char* sA = smem3;              // [2][IMG_A]
+  unsigned char* sB = smem3 + 2 * IMG_A;  // [2][IMG_B]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int ntm = (a.Cout + BM - 1) / BM;
+  const int ntn = (a.N2 + BN - 1) / BN;
+  int bid = blockIdx.x;
+  const int tm = bid % ntm;
+  bid /= ntm;
+  const int tn = bid % ntn;
+  const int ck = bid / ntn;
+  int si = 0;
+  for (int i = 1; i < a.nseg; ++i)
+    if (ck >= a.s[i].chunk_begin) si = i;
+  const WgradSeg& S = a.s[si];
+  const int pix0 = (ck - S.chunk_begin) * a.chunk;
+  const int pix1 = min(pix0 + a.chunk, S.npix);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const float* __restrict__ dy = S.dy;
+  const float* __restrict__ x = S.x;
+
+  const int ca = tid % CGA, rra = tid / CGA;
+  const int cb = tid % CGB, rrb = tid / CGB;
+  const int co = m0 + ca * 4;
+  const bool co_ok = co < a.Cout;
+  const int n2 = n0 + cb * 4;
+  const bool n2_ok = n2 < a.N2;
+  int tap = 0, ci = 0, kh = 0, kw = 0;
+  if (n2_ok) {
+    tap = n2 / a.Cin;
+    ci = n2 - tap * a.Cin;
+    kh = tap / a.KW;
+    kw = tap - kh * a.KW;
+  }
+  const int HoWo = S.Ho * S.Wo;
+  const int Wo = S.Wo, Ho = S.Ho, Hx = S.Hx, Wx = S.Wx;
+  const int dh = kh - a.pad, dw = kw - a.pad;
+  int pn[RB], ph[RB], pw[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    int pix = pix0 + rrb + i * RSB;
+    pn[i] = pix / HoWo;
+    int rem = pix - pn[i] * HoWo;
+    ph[i] = rem / Wo;
+    pw[i] = rem - ph[i] * Wo;
+  }
+  f32x4 ra[RA], rb[RB];
+  auto load_a = [&](int i, int p0) {
+    int pix = p0 + rra + i * RSA;
+    bool ok = co_ok & (pix < pix1);
+    const float* ptr = dy + (unsigned)(pix * a.Cout + co);
+    ptr = ok ? ptr : sacv_zero16;
+    ra[i] = *reinterpret_cast<const f32x4*>(ptr);
+  };
+  auto load_b = [&](int i, int p0) {
+    int pix = p0 + rrb + i * RSB;
+    int hi = ph[i] * a.stride + dh;
+    int wi = pw[i] * a.stride + dw;
+    bool ok = n2_ok & (pix < pix1) & ((unsigned)hi < (unsigned)Hx) & ((unsigned)wi < (unsigned)Wx);
+    const float* ptr = x + ((unsigned)((pn[i] * Hx + hi) * Wx + wi) * (unsigned)a.Cin + (unsigned)ci);
+    ptr = ok ? ptr : sacv_zero16;
+    rb[i] = *reinterpret_cast<const f32x4*>(ptr);
+  };
+  const int adv_n = KR / HoWo;
+  const int adv_h = (KR - adv_n * HoWo) / Wo;
+  const int adv_w = KR - adv_n * HoWo - adv_h * Wo;
+  auto advance = [&]() {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      int w = pw[i] + adv_w;
+      const int cw = w >= Wo ? 1 : 0;
+      w -= cw ? Wo : 0;
+      int h = ph[i] + adv_h + cw;
+      const int chh = h >= Ho ? 1 : 0;
+      h -= chh ? Ho : 0;
+      pw[i] = w;
+      ph[i] = h;
+      pn[i] += adv_n + chh;
+    }
+  };
+  // 4 consecutive channels of one pixel row -> three 8-byte stores (planes hi, mid, lo)
+  auto put3 = [&](unsigned char* img, int rs, int row, int col, const f32x4 v) {
+    cbf16x4 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = (cbf16)v[e];
+      const float r1 = v[e] - (float)h[e];
+      m[e] = (cbf16)r1;
+      l[e] = (cbf16)(r1 - (float)m[e]);
+    }
+    unsigned char* d = img + row * rs + col * 2;
+    *reinterpret_cast<cbf16x4*>(d) = h;
+    *reinterpret_cast<cbf16x4*>(d + KR * rs) = m;
+    *reinterpret_cast<cbf16x4*>(d + 2 * KR * rs) = l;
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) put3(sA + buf * IMG_A, RSA_B, rra + i * RSA, ca * 4, ra[i]);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) put3(sB + buf * IMG_B, RSB_B, rrb + i * RSB, cb * 4, rb[i]);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int wm0 = (wid >> 1) * WTM, wn0 = (wid & 1) * WTN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int tr_row = 8 * (tg >> 1) + tq;      // + 4 for the second read, + 16 per K step
+  const int tr_col = 16 * (tg & 1) + 4 * tp;  // channel inside the 32-wide MFMA block
+
+  const int KT = (pix1 - pix0 + KR - 1) / KR;
+  if (KT > 0) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) load_a(i, pix0);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) load_b(i, pix0);
+    store_tile(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool have_next = kt + 1 < KT;
+    const int pnext = pix0 + (kt + 1) * KR;  // beyond pix1 after the last tile: every load is masked
+    advance();
+#pragma unroll
+    for (int i = 0; i < RA; ++i) load_a(i, pnext);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) load_b(i, pnext);
+    const unsigned char* cA = sA + cur * IMG_A + tr_row * RSA_B + (wm0 + tr_col) * 2;
+    const unsigned char* cB = sB + cur * IMG_B + tr_row * RSB_B + (wn0 + tr_col) * 2;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < KR / 16; ++kk) {
+      cbf16x8 fa[3][TM], fb[3][TN];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const unsigned char* pA = cA + (pl * KR + kk * 16) * RSA_B + i * 64;
+          union { cs16x4 s[2]; cbf16x8 v; } u;
+          u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cs16x4*)(pA));
+          u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cs16x4*)(pA + 4 * RSA_B));
+          fa[pl][i] = u.v;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const unsigned char* pB = cB + (pl * KR + kk * 16) * RSB_B + j * 64;
+          union { cs16x4 s[2]; cbf16x8 v; } u;
+          u.s[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cs16x4*)(pB));
+          u.s[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) cs16x4*)(pB + 4 * RSB_B));
+          fb[pl][j] = u.v;
+        }
+      }
+      constexpr int pa[6] = {0, 1, 0, 1, 2, 0};
+      constexpr int pb[6] = {0, 0, 1, 1, 0, 2};
+#pragma unroll
+      for (int t6 = 0; t6 < 6; ++t6)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa[t6]][i], fb[pb[t6]][j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (have_next) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  constexpr int CS = BN + 4;
+  float* stage = reinterpret_cast<float*>(smem3);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        stage[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CS + wn0 + j * 32 + l31] = acc[i][j][r];
+  __syncthreads();
+  float* __restrict__ part = a.part + (size_t)ck * a.Cout * a.N2;
+  constexpr int CG = BN / 4, RS = 256 / CG;
+  const int c4 = tid % CG, rr = tid / CG;
+  const int n = n0 + c4 * 4;
+  if (n < a.N2) {
+#pragma unroll 4
+    for (int row = rr; row < BM; row += RS) {
+      int m = m0 + row;
+      if (m < a.Cout)
+        *reinterpret_cast<f32x4*>(part + (size_t)m * a.N2 + n) =
+            *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4);
+    }
+  }
+}
+
 // source element (co, ci, tap) of a weight stored OIHW (src_ohwi = 0) or OHWI = channels_last (src_ohwi = 1)
 __device__ __forceinline__ size_t w_src_index(int co, int ci, int tap, int Cin, int T, int src_ohwi) {
   return src_ohwi ? ((size_t)co * T + tap) * Cin + ci : ((size_t)co * Cin + ci) * T + tap;
@@ -1274,6 +1491,20 @@ static int launch_nt(ConvArgs& a, const NtPlan& plan, float* workspace, hipStrea
 template <int BM, int BN>
 static int launch_tn(const WgradArgs& a, int chunks, hipStream_t st) {
   int ntm = (a.Cout + BM - 1) / BM, ntn = (a.N2 + BN - 1) / BN;
+  if (sacv_share.nt_split) {
+    constexpr int KR = (BM + BN <= 128) ? 32 : 16;
+    size_t lds3 = (size_t)2 * 3 * KR * ((BM * 2 + 64) + (BN * 2 + 64));
+    const size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
+    if (epi > lds3) lds3 = epi;
+    static std::once_flag attr3;
+    std::call_once(attr3, [lds3] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tn3_kernel<BM, BN>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+    });
+    hipLaunchKernelGGL((conv_tn3_kernel<BM, BN>), dim3(ntm * ntn * chunks), dim3(256), lds3, st, a);
+    SACV_CHECK_LAUNCH("conv_tn3_kernel");
+    return SACV_OK;
+  }
   size_t lds = (size_t)2 * 32 * (BM + BN) * sizeof(float);
   size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);
   if (lds_epi > lds) lds = lds_epi;

@@ -21,6 +21,49 @@ H, W, BATCH = 800, 1333, 2
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, fp32 matrix
 PEAK_HBM_GBS = 8000.0          # same guide: HBM3E 8 TB/s spec (6.3 TB/s measured with a float4 copy)
 WINO_SAVING = 2.25             # F(2x2,3x3): 36 direct MACs per 16 Winograd-domain MACs
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # same guide: 256 CUs x 4 SIMDs x 1024 flop/clk (v_mfma_f32_32x32x16_bf16: 32 cycles) x 2.4 GHz
+SPLIT_PRODUCTS = 6             # an fp32 product on the bf16 pipe: six bf16 products (operands as three bf16 terms)
+
+
+def pipe_of(family):
+    """('bf16' | 'fp32', executed matrix-core flops per algorithmic flop, dense peak of that pipe) of a timer family.
+    Families ending in 3 (conv_nt3_*, conv_tn3, conv_nt_wino3, conv_tn_wino3) run fp32 GEMMs on the bf16 pipe with the
+    operands split into three bf16 terms: 6 executed bf16 flops per fp32 flop; the Winograd families execute 1 / 2.25 of
+    the direct-convolution flops; *_bf16 families are plain bf16 (autocast)."""
+    fam = family.split('|')[0]
+    ratio = 1.0 / WINO_SAVING if 'wino' in fam else 1.0
+    if fam.endswith('_bf16'):
+        return 'bf16', ratio, PEAK_BF16_MFMA_TFLOPS
+    if fam in ('conv_tn3', 'conv_nt_wino3', 'conv_tn_wino3') or fam.startswith('conv_nt3'):
+        return 'bf16', ratio * SPLIT_PRODUCTS, PEAK_BF16_MFMA_TFLOPS
+    return 'fp32', ratio, PEAK_FP32_MFMA_TFLOPS
+
+
+def family_roofline(agg, prefix):
+    """Launches, time, algorithmic flops / bytes of the timer families starting with `prefix`, and their matrix-core
+    accounting: executed flops on each pipe, the time they would take at that pipe's dense peak (`peak_ms`), hence the
+    utilisation frac = peak_ms / ms whatever the mix of pipes.  `achieved` / `peak` are quoted on the pipe that does most
+    of the work (launches of the other pipe enter at the ratio of the two peaks, so that achieved / peak = frac)."""
+    k = dict(launches=0, flops=0.0, ms=0.0, bytes=0.0, peak_ms=0.0, exec_bf16=0.0, exec_fp32=0.0)
+    for name, v in agg.items():
+        if not name.startswith(prefix):
+            continue
+        pipe, ratio, peak = pipe_of(name)
+        for f_ in ('launches', 'flops', 'ms'):
+            k[f_] += v[f_]
+        k['bytes'] += v.get('bytes', 0.0)
+        k['peak_ms'] += v['flops'] * ratio / (peak * 1e12) * 1e3
+        k['exec_' + pipe] += v['flops'] * ratio
+    if not k['launches']:
+        return None
+    k['pipe'] = 'bf16' if k['exec_bf16'] / PEAK_BF16_MFMA_TFLOPS >= k['exec_fp32'] / PEAK_FP32_MFMA_TFLOPS else 'fp32'
+    k['peak'] = PEAK_BF16_MFMA_TFLOPS if k['pipe'] == 'bf16' else PEAK_FP32_MFMA_TFLOPS
+    k['frac'] = k['peak_ms'] / k['ms']
+    k['achieved'] = k['frac'] * k['peak']
+    k['effective'] = k['flops'] / (k['ms'] * 1e-3) / 1e12
+    # ceiling of the ALGORITHMIC rate on the pipe in use: the fp32 matrix peak, or the bf16 peak / 6 products
+    k['effective_peak'] = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS if k['pipe'] == 'bf16' else PEAK_FP32_MFMA_TFLOPS
+    return k
 
 
 def cpu_baseline(warmup=3, steps=5):
@@ -78,18 +121,16 @@ def class_table(agg, steps):
     fraction of the 8 TB/s HBM peak -- the bound that applies is the larger fraction's."""
     rows = []
     for key, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
-        fam = key.split('|')[0]
-        half = '_bf16' in fam
-        peak = 2500.0 if half else PEAK_FP32_MFMA_TFLOPS
-        # `flops` of a record are ALGORITHMIC (direct-convolution) flops; the Winograd F(2x2,3x3) classes execute
-        # 1 / 2.25 of them on the matrix cores: `tflops` / `mfma_frac` price what the matrix cores execute (a
-        # utilisation, never above 1), `effective_tflops` keeps the algorithmic rate
-        executed = v['flops'] / WINO_SAVING if 'wino' in fam else v['flops']
-        tf = executed / (v['ms'] * 1e-3) / 1e12 if v['ms'] else 0.0
+        # `flops` of a record are ALGORITHMIC (direct-convolution, fp32) flops.  `tflops` / `mfma_frac` price what the
+        # matrix cores EXECUTE on the pipe the class runs on (pipe_of: Winograd classes 1 / 2.25 of the direct flops,
+        # split-operand classes 6 bf16 flops per fp32 flop) against that pipe's dense peak -- a utilisation, never above 1;
+        # `effective_tflops` keeps the algorithmic rate
+        pipe, ratio, peak = pipe_of(key)
+        tf = v['flops'] * ratio / (v['ms'] * 1e-3) / 1e12 if v['ms'] else 0.0
         etf = v['flops'] / (v['ms'] * 1e-3) / 1e12 if v['ms'] else 0.0
         gbs = v.get('bytes', 0.0) / (v['ms'] * 1e-3) / 1e9 if v['ms'] else 0.0
         rows.append(dict(cls=key, launches_per_step=v['launches'] / steps, ms_per_step=round(v['ms'] / steps, 4),
-                         tflops=round(tf, 1), mfma_frac=round(tf / peak, 4), effective_tflops=round(etf, 1),
+                         pipe=pipe, tflops=round(tf, 1), mfma_frac=round(tf / peak, 4), effective_tflops=round(etf, 1),
                          gbs=round(gbs, 1), hbm_frac=round(gbs / PEAK_HBM_GBS, 4)))
     return rows
 
@@ -113,6 +154,12 @@ def launch_ranks(n):
     if rc != 0:
         print(f'bench.py: the {n}-rank run failed with exit code {rc}', file=sys.stderr, flush=True)
     sys.exit(rc)
+
+
+def apply_launch_plan(args, ops):
+    """--launch-plan NAME=VALUE[,NAME=VALUE...]: fields of the library's launch plan (ops.launch_share) for A/B runs."""
+    if getattr(args, 'launch_plan', None):
+        ops.launch_share(**{kv.split('=')[0]: int(kv.split('=')[1]) for kv in args.launch_plan.split(',')})
 
 
 def apply_engine_settings(args, net):
@@ -174,21 +221,17 @@ def bench_classification(args, rank, world, group, ops, synth):
     roofline = None
     if timer is not None:
         agg = timer.summary()
-        k = dict(launches=0, flops=0.0, ms=0.0, bytes=0.0)
-        k_exec = 0.0
-        for name, v in agg.items():
-            if name.startswith('conv_nt_'):
-                for f_ in k:
-                    k[f_] += v[f_]
-                k_exec += v['flops'] / (WINO_SAVING if name.startswith('conv_nt_wino') else 1.0)
+        k = family_roofline(agg, 'conv_nt') or dict(launches=0)
         if k['launches'] and not amp:
-            eff = k['flops'] / (k['ms'] * 1e-3) / 1e12
-            ach = k_exec / (k['ms'] * 1e-3) / 1e12  # executed on the matrix cores (Winograd trunk layers: 1 / 2.25)
-            roofline = dict(kernel='conv_nt_kernel / wino_gemm_kernel (conv forward + data gradient, fp32 MFMA 32x32x2); '
-                                   'achieved = executed matrix-core flops / time, effective_achieved = algorithmic',
-                            bound='mfma', achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                            frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), effective_achieved=round(eff, 2),
-                            effective_frac=round(eff / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+            roofline = dict(kernel='conv_nt_kernel / wino_gemm_kernel (conv forward + data gradient; fp32 operands as three '
+                                   'bf16 terms, six products per fp32 product on the bf16 matrix pipe, fp32 accumulators); '
+                                   'achieved = executed matrix-core flops / time, effective_achieved = algorithmic fp32 flops / '
+                                   'time, effective_peak = that pipe\'s peak / 6',
+                            bound='mfma', pipe=k['pipe'], achieved=round(k['achieved'], 2), peak=k['peak'], unit='TFLOP/s',
+                            frac=round(k['frac'], 4), effective_achieved=round(k['effective'], 2),
+                            effective_peak=round(k['effective_peak'], 1),
+                            effective_frac=round(k['effective'] / k['effective_peak'], 4),
+                            vs_fp32_matrix_peak=round(k['effective'] / PEAK_FP32_MFMA_TFLOPS, 3), traffic=None,
                             launches_per_step=k['launches'] // n_inst,
                             share_of_step_ms=round(k['ms'] / n_inst, 2))
         elif k['launches']:
@@ -220,7 +263,7 @@ def bench_classification(args, rank, world, group, ops, synth):
         if args.class_table and rank == 0:
             with open(args.class_table, 'w') as f:
                 json.dump(dict(model='resnet50_cls', dtype=args.dtype, batch=CB, steps=args.steps,
-                               peak_tflops_bf16_mfma=2500.0, peak_tflops_fp32_mfma=PEAK_FP32_MFMA_TFLOPS,
+                               peak_tflops_bf16_mfma=PEAK_BF16_MFMA_TFLOPS, peak_tflops_fp32_mfma=PEAK_FP32_MFMA_TFLOPS,
                                peak_hbm_gbs=PEAK_HBM_GBS, classes=class_table(agg, n_inst)), f, indent=1)
     if rank == 0:
         print(json.dumps({
@@ -303,7 +346,7 @@ def bench_mae(args, rank, world, group, ops, synth):
                             algorithmic_gbs=round(k['bytes'] / (k['ms'] * 1e-3) / 1e9, 1))
         if args.class_table and rank == 0:
             with open(args.class_table, 'w') as f:
-                json.dump(dict(model='vit_mae', dtype='bf16', batch=MB, steps=args.steps, peak_tflops_bf16_mfma=2500.0,
+                json.dump(dict(model='vit_mae', dtype='bf16', batch=MB, steps=args.steps, peak_tflops_bf16_mfma=PEAK_BF16_MFMA_TFLOPS,
                                peak_hbm_gbs=PEAK_HBM_GBS, classes=class_table(agg, n_inst)), f, indent=1)
     if rank == 0:
         print(json.dumps({
@@ -485,6 +528,8 @@ def main():
                     help='one-GPU measurement of the CU reserve (DESIGN.md 5.2): every exchange stage launches a stand-in '
                          'for its all-reduce kernels -- that many resident workgroups for the duration of an 8-rank ring '
                          'all-reduce at GBPS GB/s (default 200) -- on its own stream, chained like the real collective')
+    ap.add_argument('--launch-plan', default=None, metavar='NAME=VALUE[,...]',
+                    help='fields of the library launch plan (sacv_launch_share) for A/B runs, e.g. split_policy=0')
     ap.add_argument('--engine-set', action='append', default=[], metavar='NAME=VALUE',
                     help='A/B runs: set an attribute of the model\'s executor before the first step, e.g. '
                          '--engine-set fuse_bn_bwd=False (value: a Python literal)')
@@ -570,6 +615,7 @@ def main():
         trainer.exchanger.emulate = dict(workgroups=int(f[0]), lds_bytes=int(f[1]) if len(f) > 1 else 16384,
                                          gbps=float(f[2]) if len(f) > 2 else 200.0)
     apply_engine_settings(args, net)
+    apply_launch_plan(args, ops)
     images = torch.tensor(synth.images(rank, BATCH, H, W)).cuda()
     annots = torch.tensor(synth.annotations(rank, BATCH, H, W, boxes_per_image=8)).cuda()
 
@@ -615,17 +661,10 @@ def main():
                 for key, flops, e0, e1 in recs:
                     ms = e0.elapsed_time(e1)
                     f.write(f'{key} {flops/1e9:.3f} GFLOP {ms*1e3:.1f} us {flops/(ms*1e-3)/1e12:.1f} TF\n')
-        k = None
-        for name, v in agg.items():  # keys carry a per-shape suffix after '|'
-            if name.startswith('conv_nt_'):
-                if k is None:
-                    k = dict(launches=0, flops=0.0, ms=0.0, bytes=0.0)
-                for f_ in ('launches', 'flops', 'ms', 'bytes'):
-                    k[f_] += v[f_]
+        k = family_roofline(agg, 'conv_nt')  # keys carry a per-shape suffix after '|'
         if k:
             per_launch_flops = k['flops'] / k['launches']
             per_launch_ms = k['ms'] / k['launches']
-            achieved = per_launch_flops / (per_launch_ms * 1e-3) / 1e12
             # HBM traffic per launch of the same kernel family from the PMC passes committed under profiles/
             # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 read-doubling applied there)
             traffic = None
@@ -634,55 +673,49 @@ def main():
                 if os.path.exists(tpath) and args.model == 'retinanet' and (H, W) == (800, 1333):
                     traffic = round(json.load(open(tpath))['hbm_bytes_per_launch'])
                     break
-            tn = dict(launches=0, flops=0.0, ms=0.0)
-            tn_exec = 0.0
-            for name, v in agg.items():
-                if name.startswith('conv_tn'):
-                    for f_ in tn:
-                        tn[f_] += v[f_]
-                    tn_exec += v['flops'] / (WINO_SAVING if name.startswith('conv_tn_wino') else 1.0)
+            tn = family_roofline(agg, 'conv_tn')
             secondary = None
-            if tn['launches']:
-                ach = tn['flops'] / (tn['ms'] * 1e-3) / 1e12
-                ex = tn_exec / (tn['ms'] * 1e-3) / 1e12
-                secondary = dict(kernel='weight gradient: conv_tn_kernel + wgrad_reduce (direct), wino_wgrad_kernel + transforms (Winograd, head 3x3 convolutions); achieved = executed matrix-core flops / time, effective_achieved = algorithmic flops / time', bound='mfma',
-                                 achieved=round(ex, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                                 frac=round(ex / PEAK_FP32_MFMA_TFLOPS, 4),
-                                 effective_achieved=round(ach, 2), effective_frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            if tn:
+                secondary = dict(kernel='weight gradient: conv_tn3_kernel + wgrad_reduce (direct), wino_wgrad3_kernel + transforms '
+                                        '(Winograd: head 3x3 convolutions and the trunk\'s >= 128-channel ones); achieved = executed '
+                                        'matrix-core flops / time, effective_achieved = algorithmic fp32 flops / time', bound='mfma',
+                                 pipe=tn['pipe'], achieved=round(tn['achieved'], 2), peak=tn['peak'], unit='TFLOP/s',
+                                 frac=round(tn['frac'], 4), effective_achieved=round(tn['effective'], 2),
+                                 effective_peak=round(tn['effective_peak'], 1),
+                                 effective_frac=round(tn['effective'] / tn['effective_peak'], 4),
                                  launches_per_step=tn['launches'] // n_inst,
                                  share_of_step_ms=round(tn['ms'] / n_inst, 2))
-            wino = dict(launches=0, flops=0.0, ms=0.0)
-            for name, v in agg.items():
-                if name.startswith('conv_nt_wino'):
-                    for f_ in wino:
-                        wino[f_] += v[f_]
+            wino = family_roofline(agg, 'conv_nt_wino')
             paths = None
-            if wino['launches']:
+            if wino:
                 d_fl, d_ms = k['flops'] - wino['flops'], k['ms'] - wino['ms']
                 paths = dict(
-                    winograd=dict(calls_per_step=wino['launches'] // n_inst,
-                                  algorithmic_tflops=round(wino['flops'] / (wino['ms'] * 1e-3) / 1e12, 2),
-                                  matrix_core_tflops=round(wino['flops'] / WINO_SAVING / (wino['ms'] * 1e-3) / 1e12, 2),
+                    winograd=dict(calls_per_step=wino['launches'] // n_inst, pipe=wino['pipe'],
+                                  algorithmic_tflops=round(wino['effective'], 2),
+                                  matrix_core_tflops=round(wino['achieved'], 2), matrix_core_frac=round(wino['frac'], 4),
                                   share_of_step_ms=round(wino['ms'] / n_inst, 2),
                                   note='F(2x2,3x3): 2.25x fewer matrix-core flops than the direct sum; time includes '
                                        'the input transform'),
                     direct=dict(calls_per_step=(k['launches'] - wino['launches']) // n_inst,
                                 algorithmic_tflops=round(d_fl / (d_ms * 1e-3) / 1e12, 2),
+                                matrix_core_frac=round((k['peak_ms'] - wino['peak_ms']) / d_ms, 4),
                                 share_of_step_ms=round(d_ms / n_inst, 2)))
-            # `achieved` / `frac` price the flops the matrix cores EXECUTE (Winograd F(2x2,3x3) runs 1 / 2.25 of the direct
-            # sum): matrix-core utilisation.  The algorithmic (direct-convolution) rate of the same launches -- what
-            # the step's throughput follows -- is reported beside it as effective_*.
-            executed = (k['flops'] - wino['flops'] + wino['flops'] / WINO_SAVING) / (k['ms'] * 1e-3) / 1e12
-            alg_bytes = k.get('bytes', 0.0) / k['launches']
-            roofline = dict(kernel='convolution forward + data gradient: conv_nt_kernel<128,{128|64},mode> (implicit GEMM) and, '
-                                   'for the stride-1 3x3 head / P3 convolutions, wino_gemm_kernel<64,{64|128}> (Winograd '
-                                   'F(2x2,3x3), 16 chained GEMMs + output transform); fp32 MFMA 32x32x2; `achieved` = flops '
-                                   'EXECUTED on the matrix cores / time (utilisation); effective_achieved = algorithmic '
-                                   '(direct-convolution) flops / time',
-                            bound='mfma', achieved=round(executed, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit='TFLOP/s',
-                            frac=round(executed / PEAK_FP32_MFMA_TFLOPS, 4),
-                            effective_achieved=round(achieved, 2),
-                            effective_frac=round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+            # `achieved` / `frac` price the flops the matrix cores EXECUTE on the pipe they run on (family_roofline):
+            # matrix-core utilisation.  The algorithmic (direct-convolution, fp32) rate of the same launches -- what the
+            # step's throughput follows -- is reported beside it as effective_*, against the ceiling of that pipe for
+            # fp32 products (bf16 peak / 6) and, for orientation, against the fp32 matrix pipe's peak.
+            alg_bytes = k['bytes'] / k['launches']
+            roofline = dict(kernel='convolution forward + data gradient: conv_nt_kernel<128,64,mode,...,SP> (implicit GEMM) and, '
+                                   'for the stride-1 3x3 head / P3 convolutions, wino_gemm_kernel<{128x128|64x64},split> '
+                                   '(Winograd F(2x2,3x3), 16 chained GEMMs + output transform); fp32 operands as three bf16 '
+                                   'terms, six v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulators; '
+                                   '`achieved` = flops EXECUTED on the matrix cores / time (utilisation); effective_achieved '
+                                   '= algorithmic (direct-convolution fp32) flops / time',
+                            bound='mfma', pipe=k['pipe'], achieved=round(k['achieved'], 2), peak=k['peak'], unit='TFLOP/s',
+                            frac=round(k['frac'], 4),
+                            effective_achieved=round(k['effective'], 2), effective_peak=round(k['effective_peak'], 1),
+                            effective_frac=round(k['effective'] / k['effective_peak'], 4),
+                            vs_fp32_matrix_peak=round(k['effective'] / PEAK_FP32_MFMA_TFLOPS, 3),
                             traffic=traffic,
                             algorithmic_bytes_per_launch=round(alg_bytes),
                             traffic_ratio=round(traffic / alg_bytes, 2) if (traffic and alg_bytes) else None,
@@ -711,7 +744,13 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'RetinaNet-ResNet50 COCO training step (fwd + RetinaLoss SmoothL1 + bwd + '
                                    f'grad all-reduce + AdamW), images [2,3,{H},{W}]/GPU, 8 GT boxes/image, '
-                                   'random init', 'global_batch': world * BATCH, 'parallelism': f'dp{world}'},
+                                   'random init', 'global_batch': world * BATCH, 'parallelism': f'dp{world}',
+                       'matrix_arithmetic': ('fp32 tensors, fp32 accumulators; every matrix product of the convolutions is '
+                                             'formed on the bf16 matrix pipe from operands split EXACTLY into three bf16 terms '
+                                             '(x = hi + mid + lo), six partial products per fp32 product -- the error against '
+                                             'fp64 is that of the fp32 matrix pipe (tests/test_gpu_kernels.py, '
+                                             'test_gpu_winograd.py; scripts/diag_conv_split.py)')
+                       if getattr(net.engine, 'conv_split', False) else 'fp32 matrix pipe'},
             'loss': losses_host,
             'roofline': roofline,
         }

@@ -28,8 +28,8 @@ def read_stats(path):
 # is one convolution call = one dispatch of a main kernel.
 NT_MAIN = ('conv_nt_kernel', 'wino_gemm_kernel', 'stem_conv_kernel')
 NT_AUX = ('conv_fixup_kernel', 'wino_input_kernel', 'wino_weight_kernel')
-TN_FAMILY = ('conv_tn_kernel', 'wgrad_reduce_kernel', 'wino_wgrad_kernel', 'wino_dy_kernel', 'wino_wgrad_reduce_kernel',
-             'stem_wgrad_kernel', 'wgrad_reduce_stem_kernel')
+TN_FAMILY = ('conv_tn_kernel', 'conv_tn3_kernel', 'wgrad_reduce_kernel', 'wino_wgrad_kernel', 'wino_wgrad3_kernel', 'wino_dy_kernel',
+             'wino_wgrad_reduce_kernel', 'stem_wgrad_kernel', 'wgrad_reduce_stem_kernel')
 
 
 def pmc_per_launch(path, counter, mains, aux=()):
@@ -166,14 +166,18 @@ def main():
     wino_ms, direct_ms = fam(('wino_gemm_kernel', 'wino_input_kernel', 'wino_weight_kernel')), fam(('conv_nt_kernel', 'conv_fixup_kernel'))
     md += ['', '## Roofline per kernel class', '',
            f'* MFMA-bound: convolution forward + data gradient (`conv_nt_kernel` direct, `wino_gemm_kernel` Winograd F(2x2,3x3) for the '
-           f'head 3x3 convolutions) -- bench.py HIP events: {r["achieved"]} TFLOP/s EXECUTED on the matrix cores of {r["peak"]} '
-           f'(fp32 matrix) = {r["frac"]} (Winograd calls priced at their flops / 2.25); the ALGORITHMIC (direct-convolution) rate of the '
-           f'same launches is {r.get("effective_achieved")} TFLOP/s = {r.get("effective_frac")}; avg call {r["avg_launch_ms"]} ms, '
+           f'head 3x3 convolutions; fp32 operands as three bf16 terms, six products per fp32 product on the {r.get("pipe", "fp32")} '
+           f'matrix pipe) -- bench.py HIP events: {r["achieved"]} TFLOP/s EXECUTED on the matrix cores of {r["peak"]} '
+           f'({r.get("pipe", "fp32")} dense) = {r["frac"]} (Winograd calls priced at their flops / 2.25, split-operand calls at 6 bf16 '
+           f'flops per fp32 flop); the ALGORITHMIC (direct-convolution, fp32) rate of the same launches is '
+           f'{r.get("effective_achieved")} TFLOP/s = {r.get("effective_frac")} of that pipe\'s ceiling for fp32 products '
+           f'({r.get("effective_peak")} = peak / 6) and {r.get("vs_fp32_matrix_peak")} x the fp32 matrix pipe\'s 157.3; avg call '
+           f'{r["avg_launch_ms"]} ms, '
            f'{r["algorithmic_gflop_per_launch"]} algorithmic GFLOP/call, PMC traffic / algorithmic bytes = {r.get("traffic_ratio")} '
            f'({r["launches_per_step"]} convolution calls/step). rocprofv3 over the same kernels (incl. fix-up and Winograd transforms): '
            f'{nt_calls:.0f} main-kernel launches/step, {nt_ms:.2f} ms/step (avg {nt_ms / nt_calls:.4f} ms): direct {direct_ms:.2f} ms, '
            f'Winograd {wino_ms:.2f} ms. HBM traffic {traffic["hbm_bytes_per_launch"] / 1e6:.0f} MB/call (PMC).',
-           f'* MFMA-bound: weight gradient (`conv_tn_kernel` direct, `wino_wgrad_kernel` Winograd; with their reductions / transforms) -- '
+           f'* MFMA-bound: weight gradient (`conv_tn3_kernel` direct, `wino_wgrad3_kernel` Winograd; with their reductions / transforms) -- '
            f'the same algorithmic flops as the forward convolutions '
            f'({r["algorithmic_gflop_per_launch"] * r["launches_per_step"] / 2 / 1e3:.3f} TFLOP/step) in {tn_ms:.2f} ms = '
            f'{r["algorithmic_gflop_per_launch"] * r["launches_per_step"] / 2 / tn_ms:.1f} TFLOP/s.',

@@ -200,7 +200,7 @@ def conv_gemm(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bias=Non
             pix = sum(s.shape[0] * hw[0] * hw[1] for s, hw in zip(srcs, out_hw))
         else:
             pix = sum(s.shape[0] * s.shape[1] * s.shape[2] for s in srcs)
-        TIMER.time(('conv_nt_128x128' if n_out > 64 else 'conv_nt_128x64') + f'|m{mode} k{kh} s{stride} cs{cs} n{n_out} np{n} pix{pix} f{flags}',
+        TIMER.time(_nt_family(n_out) + f'|m{mode} k{kh} s{stride} cs{cs} n{n_out} np{n} pix{pix} f{flags}',
                    2.0 * pix * n_out * kh * kw * cs, launch,
                    nbytes=4.0 * (sum(t.numel() for t in srcs) + sum(o.numel() for o in outs) + w_packed.numel()))
     else:
@@ -237,7 +237,7 @@ def conv_gemm_bnbwd(src, w_packed, n_out, kh, kw, pad, out_hw, bn_y, bn_mean, bn
 
     if TIMER is not None:
         pix = nb * (src.shape[1] * src.shape[2] if mode == 1 else out_hw[0] * out_hw[1])
-        TIMER.time(('conv_nt_128x128' if n_out > 64 else 'conv_nt_128x64') + f'|m{mode} k{kh} s{stride} cs{cs} n{n_out} np1 pix{pix} f{flags | 256}',
+        TIMER.time(_nt_family(n_out) + f'|m{mode} k{kh} s{stride} cs{cs} n{n_out} np1 pix{pix} f{flags | 256}',
                    2.0 * pix * n_out * kh * kw * cs, launch,
                    nbytes=4.0 * (src.numel() + 2 * out.numel() + w_packed.numel()))
     else:
@@ -492,6 +492,14 @@ def _conv_gemm_bf16(srcs, w_packed, n_out, kh, kw, stride, pad, mode, out_hw, bi
 
 
 SHARE_ALONE = (3, 2, 3, 2, 0, 3, 1, 0)
+
+
+def _nt_family(n_out):
+    """Timer family of a sacv_conv2d_gemm call: the tile shape the fp32 planner would take, or (a trailing 3) the
+    128 x 64 split-operand kernel on the bf16 pipe (launch plan nt_split)."""
+    if _share[7]:
+        return 'conv_nt3_128x64'
+    return 'conv_nt_128x128' if n_out > 64 else 'conv_nt_128x64'
 _share = SHARE_ALONE
 
 
@@ -573,7 +581,7 @@ def conv_wgrad(dys, xs, dw, cin, kh, kw, stride, pad, accumulate=False, cin_pad=
     if TIMER is not None:  # algorithmic flops of the weight gradient (+ its slab reduction, same event pair)
         taps = dw_taps if dw_taps else kh * kw
         flops = 2.0 * sum(b * h * w for b, h, w in zip(nb, ho, wo)) * cout * cin * taps
-        TIMER.time(f'conv_tn|k{kh} s{stride} ci{cin} co{cout} np{n}', flops, launch)
+        TIMER.time(f'conv_tn{"3" if _share[7] else ""}|k{kh} s{stride} ci{cin} co{cout} np{n}', flops, launch)
     else:
         launch()
     return dw

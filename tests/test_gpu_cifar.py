@@ -66,9 +66,11 @@ def test_resnet18cifar_step_against_reference_fixture(golden_dir, name):
     assert l1['optimizer_steps'] == 2
     for k, p in net2.named_parameters():
         want = meta['param_norm_after2'][k]
-        # (a BatchNorm bias starts at 0: its norm after two steps IS its gradient, which this batch of 8 pins to ~1e-2
-        # in fp32 arithmetic -- the median gate above; round 4 measured 2.3e-3 on conv1's with the bf16-pipe kernels)
-        assert abs(float(p.detach().double().norm()) - want) <= 5e-3 * want + 2e-5, k
+        # A parameter that starts at 0 (BatchNorm biases, fc.bias) IS its gradient after two steps, and this batch of 8 pins
+        # gradients to ~1e-2 in fp32 arithmetic (the median gate above; 3e-2 per tensor): those get the gradient gate.
+        # Measured round 4 with the bf16-pipe kernels: 2.3e-3 (conv1's bias), 6.4e-3 (layer1.1.conv1's).
+        zero_init = k.endswith('layer.1.bias') or k == 'fc.bias'
+        assert abs(float(p.detach().double().norm()) - want) <= (2e-2 if zero_init else 2e-3) * want + 2e-5, k
     net2.eval()  # the fixture's eval logits: after both optimizer steps, BN running statistics of two forwards
     with torch.no_grad():
         ev = net2(x).cpu().numpy()

@@ -67,6 +67,7 @@ struct ConvProb {
 };
 
 struct ConvArgs {
+  int ks_log2;  // log2 of the K slab of the launched conv_nt variant (5; 4 for the 128 x 128 split-operand item)
   ConvProb p[SACV_MAXP];
   int nprob;
   int total_mtiles;
@@ -244,17 +245,23 @@ typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
 // against fp64 the results carry the error of the fp32 pipe (tests/test_gpu_kernels.py, test_gpu_winograd.py for the
 // same scheme in the Winograd GEMM).  Global traffic is unchanged (fp32 tensors), the LDS image is 1.5x the bytes:
 // [2 buffers][3 planes][rows][32 bf16], 16-byte chunks XOR-swizzled by (row >> 2) & 3 for the ds_read_b128 fragments.
-template <int BM, int BN, int MODE, int WN, int OCC = WN, bool SWZ = false, bool SP = false>
+// KS = K per slab: 32, or (SP only) 16 -- the 128 x 128 split-operand item: at the same LDS bytes as the 128 x 64 / K 32 item
+// it splits and gathers 2/3 of the operand elements per MFMA (PMC round 4: the SP kernels spend 40 % of their wave cycles
+// ISSUING instructions, the split and the gather addresses; matrix pipe busy 0.2).
+template <int BM, int BN, int MODE, int WN, int OCC = WN, bool SWZ = false, bool SP = false, int KS = 32>
 __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a) {
+  static_assert(KS == 32 || (SP && KS == 16), "16-deep slabs exist for the split-operand form only");
   constexpr int LS = SWZ ? 32 : 36;
   constexpr int NT = 128 * WN;                 // 2 x WN waves
-  constexpr int RPP = NT / 8;                  // tile rows fetched per pass (8 threads x 16 B per row)
+  constexpr int KQ = KS / 4;                   // threads per tile row (16 B = 4 K each)
+  constexpr int PR = KS / 2;                   // SP: floats per plane row (KS bf16)
+  constexpr int RPP = NT / KQ;                 // tile rows fetched per pass
   constexpr int RA = BM / RPP, RB = BN / RPP;
   constexpr int WTM = BM / 2, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;
-  float* sB = smem + (SP ? 2 * 3 * BM * 16 : 2 * BM * LS);
+  float* sB = smem + (SP ? 2 * 3 * BM * PR : 2 * BM * LS);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
   const int bid = blockIdx.x;
   const int Cs = a.Cs;
   const float* __restrict__ wgt = a.w;
-  const int cpt = (Cs + 31) >> 5;  // K tiles per tap (last one zero-padded when Cs % 32 != 0)
+  const int cpt = (Cs + KS - 1) / KS;  // K tiles per tap (last one zero-padded when Cs % KS != 0)
   const int KT = a.KH * a.KW * cpt;
   const int smask = (1 << a.stride_log2) - 1;
 
@@ -280,8 +287,8 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
   // checked to be < 2^30 elements) relative to wave-uniform base pointers, so a gather is a handful of
   // cheap VALU ops + one saddr global load: no 64-bit multiplies, no branches (both would fence the
   // scheduler and cluster ~100 issue cycles of address arithmetic between two MFMAs).
-  const int kq = tid & 7;
-  const int r0 = tid >> 3;
+  const int kq = tid % KQ;
+  const int r0 = tid / KQ;
   int hb[RA], wb[RA], rowoff[RA];
   int wrow[RB];
   bool wok[RB];
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
   bool lt_kok = false;
   auto load_begin = [&](int kt, bool enable) {
     int tap = kt / cpt;
-    lt_c0 = (kt - tap * cpt) << 5;
+    lt_c0 = (kt - tap * cpt) * KS;
     lt_kh = tap / a.KW;
     lt_kw = tap - lt_kh * a.KW;
     int rtap = (a.kh0 + a.khs * lt_kh) * a.KWr + (a.kw0 + a.kws * lt_kw);
@@ -409,15 +416,16 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
       m[e] = (cbf16)r1;
       l[e] = (cbf16)(r1 - (float)m[e]);  // exact difference, rounded once
     }
-    float* d = img + row * 16 + ((((kq >> 1) ^ ((row >> 2) & 3)) << 2) + ((kq & 1) << 1));
+    const int key = KS == 32 ? (row >> 2) & 3 : (row >> 3) & 1;  // swizzle of the 16-byte chunks (ds_read_b128 groups)
+    float* d = img + row * PR + ((((kq >> 1) ^ key) << 2) + ((kq & 1) << 1));
     *reinterpret_cast<cbf16x4*>(d) = h;
-    *reinterpret_cast<cbf16x4*>(d + rows * 16) = m;
-    *reinterpret_cast<cbf16x4*>(d + 2 * rows * 16) = l;
+    *reinterpret_cast<cbf16x4*>(d + rows * PR) = m;
+    *reinterpret_cast<cbf16x4*>(d + 2 * rows * PR) = l;
   };
   auto store_tile = [&](int buf) {
     if constexpr (SP) {
-      float* dA = sA + buf * 3 * BM * 16;
-      float* dB = sB + buf * 3 * BN * 16;
+      float* dA = sA + buf * 3 * BM * PR;
+      float* dB = sB + buf * 3 * BN * PR;
 #pragma unroll
       for (int i = 0; i < RA; ++i) put3(dA, BM, r0 + RPP * i, ra[i]);
 #pragma unroll
@@ -482,34 +490,36 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
       if (last && more) setup(sidx + 1);  // switch the gather state to the next segment
       load_begin(last ? k_begin : kt + 1, have_next && !SACV_ABL(1024));
       if constexpr (SP) {
-        const float* pA = sA + cur * 3 * BM * 16 + (wm0 + l31) * 16;
-        const float* pB = sB + cur * 3 * BN * 16 + (wn0 + l31) * 16;
-        const int k3 = (l31 >> 2) & 3;  // swizzle key of this lane's fragment rows (wm0, wn0, i * 32: multiples of 16)
-        cbf16x8 fa[2][3][TM], fb[2][3][TN];
-        // reads and products in one order -- K step, plane (hi, mid, lo), A blocks then B blocks -- so that the reads
-        // trickle in between the MFMAs; products per K step: hi.hi, mid.hi, hi.mid, mid.mid, lo.hi, hi.lo
+        constexpr int NKS = KS / 16;  // MFMA K steps per slab
+        const float* pA = sA + cur * 3 * BM * PR + (wm0 + l31) * PR;
+        const float* pB = sB + cur * 3 * BN * PR + (wn0 + l31) * PR;
+        // swizzle key of this lane's fragment rows (wm0, wn0, i * 32: multiples of 16)
+        const int k3 = KS == 32 ? (l31 >> 2) & 3 : (l31 >> 3) & 1;
+        cbf16x8 fa[NKS][3][TM], fb[NKS][3][TN];
         // the next slab's gathers first: the MFMA block of a slab is only 768 cycles per wave, all of it is needed to
         // cover the loads
 #pragma unroll
         for (int i = 0; i < RA; ++i) load_a(i);
 #pragma unroll
         for (int i = 0; i < RB; ++i) load_b(i);
+        // reads and products in one order -- K step, plane (hi, mid, lo), A blocks then B blocks -- so that the reads
+        // trickle in between the MFMAs; products per K step: hi.hi, mid.hi, hi.mid, mid.mid, lo.hi, hi.lo
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
           const int o = ((ks * 2 + lh) ^ k3) * 4;
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-              fa[ks][pl][i] = *reinterpret_cast<const cbf16x8*>(pA + pl * BM * 16 + i * 32 * 16 + o);
+              fa[ks][pl][i] = *reinterpret_cast<const cbf16x8*>(pA + pl * BM * PR + i * 32 * PR + o);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              fb[ks][pl][j] = *reinterpret_cast<const cbf16x8*>(pB + pl * BN * 16 + j * 32 * 16 + o);
+              fb[ks][pl][j] = *reinterpret_cast<const cbf16x8*>(pB + pl * BN * PR + j * 32 * PR + o);
           }
         }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < NKS; ++ks) {
           constexpr int pa[6] = {0, 1, 0, 1, 2, 0};
           constexpr int pb[6] = {0, 0, 1, 1, 0, 2};
 #pragma unroll
@@ -522,7 +532,7 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
         }
 #ifndef SACV_NO_SGB
         {
-          constexpr int NRD = 6 * (TM + TN), NMF = 12 * TM * TN, PRE = TM + TN + 1;
+          constexpr int NRD = NKS * 3 * (TM + TN), NMF = NKS * 6 * TM * TN, PRE = TM + TN + 1;
           __builtin_amdgcn_sched_group_barrier(0x100, PRE, 0);
 #pragma unroll
           for (int m = 0; m < NMF; ++m) {
@@ -664,7 +674,7 @@ __global__ __launch_bounds__(NT) void conv_fixup_kernel(const ConvArgs a) {
   const int rt = blockIdx.x / QS;
   const int qrow = (blockIdx.x % QS) * (BM / QS);  // first tile row of this workgroup
   const int ntn = (a.N + BN - 1) / BN;
-  const int KT = a.KH * a.KW * ((a.Cs + 31) >> 5);
+  const int KT = a.KH * a.KW * ((a.Cs + (1 << a.ks_log2) - 1) >> a.ks_log2);
   const int tile = a.base * a.grid + rt;
   // blocks whose ranges hold the first and the last K-iteration of this tile
   const int u_first = rt * KT, u_last = u_first + KT - 1;
@@ -1457,26 +1467,27 @@ static int nt_slots_split() {
   return cus * per_cu;
 }
 
-template <int BM, int BN, int MODE, int WN, int OCC = SACV_NT_BLOCKS_PER_CU, bool SWZ = false, bool SP = false>
+template <int BM, int BN, int MODE, int WN, int OCC = SACV_NT_BLOCKS_PER_CU, bool SWZ = false, bool SP = false, int KS = 32>
 static int launch_nt(ConvArgs& a, const NtPlan& plan, float* workspace, hipStream_t st) {
+  a.ks_log2 = KS == 32 ? 5 : 4;
   int grid = SP ? nt_slots_split() : nt_slots(BN);
   a.grid = grid;
   a.base = plan.base;
   a.rem_tiles = plan.rem;
   a.sk_blocks = plan.sk_blocks;
   a.partial = workspace;
-  size_t lds = SP ? (size_t)2 * 3 * (BM + BN) * 16 * sizeof(float) : (size_t)2 * (BM + BN) * (SWZ ? 32 : 36) * sizeof(float);
+  size_t lds = SP ? (size_t)2 * 3 * (BM + BN) * (KS / 2) * sizeof(float) : (size_t)2 * (BM + BN) * (SWZ ? 32 : 36) * sizeof(float);
   size_t lds_epi = ((size_t)BM * (BN + 4) + 2 * (128 * WN / (BN / 4)) * BN) * sizeof(float);
   if (lds_epi > lds) lds = lds_epi;
   static std::once_flag attr_once;  // one per template instance; lds is a compile-time function of it
   std::call_once(attr_once, [lds] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN, MODE, WN, OCC, SWZ, SP>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_kernel<BM, BN, MODE, WN, OCC, SWZ, SP, KS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   int launch_blocks = a.base > 0 ? grid : a.sk_blocks;
   SACV_CHECK_ARG(a.sk_blocks <= grid && (a.sk_blocks == 0 || a.sk_blocks >= a.rem_tiles),
                  "conv2d_gemm: stream-K plan outside the workspace (%d ranges)", a.sk_blocks);
-  hipLaunchKernelGGL((conv_nt_kernel<BM, BN, MODE, WN, OCC, SWZ, SP>), dim3(launch_blocks), dim3(128 * WN), lds, st, a);
+  hipLaunchKernelGGL((conv_nt_kernel<BM, BN, MODE, WN, OCC, SWZ, SP, KS>), dim3(launch_blocks), dim3(128 * WN), lds, st, a);
   SACV_CHECK_LAUNCH("conv_nt_kernel");
   if (a.sk_blocks > a.rem_tiles) {
     if (a.flags & (CF_STATS | CF_BNBWD))
@@ -1672,6 +1683,15 @@ static int conv2d_gemm_impl(int nprob, const float* const* src, float* const* ds
 #endif
   NtPlan p64 = plan_nt(tiles * ((N + 63) / 64), KT, nt_slots(64), ws, mode == 1 ? SACV_W64_DGRAD : 0.8);
   if (sacv_share.nt_split) {
+#ifndef SACV_SP_WIDE_MIN_N
+#define SACV_SP_WIDE_MIN_N 128  // outputs from which the split-operand form takes 128 x 128 items (K 16 slabs)
+#endif
+    if (N >= SACV_SP_WIDE_MIN_N) {
+      const int KT16 = KH * KW * ((Cs + 15) / 16);
+      NtPlan pw = plan_nt(tiles * ((N + 127) / 128), KT16, nt_slots_split(), ws, 1.0);
+      return mode == 0 ? launch_nt<128, 128, 0, 2, 2, true, true, 16>(a, pw, workspace, st)
+                       : launch_nt<128, 128, 1, 2, 2, true, true, 16>(a, pw, workspace, st);
+    }
     NtPlan ps = plan_nt(tiles * ((N + 63) / 64), KT, nt_slots_split(), ws, 1.0);
     return mode == 0 ? launch_nt<128, 64, 0, 2, 2, true, true>(a, ps, workspace, st)
                      : launch_nt<128, 64, 1, 2, 2, true, true>(a, ps, workspace, st);

@@ -233,8 +233,33 @@ __device__ __forceinline__ int sk_range_begin(const ConvArgs& a, int KT, int b) 
 // XOR-swizzled by key (row >> 1) & 7 (exact for the lane groups of ds_read_b128, as in winograd.hip) instead of rows
 // padded to 36 floats: the 128 x 64 variant then needs 48 KB and three workgroups fit a CU.
 typedef __bf16 cbf16;
+typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 cbf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+typedef float cf32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int cu32x2 __attribute__((ext_vector_type(2)));
+
+// x = hi + mid + lo for TWO fp32 values at a time, the terms packed as bf16 pairs: v_cvt_pk_bf16_f32 rounds both, the
+// pair goes back to fp32 with one shift and one mask, v_pk_add_f32 takes both residuals -- 9 vector instructions per pair
+// (element-wise code compiled to 15: PMC round 4 showed the split-operand kernels bound by instruction ISSUE).
+__device__ __forceinline__ void split3_pair(const cf32x2 x, unsigned& h, unsigned& m, unsigned& l) {
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(x, cbf16x2));
+  const cf32x2 hf = {__builtin_bit_cast(float, h << 16), __builtin_bit_cast(float, h & 0xffff0000u)};
+  const cf32x2 r1 = x - hf;  // exact
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, cbf16x2));
+  const cf32x2 mf = {__builtin_bit_cast(float, m << 16), __builtin_bit_cast(float, m & 0xffff0000u)};
+  const cf32x2 r2 = r1 - mf;  // exact difference, rounded once below
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, cbf16x2));
+}
+// 4 consecutive values -> the three 8-byte plane pieces
+__device__ __forceinline__ void split3_quad(const f32x4 v, cu32x2& h, cu32x2& m, cu32x2& l) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  split3_pair(cf32x2{v[0], v[1]}, h0, m0, l0);
+  split3_pair(cf32x2{v[2], v[3]}, h1, m1, l1);
+  h = cu32x2{h0, h1};
+  m = cu32x2{m0, m1};
+  l = cu32x2{l0, l1};
+}
 
 // SP (split operands, round 4): the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, 157 TFLOP/s) bounds this kernel; the
 // bf16 pipe is 16x faster.  With SP the gathered fp32 values are split WHEN THEY ARE STORED TO LDS into three bf16 terms,
@@ -408,19 +433,13 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
   };
   // SP: 4 consecutive K of one row -> three 8-byte stores (planes hi, mid, lo)
   auto put3 = [&](float* img, int rows, int row, const f32x4 v) {
-    cbf16x4 h, m, l;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      h[e] = (cbf16)v[e];
-      const float r1 = v[e] - (float)h[e];  // exact
-      m[e] = (cbf16)r1;
-      l[e] = (cbf16)(r1 - (float)m[e]);  // exact difference, rounded once
-    }
+    cu32x2 h, m, l;
+    split3_quad(v, h, m, l);
     const int key = KS == 32 ? (row >> 2) & 3 : (row >> 3) & 1;  // swizzle of the 16-byte chunks (ds_read_b128 groups)
     float* d = img + row * PR + ((((kq >> 1) ^ key) << 2) + ((kq & 1) << 1));
-    *reinterpret_cast<cbf16x4*>(d) = h;
-    *reinterpret_cast<cbf16x4*>(d + rows * PR) = m;
-    *reinterpret_cast<cbf16x4*>(d + 2 * rows * PR) = l;
+    *reinterpret_cast<cu32x2*>(d) = h;
+    *reinterpret_cast<cu32x2*>(d + rows * PR) = m;
+    *reinterpret_cast<cu32x2*>(d + 2 * rows * PR) = l;
   };
   auto store_tile = [&](int buf) {
     if constexpr (SP) {
@@ -1046,18 +1065,12 @@ __global__ __launch_bounds__(256, 2) void conv_tn3_kernel(const WgradArgs a) {
   };
   // 4 consecutive channels of one pixel row -> three 8-byte stores (planes hi, mid, lo)
   auto put3 = [&](unsigned char* img, int rs, int row, int col, const f32x4 v) {
-    cbf16x4 h, m, l;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      h[e] = (cbf16)v[e];
-      const float r1 = v[e] - (float)h[e];
-      m[e] = (cbf16)r1;
-      l[e] = (cbf16)(r1 - (float)m[e]);
-    }
+    cu32x2 h, m, l;
+    split3_quad(v, h, m, l);
     unsigned char* d = img + row * rs + col * 2;
-    *reinterpret_cast<cbf16x4*>(d) = h;
-    *reinterpret_cast<cbf16x4*>(d + KR * rs) = m;
-    *reinterpret_cast<cbf16x4*>(d + 2 * KR * rs) = l;
+    *reinterpret_cast<cu32x2*>(d) = h;
+    *reinterpret_cast<cu32x2*>(d + KR * rs) = m;
+    *reinterpret_cast<cu32x2*>(d + 2 * KR * rs) = l;
   };
   auto store_tile = [&](int buf) {
 #pragma unroll

@@ -69,6 +69,12 @@ class _StepDriver:
                              "communicator object with RcclComm's all_reduce / wait / broadcast")
         self.exchanger = GradExchanger(arena.grads, stage_ranges(arena.order, arena.offsets, arena.numel, arena.split),
                                        process_group, comm=self.comm)
+        if self.world > 1:
+            # the collective's kernels share the chip with the backward pass: the persistent convolution grids plan for 224
+            # of the 256 CUs there (free on one GPU, and it takes the stand-in collective's 0.3 ms away)
+            engine = getattr(model, 'engine', None)
+            if engine is not None and getattr(engine, 'BWD_SHARE', 0) is None:
+                engine.BWD_SHARE = (3, 2, 3, 2, 32)
         if self.world > 1:  # DDP init_sync: every rank starts from rank 0's parameters and buffers
             if self.comm is not None:
                 self.comm.broadcast(arena.params, 0)

@@ -232,6 +232,9 @@ __device__ __forceinline__ int sk_range_begin(const ConvArgs& a, int KT, int b) 
 // OCC = workgroups per CU the launch bounds allow for; SWZ = unpadded LDS rows (32 floats) with the 16-byte chunks
 // XOR-swizzled by key (row >> 1) & 7 (exact for the lane groups of ds_read_b128, as in winograd.hip) instead of rows
 // padded to 36 floats: the 128 x 64 variant then needs 48 KB and three workgroups fit a CU.
+#ifndef SACV_SP_XCD_ORDER
+#define SACV_SP_XCD_ORDER 0  // measured neutral with the split-operand kernels too (23.20 vs 23.19 ms, three pairs)
+#endif
 typedef __bf16 cbf16;
 typedef __bf16 cbf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 cbf16x4 __attribute__((ext_vector_type(4)));
@@ -328,6 +331,13 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
       // plain round-robin.  (An XCD-contiguous order -- each XCD taking grid/8 consecutive tiles per
       // round -- was measured: +2 % on a single large problem, -7 % on the grouped head launches.)
       tile = bid + sidx * a.grid;
+      if (SP && SACV_SP_XCD_ORDER && ((a.base * a.grid) & 7) == 0) {
+        // XCD-contiguous order for the split-operand kernels: workgroup b runs on XCD b % 8; every XCD takes a contiguous
+        // range of the whole tiles, so the N tiles of one M tile (same activation rows) meet in one L2 at about the
+        // same time.  (For the fp32-pipe kernels, bound by the matrix pipe, this order measured +2 % / -7 %: round 1.)
+        const int per = (a.base * a.grid) >> 3;  // a bijection of [0, base * grid) when that is a multiple of 8
+        tile = (tile & 7) * per + (tile >> 3);
+      }
       k_begin = 0;
       k_end = KT;
       slot = -1;

@@ -418,7 +418,8 @@ class DetectorEngine:
         if (self.wino_trunk_wgrad and self._use_wino() and c.k == 3 and c.stride == 1 and c.pad == 1 and cin >= 128
                 and ops.wino_wgrad_supported(cin) and dy.shape[3] >= 128):
             def launch():
-                ops.wino_wgrad([dy], ops.wino_input([c.x], tag='wino_vx', split=self.wino_split), dw, cin)
+                ops.wino_wgrad([dy], ops.wino_input([c.x], tag='wino_vx', split=self.wino_split and self.wino_wgrad_split),
+                               dw, cin)
             return self._on_side(launch, [dy, c.x])
         self._wgrad([dy], [c.x], dw, cin, c.k, c.k, c.stride, c.pad)
 
@@ -707,6 +708,8 @@ class DetectorEngine:
     # values are stored to LDS, nothing changes in memory).  It is part of the calling thread's launch plan
     # (ops.launch_share(nt_split=...)); forward() / backward() set it from this attribute.
     conv_split = True
+    # Winograd weight gradients on the bf16 pipe too (False: the fp32-pipe kernel; a kept split V is rebuilt exactly)
+    wino_wgrad_split = True
 
     def _apply_plan(self):
         if not self.amp and ops.current_share()[7] != int(self.conv_split):
@@ -798,7 +801,7 @@ class DetectorEngine:
     def _wino_wgrad(self, dys, xs, v, dw, cin, sync=True):
         """3x3 weight gradient: Winograd path from the kept V when the channel count allows it, else conv_tn."""
         if v is not None and ops.wino_wgrad_supported(cin) and dys[0].shape[3] >= 64:
-            self._on_side(lambda: ops.wino_wgrad(dys, v, dw, cin), list(dys) + [v], sync=sync)
+            self._on_side(lambda: ops.wino_wgrad(dys, v, dw, cin, exact=not self.wino_wgrad_split), list(dys) + [v], sync=sync)
         else:
             self._wgrad(dys, xs, dw, cin, 3, 3, 1, 1, sync=sync)
 

@@ -64,6 +64,9 @@ def detection_predict_fn(model, decoder, criterion=None):
     from .detection.common import eval_postprocess
 
     def predict(batch):
+        if getattr(model, 'training', False):
+            raise RuntimeError('evaluation needs model.eval(): in train mode BatchNorm would use batch statistics '
+                               '(tools/scripts.py calls model.eval() before its evaluation loop)')
         images = batch['image']
         if not images.is_cuda:
             images = images.cuda(non_blocking=True)
@@ -96,7 +99,10 @@ def evaluate_coco_detection(test_loader, predict, image_ids, coco_label_to_cat_i
     if hasattr(test_loader, '__getitem__'):
         stream = ((i, test_loader[i]) for i in sorted(mine))
     else:
-        stream = ((i, b) for i, b in enumerate(test_loader) if i in mine)  # other ranks' batches are skipped unloaded
+        # a plain iterable (e.g. a DataLoader) still LOADS every batch on every rank -- only the inference of the
+        # non-owned ones is skipped; pass an indexable loader (or one built on a sampler over shard_batches) to shard the
+        # host work too
+        stream = ((i, b) for i, b in enumerate(test_loader) if i in mine)
     for i, batch in stream:
         indices = list(range(i * batch_size, min((i + 1) * batch_size, n_images)))
         scores, classes, boxes, loss = predict(batch)

@@ -135,7 +135,15 @@ class EmaModel:
         return self.ema_model.state_dict()
 
     def load_state_dict(self, sd):
+        """Accepts the reference's checkpoint layout too: there ema_model.ema_model is wrapped in DistributedDataParallel
+        (tools/utils.py:172-177), so the keys of latest.pth['ema_model_state_dict'] carry a 'module.' prefix."""
+        if sd and all(k.startswith('module.') for k in sd):
+            sd = {k[len('module.'):]: v for k, v in sd.items()}
         return self.ema_model.load_state_dict(sd)
+
+    def reference_state_dict(self):
+        """state_dict() with the 'module.' prefix of the reference's DDP-wrapped EMA model (what its train script saves)."""
+        return {'module.' + k: v for k, v in self.ema_model.state_dict().items()}
 
 
 def build_trainer(config, model, criterion, process_group=None, transport='torch'):

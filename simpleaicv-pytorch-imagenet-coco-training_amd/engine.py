@@ -104,8 +104,10 @@ class DetectorEngine:
             self._side = None
         elif self._side is None:
             # (the launch stream at high priority: 27.82 -> 27.62 ms; not adopted)
-            self._side = torch.cuda.Stream(priority=self.SIDE_PRIORITY)
-            self._side_events = [torch.cuda.Event() for _ in range(64)]
+            dev = next(iter(self.p.values())).device if self.p else None  # the PARAMETERS' device, not the current one
+            with torch.cuda.device(dev):
+                self._side = torch.cuda.Stream(device=dev, priority=self.SIDE_PRIORITY)
+                self._side_events = [torch.cuda.Event() for _ in range(64)]
 
     SIDE_PRIORITY = 0  # HIP priority of the weight gradients' stream (lower number = served first)
 
@@ -712,6 +714,13 @@ class DetectorEngine:
     wino_wgrad_split = True
 
     def _apply_plan(self):
+        # every launch goes to the CURRENT device's current stream (ops._stream): a model on another device than the
+        # current one would enqueue on the wrong stream -- one process drives one GPU (torch.cuda.set_device first)
+        if self.p:
+            d = next(iter(self.p.values())).device
+            if d.type == 'cuda' and d.index is not None and d.index != torch.cuda.current_device():
+                raise RuntimeError(f'the model is on {d} but the current device is cuda:{torch.cuda.current_device()}: '
+                                   'call torch.cuda.set_device() before building / running the model')
         if not self.amp and ops.current_share()[7] != int(self.conv_split):
             ops.launch_share(nt_split=int(self.conv_split))
 

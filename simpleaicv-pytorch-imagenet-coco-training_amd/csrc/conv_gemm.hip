@@ -21,7 +21,6 @@
 // LDS image [row][36] floats: ds_write_b128 per 8-lane row group and ds_read_b128 per lane are
 // both bank-conflict free (row stride 36 dwords = 9 x 16 B, 9 odd).
 #include "sacv_common.h"
-#include <type_traits>
 #include <mutex>
 #include <stdlib.h>
 
@@ -233,9 +232,6 @@ __device__ __forceinline__ int sk_range_begin(const ConvArgs& a, int KT, int b) 
 // OCC = workgroups per CU the launch bounds allow for; SWZ = unpadded LDS rows (32 floats) with the 16-byte chunks
 // XOR-swizzled by key (row >> 1) & 7 (exact for the lane groups of ds_read_b128, as in winograd.hip) instead of rows
 // padded to 36 floats: the 128 x 64 variant then needs 48 KB and three workgroups fit a CU.
-#ifndef SACV_SP_SGB_VALU
-#define SACV_SP_SGB_VALU 5  // vector instructions scheduled after each MFMA of the split-operand block
-#endif
 #ifndef SACV_SP_XCD_ORDER
 #define SACV_SP_XCD_ORDER 0  // measured neutral with the split-operand kernels too (23.20 vs 23.19 ms, three pairs)
 #endif
@@ -396,7 +392,7 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
     }
   };
 
-  f32x4 ra[2][RA], rb[2][RB];  // gathered slab(s): the fp32-pipe kernel uses set 0; the split-operand kernel both (two deep)
+  f32x4 ra[RA], rb[RB];
   // coordinates of the K slab being fetched (wave-uniform)
   int lt_c0 = 0, lt_kh = 0, lt_kw = 0, lt_aoff = 0, lt_boff = 0;
   bool lt_kok = false;
@@ -411,7 +407,7 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
     lt_aoff = (MODE == 0 ? (lt_kh * Ws + lt_kw) : -(lt_kh * Ws + lt_kw)) * Cs + lt_c0;
     lt_kok = enable && ((lt_c0 + kq * 4) < Cs);
   };
-  auto load_a = [&](int i, int p = 0) {
+  auto load_a = [&](int i) {
     bool ok;
     int off;
     if (MODE == 0) {
@@ -431,12 +427,12 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
     }
     ok = ok && lt_kok;
     const float* ptr = ok ? src + (unsigned)off : sacv_zero16;
-    ra[p][i] = *reinterpret_cast<const f32x4*>(ptr);
+    ra[i] = *reinterpret_cast<const f32x4*>(ptr);
   };
-  auto load_b = [&](int i, int p = 0) {
+  auto load_b = [&](int i) {
     bool ok = wok[i] && lt_kok;
     const float* ptr = ok ? wgt + (unsigned)(wrow[i] + lt_boff) : sacv_zero16;
-    rb[p][i] = *reinterpret_cast<const f32x4*>(ptr);
+    rb[i] = *reinterpret_cast<const f32x4*>(ptr);
   };
   auto load_tile = [&](int kt) {
     load_begin(kt, true);
@@ -455,24 +451,24 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
     *reinterpret_cast<cu32x2*>(d + rows * PR) = m;
     *reinterpret_cast<cu32x2*>(d + 2 * rows * PR) = l;
   };
-  auto store_tile = [&](int buf, int p = 0) {
+  auto store_tile = [&](int buf) {
     if constexpr (SP) {
       float* dA = sA + buf * 3 * BM * PR;
       float* dB = sB + buf * 3 * BN * PR;
 #pragma unroll
-      for (int i = 0; i < RA; ++i) put3(dA, BM, r0 + RPP * i, ra[p][i]);
+      for (int i = 0; i < RA; ++i) put3(dA, BM, r0 + RPP * i, ra[i]);
 #pragma unroll
-      for (int i = 0; i < RB; ++i) put3(dB, BN, r0 + RPP * i, rb[p][i]);
+      for (int i = 0; i < RB; ++i) put3(dB, BN, r0 + RPP * i, rb[i]);
       return;
     }
     float* dA = sA + buf * BM * LS;
     float* dB = sB + buf * BN * LS;
 #pragma unroll
     for (int i = 0; i < RA; ++i)
-      *reinterpret_cast<f32x4*>(dA + (r0 + RPP * i) * LS + (SWZ ? ((kq ^ (((r0 + RPP * i) >> 1) & 7)) << 2) : kq * 4)) = ra[0][i];
+      *reinterpret_cast<f32x4*>(dA + (r0 + RPP * i) * LS + (SWZ ? ((kq ^ (((r0 + RPP * i) >> 1) & 7)) << 2) : kq * 4)) = ra[i];
 #pragma unroll
     for (int i = 0; i < RB; ++i)
-      *reinterpret_cast<f32x4*>(dB + (r0 + RPP * i) * LS + (SWZ ? ((kq ^ (((r0 + RPP * i) >> 1) & 7)) << 2) : kq * 4)) = rb[0][i];
+      *reinterpret_cast<f32x4*>(dB + (r0 + RPP * i) * LS + (SWZ ? ((kq ^ (((r0 + RPP * i) >> 1) & 7)) << 2) : kq * 4)) = rb[i];
   };
 
   f32x16 acc[TM][TN];
@@ -499,88 +495,45 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
   // break the lockstep of the two workgroups of a CU was measured: no effect, they re-synchronise)
   // (the same stagger restricted to short-K, store-heavy 1x1 problems -- odd workgroups sleeping 3-14 us first --
   // only adds the delay: 78 -> 81..91 us)
-  // accumulators -> LDS [BM][BN+4] -> 16-byte row-major stores (finished tile: fused epilogue; K-slice of a split tile:
-  // row-major slab for the fix-up kernel)
-  auto finish_tile = [&](const TileCoord& my_tc, int my_slot, int my_tile) {
-    constexpr int CS = BN + 4;
-    float* stage = smem;
+  setup(0);
+  load_tile(k_begin);
+  store_tile(0);
+  __syncthreads();
+  SACV_STAMP_HERE();
+  int cur = 0;
+  for (int sidx = 0; sidx < nseg; ++sidx) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          stage[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CS + wn0 + j * 32 + l31] = acc[i][j][r];
-    __syncthreads();
-    if (my_slot < 0) {
-      const int ntn = (a.N + BN - 1) / BN;
-      vec_epilogue<BM, BN, NT>(
-          a, my_tc, my_tile / ntn,
-          [&](int row, int c4) { return *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4); },
-          smem + BM * CS);
-    } else {
-      float* dst = a.partial + (size_t)my_slot * (BM * BN);
-      constexpr int CG = BN / 4, RS = NT / CG;
-      const int c4 = tid % CG, rr = tid / CG;
-#pragma unroll 4
-      for (int row = rr; row < BM; row += RS)
-        *reinterpret_cast<f32x4*>(dst + row * BN + c4 * 4) =
-            *reinterpret_cast<const f32x4*>(stage + row * CS + c4 * 4);
-    }
-  };
-
-  if constexpr (SP) {
-    // Split-operand main loop, TWO slabs deep in registers: while slab q multiplies, slab q + 1 (gathered during slab
-    // q - 1, so it has arrived) is split into its bf16 terms and stored to the other LDS buffer BETWEEN the MFMAs, and the
-    // gathers of slab q + 2 are in flight.  (One deep, the split ran after the MFMA block on data that had just been
-    // requested: PMC round 4, 0.3-0.4 of the wave cycles parked on the loads, 0.3-0.4 issuing the split, matrix pipe
-    // busy 0.2.)  Slab number seq (counted over the workgroup's segments) lives in register set seq & 1.
-    constexpr int NKS = KS / 16;  // MFMA K steps per slab
-    const int k3 = KS == 32 ? (l31 >> 2) & 3 : (l31 >> 3) & 1;  // swizzle key of this lane's fragment rows
-    setup(0);
-    load_begin(k_begin, true);
-#pragma unroll
-    for (int i = 0; i < RA; ++i) load_a(i, 0);
-#pragma unroll
-    for (int i = 0; i < RB; ++i) load_b(i, 0);
-    int cur = 0, seq = 0;
-    for (int sidx = 0; sidx < nseg; ++sidx) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-      const TileCoord my_tc = tc;
-      const int my_slot = slot, my_tile = cur_tile;
-      const int kb = k_begin, ke = k_end;
-      const bool more = (sidx + 1) < nseg;
-      // gathers of the slab after kcur + 1 into register set p: the next slab of this segment, or the first slab of
-      // the next segment (its gather state is set up here: tc / slot / k range of THIS segment were copied above)
-      auto issue_after = [&](int kcur, int p) {
-        const int kn = kcur + 2;
-        if (kn < ke) {
-          load_begin(kn, true);
-        } else if (kn == ke && more) {
-          setup(sidx + 1);
-          load_begin(k_begin, true);
-        } else {
-          return;
-        }
-#pragma unroll
-        for (int i = 0; i < RA; ++i) load_a(i, p);
-#pragma unroll
-        for (int i = 0; i < RB; ++i) load_b(i, p);
-      };
-      auto slab = [&](auto PC, int kt) {
-        constexpr int P = decltype(PC)::value;
-        const bool last = kt + 1 == ke;
-        issue_after(kt, P);  // set P held slab kt, which is in LDS
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const TileCoord my_tc = tc;
+    const int my_slot = slot;
+    const int my_tile = cur_tile;
+    const int kb = k_begin, ke = k_end;
+    const bool more = (sidx + 1) < nseg;
+    for (int kt = kb; kt < ke; ++kt) {
+      const bool last = (kt + 1 == ke);
+      const bool have_next = !last || more;
+      if (last && more) setup(sidx + 1);  // switch the gather state to the next segment
+      load_begin(last ? k_begin : kt + 1, have_next && !SACV_ABL(1024));
+      if constexpr (SP) {
+        constexpr int NKS = KS / 16;  // MFMA K steps per slab
         const float* pA = sA + cur * 3 * BM * PR + (wm0 + l31) * PR;
         const float* pB = sB + cur * 3 * BN * PR + (wn0 + l31) * PR;
+        // swizzle key of this lane's fragment rows (wm0, wn0, i * 32: multiples of 16)
+        const int k3 = KS == 32 ? (l31 >> 2) & 3 : (l31 >> 3) & 1;
         cbf16x8 fa[NKS][3][TM], fb[NKS][3][TN];
-        // reads and products in one order -- K step, plane (hi, mid, lo), A blocks then B blocks; products per K step:
-        // hi.hi, mid.hi, hi.mid, mid.mid, lo.hi, hi.lo
+        // the next slab's gathers first: the MFMA block of a slab is only 768 cycles per wave, all of it is needed to
+        // cover the loads
+#pragma unroll
+        for (int i = 0; i < RA; ++i) load_a(i);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) load_b(i);
+        // reads and products in one order -- K step, plane (hi, mid, lo), A blocks then B blocks -- so that the reads
+        // trickle in between the MFMAs; products per K step: hi.hi, mid.hi, hi.mid, mid.mid, lo.hi, hi.lo
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
           const int o = ((ks * 2 + lh) ^ k3) * 4;
@@ -606,71 +559,23 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_nt_kernel(const ConvArgs a
               for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][pa[t6]][i], fb[ks][pb[t6]][j], acc[i][j], 0, 0, 0);
         }
-        // the next slab of this segment: split + store under the MFMAs (the first slab of the NEXT segment stays in its
-        // registers across the epilogue, which needs the LDS)
-        if (!last) store_tile(cur ^ 1, P ^ 1);
 #ifndef SACV_NO_SGB
         {
           constexpr int NRD = NKS * 3 * (TM + TN), NMF = NKS * 6 * TM * TN, PRE = TM + TN + 1;
-          constexpr int NWR = 3 * (RA + RB);  // plane stores of a slab (two 8-byte pieces each at most)
           __builtin_amdgcn_sched_group_barrier(0x100, PRE, 0);
 #pragma unroll
           for (int m = 0; m < NMF; ++m) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        // 1 MFMA
-            if (m < NRD - PRE) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 LDS read
-            __builtin_amdgcn_sched_group_barrier(0x002, SACV_SP_SGB_VALU, 0);         // split / address VALU
-            if (m >= NMF / 4 && m < NMF / 4 + NWR) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // 1 LDS write
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         // 1 MFMA
+            if (m < NRD - PRE) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 LDS read
           }
         }
 #endif
+        __builtin_amdgcn_s_setprio(0);
+        if (!last) store_tile(cur ^ 1);
         __syncthreads();
         cur ^= 1;
-      };
-      // prologue of the segment: its first slab sits in set seq & 1 -- fetch the slab after it, then split + store
-      if (sidx > 0) __syncthreads();  // the previous tile's stage has been consumed
-      if (seq & 1) {
-        issue_after(kb - 1, 0);
-        store_tile(0, 1);
-      } else {
-        issue_after(kb - 1, 1);
-        store_tile(0, 0);
+        continue;
       }
-      __syncthreads();
-      cur = 0;
-      for (int kt = kb; kt < ke; ++kt, ++seq) {
-        if (seq & 1)
-          slab(std::integral_constant<int, 1>{}, kt);
-        else
-          slab(std::integral_constant<int, 0>{}, kt);
-      }
-      finish_tile(my_tc, my_slot, my_tile);
-    }
-    return;
-  }
-
-  setup(0);
-  load_tile(k_begin);
-  store_tile(0);
-  __syncthreads();
-  SACV_STAMP_HERE();
-  int cur = 0;
-  for (int sidx = 0; sidx < nseg; ++sidx) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const TileCoord my_tc = tc;
-    const int my_slot = slot;
-    const int my_tile = cur_tile;
-    const int kb = k_begin, ke = k_end;
-    const bool more = (sidx + 1) < nseg;
-    for (int kt = kb; kt < ke; ++kt) {
-      const bool last = (kt + 1 == ke);
-      const bool have_next = !last || more;
-      if (last && more) setup(sidx + 1);  // switch the gather state to the next segment
-      load_begin(last ? k_begin : kt + 1, have_next && !SACV_ABL(1024));
       const float* cA = sA + (SACV_ABL(8192) ? 0 : cur * BM * LS + (wm0 + l31) * LS + (SWZ ? 0 : 4 * lh));
       const float* cB = sB + (SACV_ABL(8192) ? 0 : cur * BN * LS + (wn0 + l31) * LS + (SWZ ? 0 : 4 * lh));
       // float offset of the 16-byte chunk (2 * quarter + lh) of this lane's fragment row (wm0, wn0, i * 32: multiples of 16)

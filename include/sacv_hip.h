@@ -14,7 +14,7 @@
  *   - return 0 on success, negative on error (-1 bad argument, -2 launch failure,
  *     -3 unsupported); sacv_last_error() returns the message for the calling thread;
  *   - the shared object exports exactly the functions declared here (-fvisibility=hidden + csrc/exports.map;
- *     tests/test_abi.py compares the dynamic symbol table with this file).  sacv_abi_version() == 4.
+ *     tests/test_abi.py compares the dynamic symbol table with this file).  sacv_abi_version() == 5.
  *
  * Where the symbol list of SURVEY.md 8(b) went (it was written before the kernels; arguments are positional scalars
  * and pointers here, not `const sacv_<op>_args*` records -- every call site is a ctypes call, a record would be packed
@@ -446,6 +446,19 @@ int sacv_bn_apply_bf16(const void* y, const float* mean, const float* invstd_or_
 int sacv_bn_train_bwd_bf16(const void* dz, const void* zmask, const void* y, const float* mean, const float* invstd,
                            const float* gamma, const float* beta, void* dy, void* g_out, float* dgamma, float* dbeta,
                            int R, int C, int accumulate, float* workspace, void* stream);
+/* bf16 twins of sacv_conv2d_gemm_bnbwd / sacv_bn_train_bwd_partial (round 4): one data-gradient launch (mode 1, stride 1:
+ * the data gradient of the NEXT layer in forward order) whose bf16 output dz [M][N] is the upstream gradient of the BatchNorm (+ ReLU) layer
+ * with input bn_y also writes that layer's backward first-stage sums, stats[ceil(M / 128)][2][N] = (sum g, sum g * xhat)
+ * over the rounded values it stores; flags SACV_CF_BIAS / SACV_CF_ACCUM.  Mask from bn_z, or recomputed from y (bn_gamma,
+ * bn_beta) when bn_z is NULL, no mask when both are NULL. */
+int sacv_conv2d_gemm_bf16_bnbwd(const void* src, void* dst, int Nb, int Hs, int Ws, int Hd, int Wd, const void* w,
+                                const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode,
+                                int flags, float* stats, const void* bn_y, const void* bn_z, const float* bn_mean,
+                                const float* bn_invstd, const float* bn_gamma, const float* bn_beta, void* stream);
+int sacv_bn_train_bwd_partial_bf16(const void* dz, const void* zmask, const void* y, const float* mean,
+                                   const float* invstd, const float* gamma, const float* beta, void* dy, void* g_out,
+                                   float* dgamma, float* dbeta, int R, int C, int accumulate, const float* partial,
+                                   int nparts, float* workspace, void* stream);
 int sacv_maxpool_fwd_bf16(const void* x, void* y, unsigned char* idx, int Nb, int H, int W, int C, int Ho, int Wo,
                           int k, int s, int p, void* stream);
 int sacv_maxpool_bwd_bf16(const void* dy, const unsigned char* idx, void* dx, int Nb, int H, int W, int C, int Ho,

@@ -102,6 +102,8 @@ SIGNATURES = {
     'sacv_im2col_stem_bf16': (I, [P, P, I, I, I, I, LL, LL, LL, LL, I, I, I, I, I, I, I, P]),
     'sacv_bn_apply_bf16': (I, [P, P, P, P, P, P, P, LL, I, I, I, F, P]),
     'sacv_bn_train_bwd_bf16': (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, P]),
+    'sacv_bn_train_bwd_partial_bf16': (I, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, P, I, P, P]),
+    'sacv_conv2d_gemm_bf16_bnbwd': (I, [P, P, I, I, I, I, I, P, P, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, P]),
     'sacv_maxpool_fwd_bf16': (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     'sacv_maxpool_bwd_bf16': (I, [P, P, P, I, I, I, I, I, I, I, I, I, P]),
     'sacv_avgpool_fwd_bf16': (I, [P, P, I, I, I, P]),
@@ -155,7 +157,7 @@ def _load():
     return lib
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 lib = _load()
 if lib.sacv_abi_version() != ABI_VERSION:
     raise ImportError(f'{LIB_PATH} has ABI version {lib.sacv_abi_version()}, this package needs {ABI_VERSION}: rebuild it '

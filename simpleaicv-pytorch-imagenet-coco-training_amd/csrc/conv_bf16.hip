@@ -25,6 +25,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define CF_BIAS 1
 #define CF_ACCUM 8
 #define CF_STATS 32
+#define CFH_BNBWD 256  // internal (sacv_conv2d_gemm_bf16_bnbwd): the stored value is the upstream gradient of a BatchNorm
 #define CFH_OUT_F32 64  // dst is fp32 (the classifier's logits) instead of bf16
 
 // 16 zero bytes that masked gathers read (see conv_gemm.hip: a select on the ADDRESS keeps the gathered registers
@@ -47,12 +48,15 @@ struct ConvArgsH {
   int ntiles;
   float* stats;  // [mtiles][2][N]
   const float* residual;  // optional fp32 [M][N] added in the epilogue (the ViT residual stream), never remapped
+  SacvBnBwdH bn;          // CFH_BNBWD: the BatchNorm layer this launch stores the upstream gradient of (dst rows = its rows)
 };
 
 __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 
 // OCC / SWZ as conv_nt_kernel (conv_gemm.hip): SWZ = unpadded 128-byte rows, chunks XOR-swizzled by (row >> 1) & 7
-template <int BM, int BN, int MODE, int OCC = 2, bool SWZ = false>
+// BNB: the CFH_BNBWD epilogue is compiled in (its own instantiations: the operand rows it holds cost the plain kernels
+// 50-60 VGPRs and spills when it was a run-time flag)
+template <int BM, int BN, int MODE, int OCC = 2, bool SWZ = false, bool BNB = false>
 __global__ __launch_bounds__(256, OCC) void conv_nt_bf16_kernel(const ConvArgsH a) {
   constexpr int LSB = SWZ ? 128 : 144;          // LDS row stride in bytes: 64 bf16 (+ 16 bytes of padding)
   constexpr int RA = BM / 32, RB = BN / 32;     // 16-byte gathers per thread per K tile
@@ -250,6 +254,27 @@ __global__ __launch_bounds__(256, OCC) void conv_nt_bf16_kernel(const ConvArgsH 
         for (int r = 0; r < 16; ++r)
           stage[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CS + wn0 + j * 32 + l31] = acc[i][j][r];
     __syncthreads();
+    // CFH_BNBWD: the rows of y (and z) of the BatchNorm layer these values are the upstream gradient of -- all of the
+    // thread's rows requested at once, now that the accumulators have left the registers
+    constexpr bool bnb = BNB;
+    const bool bn_hasz = bnb && a.bn.z != nullptr, bn_rc = bnb && a.bn.z == nullptr && a.bn.beta != nullptr;
+    bf16x8 bny[NR], bnz[NR];
+    float bmu[8], bis[8], bga[8], bbe[8];
+    if constexpr (BNB) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+        if (rok[i]) {
+          bny[i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(a.bn.y) + ooff[i]);
+          if (bn_hasz) bnz[i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(a.bn.z) + ooff[i]);
+        }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bmu[e] = nok ? a.bn.mean[n + e] : 0.f;
+        bis[e] = nok ? a.bn.invstd[n + e] : 0.f;
+        bga[e] = (bn_rc && nok) ? a.bn.gamma[n + e] : 0.f;
+        bbe[e] = (bn_rc && nok) ? a.bn.beta[n + e] : 0.f;
+      }
+    }
     float bv[8], ssum[8], ssq[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -301,14 +326,31 @@ __global__ __launch_bounds__(256, OCC) void conv_nt_bf16_kernel(const ConvArgsH 
         }
         *reinterpret_cast<bf16x8*>(d) = q;
       }
+      if constexpr (BNB) {
+        // first stage of that layer's BatchNorm backward (norm.hip: bn_bwd_partial_kernel<bf16>) on the ROUNDED values
+        // just stored: g = dz * (z > 0), z read (residual layers) or recomputed from y by bn_apply's own expression,
+        // rounded to the storage type as the forward pass stored it; sums of g and g * xhat
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        ssum[e] += v[e];
-        ssq[e] += v[e] * v[e];
+        for (int e = 0; e < 8; ++e) {
+          const float xh = ((float)bny[i][e] - bmu[e]) * bis[e];
+          float g = v[e];
+          if (bn_hasz)
+            g = (float)bnz[i][e] > 0.f ? g : 0.f;
+          else if (bn_rc)
+            g = (float)(bf16)(xh * bga[e] + bbe[e]) > 0.f ? g : 0.f;
+          ssum[e] += g;
+          ssq[e] += g * xh;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          ssum[e] += v[e];
+          ssq[e] += v[e] * v[e];
+        }
       }
     }
     __syncthreads();  // the stage is dead: its memory is the reduction scratch / the next tile's buffers
-    if (flags & CF_STATS) {
+    if (BNB || (flags & CF_STATS)) {
       float* red = reinterpret_cast<float*>(smem);  // [2][RS][BN]
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -658,21 +700,21 @@ static int num_cus_h() {
   return cus;
 }
 
-template <int BM, int BN, int MODE, int OCC = 2, bool SWZ = false>
+template <int BM, int BN, int MODE, int OCC = 2, bool SWZ = false, bool BNB = false>
 static int launch_nt_h(ConvArgsH& a, hipStream_t st) {
   size_t lds = (size_t)2 * (BM + BN) * (SWZ ? 128 : 144);
   const size_t lds_epi = (size_t)BM * (BN + 4) * sizeof(float);
   if (lds_epi > lds) lds = lds_epi;
   static std::once_flag attr_once;
   std::call_once(attr_once, [lds] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_bf16_kernel<BM, BN, MODE, OCC, SWZ>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_nt_bf16_kernel<BM, BN, MODE, OCC, SWZ, BNB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   });
   a.ntiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   int grid = num_cus_h() * OCC;
   const int items = ((a.ntiles + 7) / 8) * 8;
   if (grid > items) grid = items;
-  hipLaunchKernelGGL((conv_nt_bf16_kernel<BM, BN, MODE, OCC, SWZ>), dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv_nt_bf16_kernel<BM, BN, MODE, OCC, SWZ, BNB>), dim3(grid), dim3(256), lds, st, a);
   SACV_CHECK_LAUNCH("conv_nt_bf16_kernel");
   return SACV_OK;
 }
@@ -702,7 +744,7 @@ SACV_API_BEGIN
 static int conv2d_gemm_bf16_impl(const void* src, void* dst, int Nb, int Hs, int Ws, int Hd, int Wd, const void* w,
                                  const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode,
                                  int flags, int remap_s, int Hr, int Wr, const int* ext, float* stats,
-                                 const float* residual, void* stream) {
+                                 const float* residual, void* stream, const SacvBnBwdH* bn = nullptr) {
   SACV_CHECK_ARG(src && dst && w, "conv2d_gemm_bf16: null pointer");
   SACV_CHECK_ARG(!residual || (remap_s == 0 && !ext), "conv2d_gemm_bf16: residual with a remapped destination");
   SACV_CHECK_ARG(Cs % 8 == 0 && Cs > 0 && N % 8 == 0 && N > 0, "conv2d_gemm_bf16: Cs=%d and N=%d must be multiples of 8",
@@ -713,6 +755,14 @@ static int conv2d_gemm_bf16_impl(const void* src, void* dst, int Nb, int Hs, int
   SACV_CHECK_ARG(!(flags & CF_BIAS) || bias, "conv2d_gemm_bf16: bias flag without bias pointer");
   SACV_CHECK_ARG(!(flags & CF_STATS) || stats, "conv2d_gemm_bf16: CF_STATS without a stats buffer");
   SACV_CHECK_ARG((flags & ~(CF_BIAS | CF_ACCUM | CF_STATS | CFH_OUT_F32)) == 0, "conv2d_gemm_bf16: unknown flag bits");
+  if (bn) {
+    SACV_CHECK_ARG(!(flags & (CF_STATS | CFH_OUT_F32)) && stats && remap_s == 0 && !ext && !residual && mode == 1,
+                   "conv2d_gemm_bf16_bnbwd: a data gradient (mode 1) into a bf16 destination without row remap / tap "
+                   "subset / SACV_CF_STATS, with a stats buffer");
+    SACV_CHECK_ARG(bn->y && bn->mean && bn->invstd && (bn->z || !bn->beta || bn->gamma),
+                   "conv2d_gemm_bf16_bnbwd: y / mean / invstd (and gamma with beta) are required");
+    flags |= CFH_BNBWD;
+  }
   SACV_CHECK_ARG(Nb > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0, "conv2d_gemm_bf16: bad dims");
   const long long M = (long long)Nb * Hd * Wd;
   SACV_CHECK_ARG(M * (long long)(N > Cs ? N : Cs) < (1LL << 31) && (long long)Nb * Hs * Ws * Cs < (1LL << 31) &&
@@ -762,11 +812,12 @@ static int conv2d_gemm_bf16_impl(const void* src, void* dst, int Nb, int Hs, int
   a.flags = flags;
   a.stats = stats;
   a.residual = residual;
+  a.bn = bn ? *bn : SacvBnBwdH{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   hipStream_t st = (hipStream_t)stream;
   // stride-1 1x1 convolutions / Linear layers are plain GEMMs over contiguous rows: the LDS-DMA kernel (gemm_bf16.hip)
   if (KH == 1 && KW == 1 && stride == 1 && pad == 0 && !ext && remap_s == 0 && Hs == Hd && Ws == Wd &&
       sacv_internal_gemm_nt_bf16_supported(M, N, Cs))
-    return sacv_internal_gemm_nt_bf16(src, w, dst, bias, residual, stats, M, N, Cs, flags, stream);
+    return sacv_internal_gemm_nt_bf16(src, w, dst, bias, residual, stats, M, N, Cs, flags & ~CFH_BNBWD, stream, bn);
   // 3x3 / stride 1 / pad 1 with 64 output channels (layer1 of the classifier): the halo-resident kernel reads the input
   // once per tile instead of once per tap (conv3x3_halo_bf16.hip).  Its statistics rows cover 256 padded positions
   // each -- fewer rows than the 128-row granule the caller allocated: the rest is zeroed for the finalize pass.
@@ -783,6 +834,8 @@ static int conv2d_gemm_bf16_impl(const void* src, void* dst, int Nb, int Hs, int
     }
     return sacv_internal_conv3x3_halo_bf16(src, dst, Nb, Hs, Ws, w, Cs, N, mode, flags, stats, stream);
   }
+  if (bn)  // data gradients only (the kernels with the BatchNorm-backward epilogue compiled in)
+    return N <= 64 ? launch_nt_h<128, 64, 1, 3, true, true>(a, st) : launch_nt_h<128, 128, 1, 2, false, true>(a, st);
   if (N <= 64)  // three workgroups per CU on the unpadded, swizzled 48 KB LDS image (29.05 -> 28.8 ms on the bf16 classifier;
                 // for wider outputs the two-per-CU 128 x 128 tile stays ahead)
     return mode == 0 ? launch_nt_h<128, 64, 0, 3, true>(a, st) : launch_nt_h<128, 64, 1, 3, true>(a, st);
@@ -794,6 +847,19 @@ int sacv_conv2d_gemm_bf16(const void* src, void* dst, int Nb, int Hs, int Ws, in
                           int remap_s, int Hr, int Wr, const int* ext, float* stats, void* stream) {
   return conv2d_gemm_bf16_impl(src, dst, Nb, Hs, Ws, Hd, Wd, w, bias, Cs, N, KH, KW, stride, pad, mode, flags, remap_s,
                                Hr, Wr, ext, stats, nullptr, stream);
+}
+
+// One data gradient (mode 1) whose bf16 output dz [M][N] is the upstream gradient of the
+// BatchNorm (+ ReLU) layer with input bn_y: the epilogue also writes that layer's backward first-stage sums (the bf16
+// twin of sacv_conv2d_gemm_bnbwd); stats: [ceil(M / 128)][2][N] rows of (sum g, sum g * xhat).
+int sacv_conv2d_gemm_bf16_bnbwd(const void* src, void* dst, int Nb, int Hs, int Ws, int Hd, int Wd, const void* w,
+                                const float* bias, int Cs, int N, int KH, int KW, int stride, int pad, int mode,
+                                int flags, float* stats, const void* bn_y, const void* bn_z, const float* bn_mean,
+                                const float* bn_invstd, const float* bn_gamma, const float* bn_beta, void* stream) {
+  SACV_CHECK_ARG((flags & ~(CF_BIAS | CF_ACCUM)) == 0, "conv2d_gemm_bf16_bnbwd: flags SACV_CF_BIAS / SACV_CF_ACCUM only");
+  const SacvBnBwdH bn = {bn_y, bn_z, bn_mean, bn_invstd, bn_gamma, bn_beta};
+  return conv2d_gemm_bf16_impl(src, dst, Nb, Hs, Ws, Hd, Wd, w, bias, Cs, N, KH, KW, stride, pad, mode, flags, 0, 0, 0,
+                               nullptr, stats, nullptr, stream, &bn);
 }
 
 // nn.Linear on bf16 rows: y[M][N] (bf16, or fp32 with SACV_CFH_OUT_F32) = x[M][K] w[N][K]^T (+ bias) (+ residual, an

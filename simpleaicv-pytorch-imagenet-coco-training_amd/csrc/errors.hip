@@ -12,7 +12,7 @@ void sacv_set_error(const char* fmt, ...) {
 }
 
 SACV_API const char* sacv_last_error(void) { return g_err; }
-SACV_API int sacv_abi_version(void) { return 4; }
+SACV_API int sacv_abi_version(void) { return 5; }
 
 // One plan per PROCESS (one process drives one GPU): PyTorch runs a backward pass on its autograd thread, not on the
 // thread that ran the forward pass, and a per-thread plan sent the two passes of one step to different kernels.

@@ -48,6 +48,8 @@ struct GemmArgsH {
   int M, N, K;
   int flags;
   int ntiles;
+  SacvBnBwdH bn;  // bn.y non-null: C is the upstream gradient of this BatchNorm layer -- `stats` receives its backward
+                  // first-stage sums (sum g, sum g * xhat) per 128-row granule (conv_bf16.hip: CFH_BNBWD)
 };
 
 template <int BM, int BN>
@@ -194,6 +196,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_dma_kernel(const GemmArgs
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = ((flags & GCF_BIAS) && nok) ? a.bias[n + e] : 0.f;
+    const bool bnb = a.bn.y != nullptr;
+    const bool bn_hasz = bnb && a.bn.z != nullptr, bn_rc = bnb && a.bn.z == nullptr && a.bn.beta != nullptr;
+    float bmu[8], bis[8], bga[8], bbe[8];
+    if (bnb) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bmu[e] = nok ? a.bn.mean[n + e] : 0.f;
+        bis[e] = nok ? a.bn.invstd[n + e] : 0.f;
+        bga[e] = (bn_rc && nok) ? a.bn.gamma[n + e] : 0.f;
+        bbe[e] = (bn_rc && nok) ? a.bn.beta[n + e] : 0.f;
+      }
+    }
     // CF_STATS granule is 128 rows (two per tile): rows rr, rr + RS, ... of the first half, then of the second half
     float ssum[2][8], ssq[2][8];
 #pragma unroll
@@ -210,6 +224,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_dma_kernel(const GemmArgs
           if (nok && m < a.M) {
             res[i][0] = *reinterpret_cast<const f32x4*>(a.residual + (size_t)m * a.N + n);
             res[i][1] = *reinterpret_cast<const f32x4*>(a.residual + (size_t)m * a.N + n + 4);
+          }
+        }
+      }
+      bf16x8 bny[RPH], bnz[RPH];  // the half's rows of y (and z) of the BatchNorm layer, all requested before the first is used
+      if (bnb) {
+#pragma unroll
+        for (int i = 0; i < RPH; ++i) {
+          const int m = m0 + h * 128 + rr + i * RS;
+          if (nok && m < a.M) {
+            bny[i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(a.bn.y) + (size_t)m * a.N + n);
+            if (bn_hasz)
+              bnz[i] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(a.bn.z) + (size_t)m * a.N + n);
           }
         }
       }
@@ -256,14 +282,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_bf16_dma_kernel(const GemmArgs
           }
           *reinterpret_cast<bf16x8*>(d) = q;
         }
+        if (bnb) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          ssum[h][e] += v[e];
-          ssq[h][e] += v[e] * v[e];
+          for (int e = 0; e < 8; ++e) {
+            const float xh = ((float)bny[i][e] - bmu[e]) * bis[e];
+            float g = v[e];
+            if (bn_hasz)
+              g = (float)bnz[i][e] > 0.f ? g : 0.f;
+            else if (bn_rc)
+              g = (float)(bf16)(xh * bga[e] + bbe[e]) > 0.f ? g : 0.f;
+            ssum[h][e] += g;
+            ssq[h][e] += g * xh;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            ssum[h][e] += v[e];
+            ssq[h][e] += v[e] * v[e];
+          }
         }
       }
     }
-    if (flags & GCF_STATS) {
+    if ((flags & GCF_STATS) || bnb) {
       __syncthreads();  // the stage is dead
       float* red = reinterpret_cast<float*>(smem);  // [2 halves][2][RS][BN]
 #pragma unroll
@@ -320,7 +360,8 @@ int sacv_internal_gemm_nt_bf16_supported(long long M, int N, int K) {
 }
 
 int sacv_internal_gemm_nt_bf16(const void* A, const void* B, void* C, const float* bias, const float* residual,
-                               float* stats, long long M, int N, int K, int flags, void* stream) {
+                               float* stats, long long M, int N, int K, int flags, void* stream,
+                               const SacvBnBwdH* bn) {
   GemmArgsH a;
   a.A = (const bf16*)A;
   a.B = (const bf16*)B;
@@ -332,6 +373,7 @@ int sacv_internal_gemm_nt_bf16(const void* A, const void* B, void* C, const floa
   a.N = N;
   a.K = K;
   a.flags = flags;
+  a.bn = bn ? *bn : SacvBnBwdH{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   constexpr int BM = 256, BN = 128;
   a.ntiles = (int)(((M + BM - 1) / BM) * ((N + BN - 1) / BN));
   const int lds = 3 * (BM + BN) * 128;

@@ -538,6 +538,16 @@ int sacv_bn_train_bwd_bf16(const void* dz, const void* zmask, const void* y, con
                                       gamma, beta, (sacv_bf16*)dy, (sacv_bf16*)g_out, dgamma, dbeta, R, C, accumulate,
                                       workspace, stream);
 }
+// bf16 twin of sacv_bn_train_bwd_partial: partial sums from sacv_conv2d_gemm_bf16_bnbwd
+int sacv_bn_train_bwd_partial_bf16(const void* dz, const void* zmask, const void* y, const float* mean,
+                                   const float* invstd, const float* gamma, const float* beta, void* dy, void* g_out,
+                                   float* dgamma, float* dbeta, int R, int C, int accumulate, const float* partial,
+                                   int nparts, float* workspace, void* stream) {
+  SACV_CHECK_ARG(partial, "bn_train_bwd_partial_bf16: null partial sums");
+  return bn_train_bwd_impl<sacv_bf16>((const sacv_bf16*)dz, (const sacv_bf16*)zmask, (const sacv_bf16*)y, mean, invstd,
+                                      gamma, beta, (sacv_bf16*)dy, (sacv_bf16*)g_out, dgamma, dbeta, R, C, accumulate,
+                                      workspace, stream, partial, nparts);
+}
 
 // jobs: device array of njobs records {const float* gamma, beta, running_mean, running_var; float* out /*[2][C]*/;
 // int C; int pad} (48 bytes): out[0] = shift, out[1] = scale of the eval-mode BatchNorm (classification/backbones/

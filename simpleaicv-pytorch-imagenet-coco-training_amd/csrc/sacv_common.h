@@ -58,9 +58,20 @@ int sacv_internal_wgrad_reduce(const float* part, float* dw, int chunks, int Cou
 
 // internal: plain bf16 NT GEMM on the LDS-DMA pipelined kernel (gemm_bf16.hip), used by sacv_conv2d_gemm_bf16 for
 // stride-1 1x1 problems / Linear layers; flags = the CF_* bits of the bf16 convolution
+// SacvBnBwdH (optional): the BatchNorm layer whose upstream gradient the launch stores (sacv_conv2d_gemm_bf16_bnbwd) --
+// the epilogue then writes that layer's backward first-stage sums into `stats` instead of the column sums
+struct SacvBnBwdH {
+  const void* y;        // the layer's pre-normalisation input [M][N] bf16
+  const void* z;        // ReLU mask source (the stored layer output, bf16) or null: mask recomputed from y
+  const float* mean;    // [N]
+  const float* invstd;  // [N]
+  const float* gamma;   // [N] (mask recomputation)
+  const float* beta;    // [N] (mask recomputation; null together with z: no ReLU, no mask)
+};
 int sacv_internal_gemm_nt_bf16_supported(long long M, int N, int K);
 int sacv_internal_gemm_nt_bf16(const void* A, const void* B, void* C, const float* bias, const float* residual,
-                               float* stats, long long M, int N, int K, int flags, void* stream);
+                               float* stats, long long M, int N, int K, int flags, void* stream,
+                               const SacvBnBwdH* bn = nullptr);
 
 // internal: halo-resident bf16 3x3 / stride 1 / pad 1 convolution with 64 output channels (conv3x3_halo_bf16.hip),
 // used by sacv_conv2d_gemm_bf16 for the layer1-class problems; mode 0 forward, 1 data gradient; flags: CF_STATS only

@@ -357,6 +357,14 @@ class DetectorEngine:
     # weight gradients) disappears for 41 of the trunk's 53 layers.  False: every layer runs its own first stage (A/B,
     # tests).
     fuse_bn_bwd = True
+    # The same under bf16 autocast (sacv_conv2d_gemm_bf16_bnbwd; the 64-channel 3x3 data gradients stay on the
+    # halo-resident kernel, which has no such epilogue).  Built, parity-tested (tests/test_gpu_bf16.py) and measured on
+    # ResNet50 bs 256 (scripts/ab_cls_bnbwd.sh, stream order, ms per step): bn_bwd_partial 2.82 -> 1.20 (38 of 53 launches
+    # gone), but gemm_nt_bf16_dma_kernel 3.79 -> 4.82, conv_nt_bf16<128,128> data gradients 2.19 -> 3.22, <128,64> 0.51 ->
+    # 0.70: the step 26.6 -> 27.4 ms.  The bf16 epilogues are latency-bound (one 512-thread workgroup per CU in the GEMM
+    # kernel: every tile waits once more for its rows of y), the stand-alone pass streams the same bytes at 0.6-0.7 of the
+    # HBM roofline.  Off.
+    fuse_bn_bwd_amp = False
     # Where a layer's weight gradient enters the side stream: right behind the BatchNorm backward that produces its dy
     # (False: it starts WITH the layer's data gradient -- two matrix-core kernels taking turns on the CUs) or behind the
     # data gradient's launch (True: it starts when the data gradient has finished, next to the NEXT layer's BatchNorm
@@ -393,8 +401,9 @@ class DetectorEngine:
             self._trunk_wgrad(c, dy, g[wname], cin)
         dx, st = None, None
         if need_dx:
-            if (fuse is not None and self.fuse_bn_bwd and not self.amp and c.stride == 1 and fuse.relu
-                    and tuple(fuse.y.shape) == tuple(c.x.shape)):
+            if (fuse is not None and self.fuse_bn_bwd and c.stride == 1 and fuse.relu
+                    and tuple(fuse.y.shape) == tuple(c.x.shape)
+                    and (not self.amp or (self.fuse_bn_bwd_amp and not (c.k == 3 and cin == 64)))):
                 f_rc = not fuse.residual  # as above: mask recomputed from y unless a residual entered the ReLU
                 fbn = fuse.prefix + '.layer.1.'
                 dx, st = ops.conv_gemm_bnbwd(dy, self._dgrad_panel(w), cin, c.k, c.k, c.pad, c.x.shape[1:3], fuse.y,

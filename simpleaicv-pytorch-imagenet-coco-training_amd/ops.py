@@ -215,7 +215,10 @@ def conv_gemm_bnbwd(src, w_packed, n_out, kh, kw, pad, out_hw, bn_y, bn_mean, bn
     """One stride-1 data gradient (mode 1; out_hw = input H, W) whose output dz is the upstream gradient of the
     BatchNorm (+ ReLU) layer with input bn_y: returns (dz, partial) with partial [m tiles, 2, n_out] = that layer's
     backward first-stage sums (sum g, sum g * xhat) for bn_train_bwd(partial=...).  Mask from bn_z (stored output) or
-    recomputed from y with bn_gamma / bn_beta."""
+    recomputed from y with bn_gamma / bn_beta.  bf16 activations: sacv_conv2d_gemm_bf16_bnbwd (no mask operand)."""
+    if src.dtype == BF16:
+        return _conv_gemm_bf16_bnbwd(src, w_packed, n_out, kh, kw, pad, out_hw, bn_y, bn_mean, bn_invstd, bn_gamma,
+                                     bn_beta, bn_z, out, flags, mask, mode, stride)
     _chk(src, 'conv src')
     cs = src.shape[3]
     nb = src.shape[0]
@@ -240,6 +243,40 @@ def conv_gemm_bnbwd(src, w_packed, n_out, kh, kw, pad, out_hw, bn_y, bn_mean, bn
         TIMER.time(_nt_family(n_out) + f'|m{mode} k{kh} s{stride} cs{cs} n{n_out} np1 pix{pix} f{flags | 256}',
                    2.0 * pix * n_out * kh * kw * cs, launch,
                    nbytes=4.0 * (src.numel() + 2 * out.numel() + w_packed.numel()))
+    else:
+        launch()
+    return out, st
+
+
+def _conv_gemm_bf16_bnbwd(src, w_packed, n_out, kh, kw, pad, out_hw, bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_z,
+                          out, flags, mask, mode, stride):
+    if mask is not None or (flags & ~(CF_BIAS | CF_ACCUM)):
+        raise ValueError(f'bf16 conv_gemm_bnbwd: no mask epilogue, flags BIAS / ACCUM only (flags={flags})')
+    _chk(src, 'conv src', BF16)
+    _chk(w_packed, 'bf16 weight panel', BF16)
+    cs, nb = src.shape[3], src.shape[0]
+    if out is None:
+        out = torch.empty((nb, out_hw[0], out_hw[1], n_out), device=src.device, dtype=BF16)
+    _chk(out, 'conv dst', BF16)
+    if tuple(bn_y.shape) != tuple(out.shape):
+        raise ValueError(f'conv_gemm_bnbwd: bn_y is {tuple(bn_y.shape)}, the output {tuple(out.shape)}')
+    _chk(bn_y, 'bn_y', BF16)
+    if bn_z is not None:
+        _chk(bn_z, 'bn_z', BF16)
+    rows = -(-(nb * out_hw[0] * out_hw[1]) // 128)
+    st = torch.empty((rows, 2, n_out), device=src.device, dtype=torch.float32)
+
+    def launch():
+        check(lib.sacv_conv2d_gemm_bf16_bnbwd(
+            src.data_ptr(), out.data_ptr(), nb, src.shape[1], src.shape[2], out_hw[0], out_hw[1], _ptr(w_packed), None,
+            cs, n_out, kh, kw, stride, pad, mode, flags, st.data_ptr(), bn_y.data_ptr(), _ptr(bn_z), _ptr(bn_mean),
+            _ptr(bn_invstd), _ptr(bn_gamma), _ptr(bn_beta), _stream()), 'conv2d_gemm_bf16_bnbwd')
+
+    if TIMER is not None:
+        pix = nb * (src.shape[1] * src.shape[2] if mode == 1 else out_hw[0] * out_hw[1])
+        TIMER.time(f'conv_nt_bf16|m{mode} k{kh} s{stride} cs{cs} n{n_out} pix{pix} f{flags | 256}',
+                   2.0 * pix * n_out * kh * kw * cs, launch,
+                   nbytes=2.0 * (src.numel() + 2 * out.numel() + w_packed.numel()))
     else:
         launch()
     return out, st
@@ -737,10 +774,10 @@ def bn_train_bwd(dz, zmask, y, mean, invstd, gamma, dgamma, dbeta, want_g=False,
     dy = dy_out if dy_out is not None else torch.empty_like(y)
     g = torch.empty_like(y) if want_g else None
     if partial is not None:
-        check(lib.sacv_bn_train_bwd_partial(_ptr(dz), _ptr(zmask), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma),
-                                            _ptr(relu_beta), _ptr(dy), _ptr(g), _ptr(dgamma), _ptr(dbeta), r, c,
-                                            int(accumulate), _ptr(_chk(partial, 'bn partial sums')), partial.shape[0],
-                                            _bn_ws(r, c, y.device).data_ptr(), _stream()), 'bn_train_bwd_partial')
+        fn = lib.sacv_bn_train_bwd_partial_bf16 if y.dtype == BF16 else lib.sacv_bn_train_bwd_partial
+        check(fn(_ptr(dz), _ptr(zmask), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(relu_beta), _ptr(dy), _ptr(g),
+                 _ptr(dgamma), _ptr(dbeta), r, c, int(accumulate), _ptr(_chk(partial, 'bn partial sums')),
+                 partial.shape[0], _bn_ws(r, c, y.device).data_ptr(), _stream()), 'bn_train_bwd_partial')
         return dy, g
     if y.dtype == BF16:
         check(lib.sacv_bn_train_bwd_bf16(_ptr(dz), _ptr(zmask), _ptr(y), _ptr(mean), _ptr(invstd), _ptr(gamma),

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f'{s} declared in include/sacv_hip.h but not exported'
     assert sorted(_lib.SIGNATURES) == syms, 'ctypes binding and header disagree'
-    assert _lib.lib.sacv_abi_version() == 4
+    assert _lib.lib.sacv_abi_version() == 5
 
 
 def test_library_exports_nothing_else():

@@ -266,3 +266,94 @@ def test_halo_resident_3x3_kernel(n, h, w, cin):
         wd = wt.permute(1, 2, 3, 0).contiguous().view(cin, -1).cuda().to(BF)      # [Cin][taps*Cout]
         dx = ops.conv_gemm([nhwc(dy).cuda().to(BF)], wd, cin, 3, 3, 1, 1, 1, [(h, w)])[0]
         close_bf16(dx.permute(0, 3, 1, 2), xr.grad, 'dgrad')
+
+
+@pytest.mark.parametrize('n,cin,h,w,cout,k,zmask', [
+    (2, 256, 50, 67, 64, 1, False),      # 1x1, conv_nt_bf16<128,128> with the BatchNorm-backward epilogue
+    (2, 64, 37, 41, 256, 1, True),       # N = 64: the <128,64> kernel; mask from z, accumulating destination
+    (2, 128, 26, 31, 128, 3, False),     # 3x3
+    (1, 256, 1, 256 * 150 + 19, 128, 1, False),  # 302 tiles of 256 x 128: gemm_nt_bf16_dma_kernel, ragged last granule
+    (1, 128, 1, 256 * 300 + 77, 192, 1, True),   # the same kernel, mask from z + accumulate
+])
+def test_bn_backward_first_stage_in_the_bf16_data_gradient_epilogue(n, cin, h, w, cout, k, zmask):
+    """sacv_conv2d_gemm_bf16_bnbwd + sacv_bn_train_bwd_partial_bf16 against the unfused pair (bf16 twin of
+    tests/test_gpu_kernels.py::test_bn_backward_first_stage_in_the_data_gradient_epilogue): dz bit-identical, the
+    first-stage sums against fp64 sums of the same bf16 values, dgamma / dbeta / dy to summation noise (dy is bf16:
+    one rounding step of its scale)."""
+    from sacv_amd import ops
+    p = k // 2
+    wt = q(rnd(2, cout, cin, k, k, std=(1.0 / (cin * k * k))**0.5))
+    wd = wt.permute(1, 2, 3, 0).contiguous().view(cin, -1).cuda().to(BF)   # [Cin][taps*Cout]
+    dy = nhwc(rnd(3, n, cout, h, w)).cuda().to(BF)
+    y = nhwc(rnd(4, n, cin, h, w)).cuda().to(BF)
+    gamma = (1.0 + 0.2 * rnd(5, cin)).cuda()
+    beta = (0.2 * rnd(6, cin)).cuda()
+    yf = y.float().view(-1, cin)
+    mean = yf.mean(0)
+    invstd = 1.0 / torch.sqrt(yf.var(0, unbiased=False) + 1e-5)
+    res = nhwc(rnd(7, n, cin, h, w)).cuda().to(BF) if zmask else None
+    z = ops.bn_apply(y, mean, invstd, gamma, beta, res, True)
+    base = nhwc(rnd(8, n, cin, h, w)).cuda().to(BF) if zmask else None
+    flags = ops.CF_ACCUM if zmask else 0
+
+    def grads():
+        return torch.zeros(cin, device='cuda'), torch.zeros(cin, device='cuda')
+    out0 = base.clone() if zmask else None
+    dz0 = ops.conv_gemm([dy], wd, cin, k, k, 1, p, 1, [(h, w)], flags=flags, outs=[out0] if zmask else None)[0]
+    dg0, db0 = grads()
+    dx0, g0 = ops.bn_train_bwd(dz0, z if zmask else None, y, mean, invstd, gamma, dg0, db0, want_g=True,
+                               relu_beta=None if zmask else beta)
+    out1 = base.clone() if zmask else None
+    dz1, st = ops.conv_gemm_bnbwd(dy, wd, cin, k, k, p, (h, w), y, mean, invstd, bn_gamma=None if zmask else gamma,
+                                  bn_beta=None if zmask else beta, bn_z=z if zmask else None, out=out1, flags=flags)
+    assert dz1.dtype == BF and torch.equal(dz1, dz0)
+    assert st.shape == (-(-(n * h * w) // 128), 2, cin)
+    dg1, db1 = grads()
+    dx1, g1 = ops.bn_train_bwd(dz1, z if zmask else None, y, mean, invstd, gamma, dg1, db1, want_g=True,
+                               relu_beta=None if zmask else beta, partial=st)
+    assert torch.equal(g1, g0)
+    gm = g0.float().reshape(-1, cin).double()
+    xh = (yf.double() - mean.double()) * invstd.double()
+    scale = float(gm.abs().sum(0).max())
+    assert torch.allclose(st[:, 0].double().sum(0), gm.sum(0), rtol=1e-5, atol=1e-4 * scale)
+    assert torch.allclose(st[:, 1].double().sum(0), (gm * xh).sum(0), rtol=1e-5, atol=1e-4 * scale)
+    # one granule on its own (the ragged last one included): rows r*128 .. of the same fp64 sums
+    for r in (0, st.shape[0] - 1):
+        blk = slice(r * 128, (r + 1) * 128)
+        assert torch.allclose(st[r, 0].double(), gm[blk].sum(0), rtol=1e-4, atol=1e-4 * float(gm[blk].abs().sum(0).max()))
+        assert torch.allclose(st[r, 1].double(), (gm[blk] * xh[blk]).sum(0), rtol=1e-4,
+                              atol=1e-4 * float(gm[blk].abs().sum(0).max()))
+    for a, b in ((dg1, dg0), (db1, db0)):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6
+    assert float((dx1.float() - dx0.float()).abs().max()) <= 2.0**-7 * float(dx0.float().abs().max())
+
+
+def test_classifier_step_bf16_fused_bn_backward_matches_unfused():
+    """ResNet50 under autocast, 8 x 96 x 96: the backward pass with BatchNorm's first stage in the data-gradient
+    epilogues (engine.fuse_bn_bwd_amp) against the same pass with every layer's own first stage: identical forward
+    pass, and gradients that differ by the summation order of the per-channel sums only (a changed last bit of one
+    bf16 dy moves everything upstream by rounding noise: bound = 1/4 of the amp fixture test's own gate)."""
+    from sacv_amd.classification import backbones, losses
+    nc, B, R = 100, 8, 96
+    x = torch.tensor(synth.images(11, B, R, R)).cuda()
+    lab = torch.tensor(gi.labels_for(23, B, nc)).cuda()
+    runs = []
+    for fuse in (True, False):
+        net = backbones.__dict__['resnet50'](num_classes=nc)
+        net.load_state_dict(omodel.init_resnet50_cls_state(0, nc), strict=True)
+        net = net.cuda().train().set_amp(True)
+        net.engine.fuse_bn_bwd_amp = fuse
+        loss = losses.__dict__['CELoss']()(net(x), lab)
+        loss.backward()
+        runs.append((float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters()}))
+        del net
+    (la, ga), (lb, gb) = runs
+    assert la == lb
+    rel = []
+    for k in ga:
+        na, nb = float(ga[k].double().norm()), float(gb[k].double().norm())
+        rel.append(abs(na - nb) / (nb + 1e-12))
+        d = float((ga[k] - gb[k]).abs().max()) / (float(gb[k].abs().max()) + 1e-12)
+        assert d <= 6e-2, (k, d)
+    print('fused vs unfused bf16 BatchNorm backward: grad-norm rel diff median %.2e max %.2e' % (np.median(rel), max(rel)))
+    assert float(np.median(rel)) <= 1.5e-2 and max(rel) <= 6e-2

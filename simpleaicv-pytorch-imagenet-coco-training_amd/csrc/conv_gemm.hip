@@ -1425,8 +1425,10 @@ struct NtPlan {
 // Schedule of `tiles` equal tiles of KT K-iterations on `grid` persistent workgroups.  w = relative cost of
 // one K-iteration of this tile shape (1.0 for 128x128, ~0.6 for 128x64).  The split-K workspace holds two
 // slabs per workgroup (sacv_conv2d_gemm_workspace_bytes).
-static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w) {
-  const double epi = 3.0, epi_split = SACV_EPI_SPLIT;  // epilogue / slab write + fix-up, in K-iterations
+// `ks` scales the per-tile constants (epilogue, slab + fix-up, stream-K extra, shortest range): they are given in
+// K-iterations of the fp32-pipe kernels; a K-iteration of a split-operand kernel is shorter, its epilogue is not.
+static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w, double ks = 1.0) {
+  const double epi = 3.0 * ks, epi_split = SACV_EPI_SPLIT * ks;  // epilogue / slab write + fix-up, in K-iterations
   NtPlan p;
   p.base = tiles / grid;
   p.rem = tiles - p.base * grid;
@@ -1443,7 +1445,8 @@ static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w) {
   // range crosses a tile boundary and more slabs per tile in the fix-up: measured ~+12 us per launch
   // (~6 K-iterations) over a uniform split, so it wins on the long-K problems (3x3 convs, head towers).
   const int policy = sacv_share.split_policy == 0 ? 0 : SACV_SK_POLICY;  // 0 none, 1 uniform only, 2 stream-K only, 3 auto
-  constexpr double sk_extra = SACV_SK_EXTRA;
+  const double sk_extra = SACV_SK_EXTRA * ks;
+  const long long sk_min_iters = (long long)(SACV_SK_MIN_ITERS * ks + 0.5);
   p.sk_blocks = p.rem;
   double tail = KT + epi;
   if (has_ws && policy > 0) {
@@ -1461,7 +1464,7 @@ static NtPlan plan_nt(int tiles, int KT, int grid, bool has_ws, double w) {
     if (policy != 1) {
       const long long U = (long long)p.rem * KT;
       long long gs = grid;
-      if (U / gs < SACV_SK_MIN_ITERS) gs = U / SACV_SK_MIN_ITERS;
+      if (U / gs < sk_min_iters) gs = U / sk_min_iters;
       if (gs < p.rem) gs = p.rem;
       const double c = (double)((U + gs - 1) / gs) + epi_split + sk_extra;
       if (gs > p.rem && (c < tail || policy == 2)) {
@@ -1711,11 +1714,17 @@ static int conv2d_gemm_impl(int nprob, const float* const* src, float* const* ds
 #endif
     if (N >= SACV_SP_WIDE_MIN_N) {
       const int KT16 = KH * KW * ((Cs + 15) / 16);
-      NtPlan pw = plan_nt(tiles * ((N + 127) / 128), KT16, nt_slots_split(), ws, 1.0);
+#ifndef SACV_SP_KS_WIDE
+#define SACV_SP_KS_WIDE 1.0  // tuning builds (scripts/build_variant.sh): planner constants of the 16-deep split kernels
+#endif
+#ifndef SACV_SP_KS_NARROW
+#define SACV_SP_KS_NARROW 1.0
+#endif
+      NtPlan pw = plan_nt(tiles * ((N + 127) / 128), KT16, nt_slots_split(), ws, 1.0, SACV_SP_KS_WIDE);
       return mode == 0 ? launch_nt<128, 128, 0, 2, 2, true, true, 16>(a, pw, workspace, st)
                        : launch_nt<128, 128, 1, 2, 2, true, true, 16>(a, pw, workspace, st);
     }
-    NtPlan ps = plan_nt(tiles * ((N + 63) / 64), KT, nt_slots_split(), ws, 1.0);
+    NtPlan ps = plan_nt(tiles * ((N + 63) / 64), KT, nt_slots_split(), ws, 1.0, SACV_SP_KS_NARROW);
     return mode == 0 ? launch_nt<128, 64, 0, 2, 2, true, true>(a, ps, workspace, st)
                      : launch_nt<128, 64, 1, 2, 2, true, true>(a, ps, workspace, st);
   }

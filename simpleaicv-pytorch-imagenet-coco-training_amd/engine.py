@@ -634,6 +634,8 @@ class DetectorEngine:
         return ops.conv_gemm([x], wp, w.shape[0], k, k, stride, pad, 0, [hw], bias=self.p[name + '.bias'],
                              flags=flags)[0]
 
+    fpn_on_side = True  # P5_2 / P4_2 / P6 / P7 of the forward pass on the side stream, beside P3_2 (_fpn_fwd)
+
     WINO_MIN_TILES = 6000  # a single 3x3 conv goes to the Winograd path from this many 2x2 output tiles (enough
     #                        64-tile work items to occupy the 256 CUs; below it the direct kernel is faster)
 
@@ -665,12 +667,29 @@ class DetectorEngine:
         p4 = ops.upsample_add_fwd(p5, p4l)
         p3l = self._conv_bias(c3, 'fpn.P3_1', 1, 1, 0)
         p3 = ops.upsample_add_fwd(p4, p3l)
-        p5o = self._conv_bias(p5, 'fpn.P5_2', 3, 1, 1)
-        p4o = self._conv_bias(p4, 'fpn.P4_2', 3, 1, 1)
-        p3o = self._conv3x3_bias(p3, 'fpn.P3_2', ctx)
-        p6 = self._conv_bias(p5o if self.fcos else c5, 'fpn.P6', 3, 2, 1)  # use_p5 (fpn.py:80)
-        p6r = ops.eltwise(ops.EW_RELU, p6)
-        p7 = self._conv_bias(p6r, 'fpn.P7.1', 3, 2, 1)
+        box = {}
+
+        def small_levels():
+            p5o = self._conv_bias(p5, 'fpn.P5_2', 3, 1, 1)
+            p4o = self._conv_bias(p4, 'fpn.P4_2', 3, 1, 1)
+            p6 = self._conv_bias(p5o if self.fcos else c5, 'fpn.P6', 3, 2, 1)  # use_p5 (fpn.py:80)
+            p6r = ops.eltwise(ops.EW_RELU, p6)
+            box['r'] = (p5o, p4o, p6, p6r, self._conv_bias(p6r, 'fpn.P7.1', 3, 2, 1))
+        if self._side is not None and self.fpn_on_side and ops.TIMER is None:
+            # P3_2 is one Winograd launch of 524 work items for 512 slots (a second, nearly empty round) or, below the
+            # Winograd threshold, a direct launch with a long tail; the four small output convolutions are independent
+            # of it: they run on the side stream (idle during the forward pass) beside it.  Their outputs are allocated
+            # under the side stream and live on on the launch stream: record_stream, as for the shortcut branch.
+            self._on_side(small_levels, [p5, p4, c5])
+            p3o = self._conv3x3_bias(p3, 'fpn.P3_2', ctx)
+            self._side_join()
+            cur = torch.cuda.current_stream()
+            for t in box['r']:
+                t.record_stream(cur)
+        else:
+            small_levels()
+            p3o = self._conv3x3_bias(p3, 'fpn.P3_2', ctx)
+        p5o, p4o, p6, p6r, p7 = box['r']
         if ctx is not None:
             ctx['fpn'] = dict(c3=c3, c4=c4, c5=c5, p5=p5, p4=p4, p3=p3, p6=p6, p6r=p6r, p5o=p5o)
         return [p3o, p4o, p5o, p6, p7]

@@ -500,9 +500,19 @@ class DetectorEngine:
                         self._wino_prepared = True
                 self._on_side(prep, [])
         self._fold_prepare(training, keep)
-        feats = self._backbone_fwd(images, training, keep, ctx)
+        early = {}
+        on_feat = None
+        if self._side is not None and self.fpn_laterals_early and ops.TIMER is None:
+            # the 1x1 laterals of C3 / C4 depend on their stage alone: on the side stream, under layer3 / layer4
+            def on_feat(li, x):
+                name = {2: 'fpn.P3_1', 3: 'fpn.P4_1'}.get(li)
+                if name is not None:
+                    def lateral():
+                        early[name] = self._conv_bias(x, name, 1, 1, 0)
+                    self._on_side(lateral, [x])
+        feats = self._backbone_fwd(images, training, keep, ctx, on_feat)
         c3f, c4f, c5f = feats[1], feats[2], feats[3]
-        fpn = self._fpn_fwd(c3f, c4f, c5f, ctx)
+        fpn = self._fpn_fwd(c3f, c4f, c5f, ctx, early)
         outs = self._fcos_heads_fwd(fpn, ctx) if self.fcos else self._heads_fwd(fpn, ctx)
         if keep:
             self.ctx = ctx
@@ -523,8 +533,9 @@ class DetectorEngine:
         f.refresh()
         self._fold = f
 
-    def _backbone_fwd(self, images, training, keep, ctx):
-        """ResNet trunk (classification/backbones/resnet.py:158-245): returns [C2, C3, C4, C5]."""
+    def _backbone_fwd(self, images, training, keep, ctx, on_feat=None):
+        """ResNet trunk (classification/backbones/resnet.py:158-245): returns [C2, C3, C4, C5].  on_feat(li, x): called
+        when stage li's output exists (the FPN laterals of C3 / C4 start on the side stream under the next stage)."""
         p, bp = self.p, self.bp
         b, _, h, w = images.shape
         # stem: explicit im2col (Cin=3) + GEMM, BN, ReLU (+ 3x3/s2 max pool for the ImageNet stem)
@@ -568,6 +579,8 @@ class DetectorEngine:
                 blocks.append((saved, li, bi))
                 x = out
             feats.append(x)
+            if on_feat is not None:
+                on_feat(li, x)
         if keep:
             ctx['blocks'] = blocks
         return feats
@@ -635,6 +648,9 @@ class DetectorEngine:
                              flags=flags)[0]
 
     fpn_on_side = True  # P5_2 / P4_2 / P6 / P7 of the forward pass on the side stream, beside P3_2 (_fpn_fwd)
+    # P3_1 / P4_1 on the side stream as soon as C3 / C4 exist (forward()): measured a tie (23.03 vs 23.01 ms, three
+    # same-session pairs) -- beside layer3 / layer4's kernels a lateral takes from them what it saves later.  Off.
+    fpn_laterals_early = False
 
     WINO_MIN_TILES = 6000  # a single 3x3 conv goes to the Winograd path from this many 2x2 output tiles (enough
     #                        64-tile work items to occupy the 256 CUs; below it the direct kernel is faster)
@@ -661,11 +677,16 @@ class DetectorEngine:
         self._bias_grad([dy], name, sync=False)
         return ops.conv3x3_wino([[dy]], [self._wino_u(w, dgrad=True)], [w.shape[1]], mode=1)[0][0]
 
-    def _fpn_fwd(self, c3, c4, c5, ctx):
+    def _fpn_fwd(self, c3, c4, c5, ctx, early=None):
         p5 = self._conv_bias(c5, 'fpn.P5_1', 1, 1, 0)
-        p4l = self._conv_bias(c4, 'fpn.P4_1', 1, 1, 0)
+        if early:  # laterals enqueued on the side stream when their stage finished (forward())
+            self._side_join()
+            cur = torch.cuda.current_stream()
+            for t in early.values():
+                t.record_stream(cur)
+        p4l = early['fpn.P4_1'] if early else self._conv_bias(c4, 'fpn.P4_1', 1, 1, 0)
         p4 = ops.upsample_add_fwd(p5, p4l)
-        p3l = self._conv_bias(c3, 'fpn.P3_1', 1, 1, 0)
+        p3l = early['fpn.P3_1'] if early else self._conv_bias(c3, 'fpn.P3_1', 1, 1, 0)
         p3 = ops.upsample_add_fwd(p4, p3l)
         box = {}
 

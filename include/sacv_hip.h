@@ -44,6 +44,12 @@ extern "C" {
 
 const char* sacv_last_error(void);
 int sacv_abi_version(void);
+/* Stream `waiter` waits for everything enqueued on stream `signaller` so far (both hipStream_t of the current device): the
+ * executor's replacement for torch.cuda.Stream.wait_stream / Event.record + wait_event between its launch stream and its
+ * weight-gradient stream (the role of DDP's reducer events in the reference, tools/utils.py:178-180).  The event it records
+ * is created with hipEventDisableTiming | hipEventDisableSystemFence: no system-scope cache writeback / invalidation per
+ * record (nothing ordered this way leaves the device). */
+int sacv_stream_wait_stream(void* waiter, void* signaller);
 
 /* Launch plan of the process's subsequent launches (one process drives one GPU; the plan is not per thread: a framework
  * may run the backward pass on another thread than the forward pass).  The convolution kernels are PERSISTENT: a launch is

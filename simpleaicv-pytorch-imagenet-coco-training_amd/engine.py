@@ -14,6 +14,7 @@ RetinaFPN.forward (simpleAICV/detection/models/fpn.py:60-87), RetinaClsHead/Reti
 import torch
 
 from . import ops
+from ._lib import lib, check
 from .ops import CF_RELU, CF_SIGMOID, CF_ACCUM, CF_MASK, PACK_FWD, PACK_DGRAD, PACK_STEM
 
 RESNET50_LAYERS = (3, 4, 6, 3)
@@ -199,10 +200,18 @@ class DetectorEngine:
         """The side stream waits for everything enqueued on the launch stream so far."""
         # events come from a small ring (creating / destroying ~150 HIP events per step showed up as multi-second host
         # stalls on a loaded box); a ring slot is reused only long after its wait has been enqueued
+        if self.device_scope_events:
+            check(lib.sacv_stream_wait_stream(self._side.cuda_stream, torch.cuda.current_stream().cuda_stream),
+                  'stream_wait_stream')
+            return
         ev = self._side_events[self._side_evi]
         self._side_evi = (self._side_evi + 1) % len(self._side_events)
         ev.record(torch.cuda.current_stream())
         self._side.wait_event(ev)
+
+    # Cross-stream ordering through the library's events (sacv_stream_wait_stream: no system-scope fence per record)
+    # instead of torch.cuda.Event / Stream.wait_stream.  False: torch's (A/B).
+    device_scope_events = True
 
     def _stage(self, on_stage, name, pre=None):
         """The gradients of exchange stage `name` are all enqueued (weight gradients on the side stream, the rest on the
@@ -230,7 +239,11 @@ class DetectorEngine:
 
     def _side_join(self):
         if self._side is not None and self._side_busy:
-            torch.cuda.current_stream().wait_stream(self._side)
+            if self.device_scope_events:
+                check(lib.sacv_stream_wait_stream(torch.cuda.current_stream().cuda_stream, self._side.cuda_stream),
+                      'stream_wait_stream')
+            else:
+                torch.cuda.current_stream().wait_stream(self._side)
             self._side_busy = False
             self._side_keep.clear()
 

@@ -171,3 +171,27 @@ def test_training_step_with_the_fused_stem():
     rel = {k: abs(g0[k] - g1[k]) / (g0[k] + 1e-12) for k in g0}
     assert max(rel.values()) <= 5e-2, sorted(rel.items(), key=lambda kv: -kv[1])[:3]
     assert rel['backbone.conv1.layer.0.weight'] <= 5e-2
+
+
+def test_stream_wait_stream_orders_two_streams():
+    """sacv_stream_wait_stream (events without a system-scope fence): a consumer on stream B behind a long producer on
+    stream A must see the producer's result -- every iteration (the LAST element of the buffer, written by the producer's
+    last workgroups), in both directions, and past the wrap of the event ring (300 > 256)."""
+    from sacv_amd._lib import lib, check
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    n, iters = 1 << 24, 300
+    x = torch.zeros(n, device='cuda')
+    snap = torch.zeros(iters, device='cuda')
+    torch.cuda.synchronize()
+    for it in range(iters):
+        prod, cons = (a, b) if it % 2 == 0 else (b, a)
+        with torch.cuda.stream(prod):
+            for _ in range(4):          # a producer chain long enough for an unordered consumer to overtake it
+                x.add_(0.25)
+        check(lib.sacv_stream_wait_stream(cons.cuda_stream, prod.cuda_stream), 'stream_wait_stream')
+        with torch.cuda.stream(cons):
+            snap[it:it + 1].copy_(x[-1:])
+        check(lib.sacv_stream_wait_stream(prod.cuda_stream, cons.cuda_stream), 'stream_wait_stream')  # cons reads x
+    torch.cuda.synchronize()
+    want = torch.arange(1, iters + 1, dtype=torch.float32, device='cuda')
+    assert torch.equal(snap, want), (snap - want).abs().max()

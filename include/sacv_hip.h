@@ -50,6 +50,12 @@ int sacv_abi_version(void);
  * is created with hipEventDisableTiming | hipEventDisableSystemFence: no system-scope cache writeback / invalidation per
  * record (nothing ordered this way leaves the device). */
 int sacv_stream_wait_stream(void* waiter, void* signaller);
+/* The same ordering through a ticket in device memory: a one-lane kernel on `signaller` stores it (release, agent scope),
+ * a one-lane kernel on `waiter` polls it -- no barrier packet that depends on another queue's signal.  The wait kernel is
+ * enqueued after its signal kernel (no deadlock on a shared hardware queue) and gives up after 2 s, counted by
+ * sacv_stream_ticket_timeouts() (synchronises; 0 in a healthy process).  At most 8 signalling streams per device. */
+int sacv_stream_wait_stream_ticket(void* waiter, void* signaller);
+long long sacv_stream_ticket_timeouts(void);
 
 /* Launch plan of the process's subsequent launches (one process drives one GPU; the plan is not per thread: a framework
  * may run the backward pass on another thread than the forward pass).  The convolution kernels are PERSISTENT: a launch is

@@ -17,6 +17,8 @@ SIGNATURES = {
     'sacv_last_error': (C.c_char_p, []),
     'sacv_abi_version': (I, []),
     'sacv_stream_wait_stream': (I, [P, P]),
+    'sacv_stream_wait_stream_ticket': (I, [P, P]),
+    'sacv_stream_ticket_timeouts': (LL, []),
     'sacv_launch_share': (I, [I, I, I, I, I, I, I, I]),
     'sacv_conv2d_gemm': (I, [I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, P, P]),
     'sacv_conv2d_gemm_stats_rows': (I, [I, P, P, P]),

@@ -173,11 +173,16 @@ def test_training_step_with_the_fused_stem():
     assert rel['backbone.conv1.layer.0.weight'] <= 5e-2
 
 
-def test_stream_wait_stream_orders_two_streams():
-    """sacv_stream_wait_stream (events without a system-scope fence): a consumer on stream B behind a long producer on
-    stream A must see the producer's result -- every iteration (the LAST element of the buffer, written by the producer's
-    last workgroups), in both directions, and past the wrap of the event ring (300 > 256)."""
-    from sacv_amd._lib import lib, check
+@pytest.mark.parametrize('fn', ['sacv_stream_wait_stream', 'sacv_stream_wait_stream_ticket'])
+def test_stream_wait_stream_orders_two_streams(fn):
+    """sacv_stream_wait_stream (events without a system-scope fence) / sacv_stream_wait_stream_ticket (a ticket in device
+    memory, polled by a one-lane kernel): a consumer on stream B behind a long producer on stream A must see the
+    producer's result -- every iteration (the LAST element of the buffer, written by the producer's last workgroups), in
+    both directions, and past the wrap of the event ring (300 > 256).  No ticket wait may have timed out."""
+    from sacv_amd._lib import lib as lib_, check
+
+    class lib:  # the function under test under one name
+        sacv_stream_wait_stream = staticmethod(getattr(lib_, fn))
     a, b = torch.cuda.Stream(), torch.cuda.Stream()
     n, iters = 1 << 24, 300
     x = torch.zeros(n, device='cuda')
@@ -195,3 +200,4 @@ def test_stream_wait_stream_orders_two_streams():
     torch.cuda.synchronize()
     want = torch.arange(1, iters + 1, dtype=torch.float32, device='cuda')
     assert torch.equal(snap, want), (snap - want).abs().max()
+    assert lib_.sacv_stream_ticket_timeouts() == 0

@@ -64,8 +64,9 @@ int sacv_stream_wait_stream_ticket(void* waiter, void* signaller) {
   unsigned long long* flag;
   unsigned long long ticket;
   unsigned long long* timeouts;
+  // the lock covers the two launches: tickets of one signalling stream reach its queue in ticket order whatever thread asks
+  std::lock_guard<std::mutex> lock(g_mu);
   {
-    std::lock_guard<std::mutex> lock(g_mu);
     TicketState& t = g_tickets[dev];
     if (!t.flags) {
       e = hipMalloc(&t.flags, (MAXS + 1) * sizeof(unsigned long long));
